@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: UNet denoise steps/s at BASELINE.json configs[1]
+(Residual_Attention_UNet_superres 128x128 -> 256x256, mag 2, batch 16 per GPU, cosine T=1500, eval mode).
+
+A "step" is one iteration of Diffusion.sample's loop (train_diffusion_superres.py:234-249 in the reference):
+UNet forward on a 16-image batch + fresh Gaussian noise + the ancestral update, with x, lr_img and the weights
+resident in HBM.  N GPUs run N independent 16-image batches (sampling shards by image, no collective on the data
+path) => weak scaling; `value` counts batch-steps of all ranks per second, `image_steps_per_s` = 16x that.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--impl direct|mfma_f32|mfma_bf16x3|mfma_f16]
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BATCH, IMAGE, MAG, T_STEPS = 16, 256, 2, 1500
+# algorithmic work per 16-image forward, SURVEY.md section 8(d) / BASELINE.md
+GFLOP_PER_FWD = 454.39
+MB_PER_FWD = 4998.3
+PEAK_TFLOPS = {"direct": 157.3, "mfma_f32": 157.3, "mfma_bf16x3": 2500.0, "mfma_f16": 2500.0}
+DTYPE = {"direct": "f32", "mfma_f32": "f32", "mfma_bf16x3": "bf16x3 (hi+lo split, f32 accumulate)",
+         "mfma_f16": "f16 (f32 accumulate)"}
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(sd, x, t, lr):
+    """The oracle (CPU port of the reference graph, stock torch ops) on this box's host cores: bounded sample of
+    the same workload = 1 warm-up + 2 timed 16-image forwards."""
+    from oracle import unet_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        unet_oracle.unet_forward(sd, x, t, lr, MAG)
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            unet_oracle.unet_forward(sd, x, t, lr, MAG)
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": 1.0 / best, "unit": "batch16_steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"2 timed eval forwards of the B=16 256x256 batch after 1 warm-up (min {best:.3f} s), "
+                      f"torch {torch.__version__} CPU ops, {platform.processor() or platform.machine()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--impl", default=os.environ.get("DRS_IMPL", "direct"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from diffusionremotesensing_amd import _lib, dist, hip_ops, synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    from diffusionremotesensing_amd.train_diffusion_superres import Diffusion
+
+    _lib.load()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device: there is no CPU path to measure")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+        dist.init_process_group("nccl")
+    rank = dist.rank()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model = Residual_Attention_UNet_superres(3, 3, dev)
+    sd = synthetic.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    engine = model.hip_engine()
+    engine.set_impl(args.impl)
+    diffusion = Diffusion("cosine", model, "/nonexistent/snapshot.pt", noise_steps=T_STEPS, device=dev,
+                          magnification_factor=MAG, image_size=IMAGE, Degradation_type="DownBlur")
+
+    # synthetic inputs of configs[1], different per rank
+    x_cpu = synthetic.tensor_normal("bench.x", (BATCH, 3, IMAGE, IMAGE), seed=rank)
+    lr_cpu = synthetic.tensor_uniform("bench.lr", (BATCH, 3, IMAGE // MAG, IMAGE // MAG), seed=rank)
+    x = x_cpu.to(dev)
+    lr = lr_cpu.to(dev)
+    t = torch.empty(BATCH, dtype=torch.int64, device=dev)
+
+    def step(i, first):
+        t.fill_(i)
+        eps = engine.forward(x, t, lr, MAG, reuse_cond=not first, check_weights=first)
+        noise = torch.randn_like(x) if i > 1 else None
+        hip_ops.sampler_step_(x, eps, noise, i, diffusion.alpha, diffusion.alpha_hat, diffusion.beta)
+
+    def sync():
+        if dist.is_initialized():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        i = T_STEPS - 1
+        for w in range(args.warmup):
+            step(i, w == 0)
+            i -= 1
+        if args.warmup == 0:
+            engine.forward(x, t.fill_(i), lr, MAG)  # conditioning + weights in place before the timed region
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(max(i, 1), False)
+            i -= 1
+        sync()
+        elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist.is_initialized():
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = el.item()
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # roofline of the dominant kernel family (the wide tap-convolutions): per-op HIP events on the launch stream
+        with torch.no_grad():
+            x.copy_(x_cpu)
+            ops = engine.profile_forward(x, t.fill_(750), lr, MAG, iters=5)
+        conv = [(n, ms, fl, by) for n, ms, fl, by in ops if fl > 0 and n not in ("lr_branch", "conv0")]
+        conv_ms = sum(o[1] for o in conv)
+        conv_fl = sum(o[2] for o in conv)
+        all_ms = sum(o[1] for o in ops)
+        top = sorted(ops, key=lambda o: -o[1])[:6]
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.impl]
+        roofline = {"bound": "mfma", "kernel": "tap-convolution family (%d launches/forward)" % len(conv),
+                    "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
+                    "traffic": None,
+                    "forward_ms_sum_of_ops": round(all_ms, 4), "conv_ms": round(conv_ms, 4),
+                    "hbm_equiv_GBs": round(MB_PER_FWD / 1e3 / (all_ms * 1e-3), 1),
+                    "hbm_equiv_frac": round(MB_PER_FWD / 1e3 / (all_ms * 1e-3) / HBM_PEAK_GBS, 5),
+                    "top_ops_ms": {n: round(ms, 4) for n, ms, _, _ in top}}
+        result = {
+            "metric": "unet_denoise_steps_per_s", "value": round(value, 4), "unit": "batch16_steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.impl],
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Residual_Attention_UNet_superres 128x128->256x256 mag=2 DownBlur, "
+                                   "batch 16 per GPU, cosine T=1500, eval-mode UNet forward + ancestral update per step",
+                       "batch_per_gpu": BATCH, "image_size": IMAGE, "noise_steps": T_STEPS, "impl": args.impl,
+                       "weights": "seeded random (no pretrained weights exist)"},
+            "image_steps_per_s": round(value * BATCH, 2),
+            "tflops_algorithmic": round(value * GFLOP_PER_FWD / 1e3, 3),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, x_cpu, torch.full((BATCH,), 750, dtype=torch.int64), lr_cpu)
+        print(json.dumps(result), flush=True)
+    if dist.is_initialized():
+        torch.distributed.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

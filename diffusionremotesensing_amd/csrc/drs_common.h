@@ -1,0 +1,95 @@
+// Shared host/device declarations of the gfx950 kernels behind include/drs_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/drs_hip.h"
+
+#define DRS_MAX_TAPS 9
+
+// One fused "tap convolution" over channels-last activations.  Every convolution flavour of the
+// UNet (3x3 s1, 3x3 s2, 1x1, 2x2 s2, and each of the 4 output phases of ConvTranspose 3x3 s2) is
+// an instance:
+//   logical output position (n, ty, tx), ty < TH, tx < TW
+//   physical output pixel   (ty*out_scale + out_oy, tx*out_scale + out_ox)
+//   tap i reads input pixel (ty*in_stride + dy[i], tx*in_stride + dx[i]), zero outside [0,H)x[0,W)
+//   acc[co] = sum_i sum_ci (in[..ci] + in_add[n][ci]) * w[wtap[i]][ci][co]
+// Epilogue (in this order, each step optional):
+//   v = acc * gate[n][oy/2][ox/2]  ->  v += bias[co]  ->  relu_pre  ->  v += post_add[n][co]
+//   -> v += res[n][oy][ox][co]  ->  relu_post  ->  sigmoid  ->  store (NHWC slice or NCHW)
+struct TapConv {
+  const float* in;
+  int in_cs, in_co;  // channel stride of the input buffer, first channel of the slice read
+  int N, H, W, Cin;
+  const float* w;     // layout depends on the kernel family (see pack kernels)
+  const void* w_aux;  // second weight image (e.g. low halves for split-bf16), or null
+  const float* bias;  // [Cout] or null
+  float* out;
+  int out_cs, out_co;
+  int OH, OW, Cout;
+  int TH, TW;
+  int in_stride, out_scale, out_oy, out_ox;
+  int ntaps;
+  int dy[DRS_MAX_TAPS], dx[DRS_MAX_TAPS], wtap[DRS_MAX_TAPS];
+  int wtaps_total;       // number of taps stored in w (stride between taps is Cin*Cout)
+  const float* in_add;   // [N][in_add_cs] (already offset to this layer's slice) or null
+  int in_add_cs;
+  const float* post_add; // [N][post_cs] (already offset to this layer's slice) or null
+  int post_cs;
+  const float* res;      // NHWC, same spatial size as out, or null
+  int res_cs, res_co;
+  int res_bstride_zero;  // 1: res has batch 1 and is broadcast over n
+  const float* gate;     // [N][OH/2][OW/2] or null
+  int relu_pre, relu_post, sigmoid;
+  int out_nchw;          // 1: out is (N,Cout,OH,OW) planar
+};
+
+struct DrsErr {
+  static void set(const char* fmt, ...);
+};
+
+#define DRS_CHECK_HIP(expr)                                                             \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      DrsErr::set("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return DRS_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define DRS_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) {                   \
+      DrsErr::set(__VA_ARGS__);      \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+static inline int drs_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- kernel launchers (each returns a DRS_* status) ------------------------------------------
+int drs_launch_tapconv_direct(const TapConv& d, hipStream_t s);
+int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s);
+bool drs_tapconv_mfma_supported(const TapConv& d, int impl);
+
+// weight packing: src is torch layout (Cout,Cin,KH,KW) or, transposed, (Cin,Cout,KH,KW).
+// bn = {gamma,beta,running_mean,running_var} or all null.  dst_w layout:
+//   DIRECT:  [tap][Cin][Cout]      MFMA: [tap][Cout][Cin]
+int drs_launch_pack_conv(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
+                         const float* rvar, float eps, float* dst_w, float* dst_b, int Cout, int Cin, int taps,
+                         int transposed, int mfma_layout, hipStream_t s);
+
+int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
+                            hipStream_t s);
+int drs_launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int src_cs, int src_co,
+                            hipStream_t s);
+
+// planar (NCHW) small-channel kernels
+int drs_launch_conv3x3_planar(const float* in, const float* w, const float* b, const float* res, float* out, int N,
+                              int Cin, int Cout, int H, int W, int relu, hipStream_t s);
+int drs_launch_stem(const float* in_nchw, const float* w, const float* b, const float* res_nhwc, int res_batch,
+                    float* out_nhwc, int N, int Cin, int Cout, int H, int W, hipStream_t s);
+int drs_launch_bicubic(const float* x, float* y, int N, int C, int H, int W, int scale, hipStream_t s);
+int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
+                        const float* b2, float* out, int out_stride, int B, int dim_in, int dim_out, hipStream_t s);

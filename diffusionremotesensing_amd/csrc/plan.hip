@@ -1,0 +1,709 @@
+// C-ABI of include/drs_hip.h: error state, the operator-level convolution entry and the
+// whole-UNet plan (weight packing + the launch schedule of one eval forward).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "drs_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error state
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void DrsErr::set(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* drs_last_error(void) { return g_err; }
+extern "C" int drs_abi_version(void) { return 1; }
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------
+// TapConv builders
+// ------------------------------------------------------------------------------------------------
+static TapConv conv_desc(const float* in, int N, int H, int W, int Cin, int in_cs, int in_co, const float* w,
+                         const float* bias, float* out, int Cout, int out_cs, int out_co, int KH, int KW, int stride,
+                         int pad) {
+  TapConv d = {};
+  d.in = in; d.in_cs = in_cs; d.in_co = in_co;
+  d.N = N; d.H = H; d.W = W; d.Cin = Cin;
+  d.w = w; d.bias = bias;
+  d.out = out; d.out_cs = out_cs; d.out_co = out_co;
+  d.OH = (H + 2 * pad - KH) / stride + 1;
+  d.OW = (W + 2 * pad - KW) / stride + 1;
+  d.Cout = Cout;
+  d.TH = d.OH; d.TW = d.OW;
+  d.in_stride = stride; d.out_scale = 1; d.out_oy = 0; d.out_ox = 0;
+  d.ntaps = KH * KW;
+  d.wtaps_total = KH * KW;
+  for (int ky = 0; ky < KH; ++ky)
+    for (int kx = 0; kx < KW; ++kx) {
+      const int i = ky * KW + kx;
+      d.dy[i] = ky - pad; d.dx[i] = kx - pad; d.wtap[i] = i;
+    }
+  return d;
+}
+
+// Phase (py,px) of ConvTranspose2d(k=3, s=2, p=1, output_padding=1): out[2*iy - 1 + ky] += in[iy] * w[ky]
+// (reference UpConvBlock.transform, UNet_model_superres.py:185).  Even output rows take ky=1 from iy=t; odd rows
+// take ky=0 from iy=t+1 and ky=2 from iy=t.  Output is (2H, 2W).
+static TapConv convT_phase_desc(const float* in, int N, int H, int W, int Cin, int in_cs, int in_co, const float* w,
+                                const float* bias, float* out, int Cout, int out_cs, int out_co, int py, int px) {
+  TapConv d = {};
+  d.in = in; d.in_cs = in_cs; d.in_co = in_co;
+  d.N = N; d.H = H; d.W = W; d.Cin = Cin;
+  d.w = w; d.bias = bias;
+  d.out = out; d.out_cs = out_cs; d.out_co = out_co;
+  d.OH = 2 * H; d.OW = 2 * W; d.Cout = Cout;
+  d.TH = H; d.TW = W;
+  d.in_stride = 1; d.out_scale = 2; d.out_oy = py; d.out_ox = px;
+  d.wtaps_total = 9;
+  int ydy[2], yk[2], ny, xdx[2], xk[2], nx;
+  if (py == 0) { ny = 1; ydy[0] = 0; yk[0] = 1; } else { ny = 2; ydy[0] = 1; yk[0] = 0; ydy[1] = 0; yk[1] = 2; }
+  if (px == 0) { nx = 1; xdx[0] = 0; xk[0] = 1; } else { nx = 2; xdx[0] = 1; xk[0] = 0; xdx[1] = 0; xk[1] = 2; }
+  int i = 0;
+  for (int a = 0; a < ny; ++a)
+    for (int b = 0; b < nx; ++b, ++i) {
+      d.dy[i] = ydy[a]; d.dx[i] = xdx[b]; d.wtap[i] = yk[a] * 3 + xk[b];
+    }
+  d.ntaps = i;
+  return d;
+}
+
+static int run_conv(const TapConv& d, int impl, hipStream_t s) {
+  if (impl != DRS_IMPL_DIRECT && drs_tapconv_mfma_supported(d, impl)) return drs_launch_tapconv_mfma(d, impl, s);
+  return drs_launch_tapconv_direct(d, s);
+}
+// algorithmic work of one tap-convolution (SURVEY.md 8(d) model: 2*MACs; fp32 input + output + weights)
+static double conv_flops(const TapConv& d) { return 2.0 * d.N * d.TH * d.TW * (double)d.Cout * d.Cin * d.ntaps; }
+static double conv_bytes(const TapConv& d, bool count_out_once = true) {
+  const double in = (double)d.N * d.H * d.W * d.Cin, out = (double)d.N * d.TH * d.TW * d.Cout;
+  (void)count_out_once;
+  return 4.0 * (in + out + (double)d.ntaps * d.Cin * d.Cout);
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator-level convolution (NCHW boundary)
+// ------------------------------------------------------------------------------------------------
+static bool conv_flavour_ok(int KH, int KW, int stride, int pad, int transposed, int out_pad) {
+  if (transposed) return KH == 3 && KW == 3 && stride == 2 && pad == 1 && out_pad == 1;
+  if (KH == 3 && KW == 3 && pad == 1 && (stride == 1 || stride == 2)) return true;
+  if (KH == 1 && KW == 1 && pad == 0 && stride == 1) return true;
+  if (KH == 2 && KW == 2 && pad == 0 && stride == 2) return true;
+  return false;
+}
+static void conv_out_hw(int H, int W, int KH, int KW, int stride, int pad, int transposed, int out_pad, int* OH,
+                        int* OW) {
+  if (transposed) {
+    *OH = (H - 1) * stride - 2 * pad + KH + out_pad;
+    *OW = (W - 1) * stride - 2 * pad + KW + out_pad;
+  } else {
+    *OH = (H + 2 * pad - KH) / stride + 1;
+    *OW = (W + 2 * pad - KW) / stride + 1;
+  }
+}
+
+extern "C" size_t drs_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                                             int transposed, int out_pad) {
+  int OH, OW;
+  conv_out_hw(H, W, KH, KW, stride, pad, transposed, out_pad, &OH, &OW);
+  size_t b = 0;
+  b += align_up((size_t)N * H * W * Cin * 4);
+  b += align_up((size_t)N * OH * OW * Cout * 4);
+  b += 2 * align_up((size_t)Cout * Cin * KH * KW * 4);
+  b += align_up((size_t)Cout * 4);
+  return b + 256;
+}
+
+extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
+                               int Cout, int KH, int KW, int stride, int pad, int transposed, int out_pad, int relu,
+                               void* workspace, size_t workspace_bytes, int impl, drs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DRS_REQUIRE(x && w && y && workspace, DRS_ERR_ARG, "conv2d: null pointer");
+  DRS_REQUIRE(N >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DRS_ERR_SHAPE, "conv2d: bad dims");
+  DRS_REQUIRE(conv_flavour_ok(KH, KW, stride, pad, transposed, out_pad), DRS_ERR_SHAPE,
+              "conv2d: unsupported flavour k=%dx%d s=%d p=%d transposed=%d out_pad=%d", KH, KW, stride, pad, transposed,
+              out_pad);
+  DRS_REQUIRE(impl >= DRS_IMPL_DIRECT && impl <= DRS_IMPL_MFMA_F16, DRS_ERR_ARG, "conv2d: impl=%d", impl);
+  DRS_REQUIRE(workspace_bytes >= drs_conv2d_workspace_bytes(N, Cin, H, W, Cout, KH, KW, stride, pad, transposed, out_pad),
+              DRS_ERR_WORKSPACE, "conv2d: workspace too small");
+  if (N == 0) return DRS_OK;
+  int OH, OW;
+  conv_out_hw(H, W, KH, KW, stride, pad, transposed, out_pad, &OH, &OW);
+  DRS_REQUIRE(OH > 0 && OW > 0, DRS_ERR_SHAPE, "conv2d: empty output");
+  char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float* xin = (float*)base; base += align_up((size_t)N * H * W * Cin * 4);
+  float* yout = (float*)base; base += align_up((size_t)N * OH * OW * Cout * 4);
+  float* pw = (float*)base; base += 2 * align_up((size_t)Cout * Cin * KH * KW * 4);
+  float* pb = (float*)base;
+  int rc;
+  if ((rc = drs_launch_nchw_to_nhwc(x, xin, N, Cin, H, W, Cin, 0, s))) return rc;
+
+  // decide the kernel family on a probe descriptor, then pack in that family's layout
+  TapConv probe = transposed ? convT_phase_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0, 1, 1)
+                             : conv_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0, KH, KW, stride, pad);
+  const bool mfma = impl != DRS_IMPL_DIRECT && drs_tapconv_mfma_supported(probe, impl);
+  if ((rc = drs_launch_pack_conv(w, b, nullptr, nullptr, nullptr, nullptr, 0.f, pw, pb, Cout, Cin, KH * KW, transposed,
+                                 mfma ? 1 : 0, s)))
+    return rc;
+  const int use_impl = mfma ? impl : DRS_IMPL_DIRECT;
+  if (!transposed) {
+    TapConv d = probe;
+    d.relu_pre = relu;
+    if ((rc = run_conv(d, use_impl, s))) return rc;
+  } else {
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        TapConv d = convT_phase_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0, py, px);
+        d.relu_pre = relu;
+        if ((rc = run_conv(d, use_impl, s))) return rc;
+      }
+  }
+  return drs_launch_nhwc_to_nchw(yout, y, N, Cout, OH, OW, Cout, 0, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// UNet plan
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Param { std::string name; int64_t numel; };
+
+struct ConvLayer {
+  int w = -1, b = -1, bn = -1;  // param indices; bn = index of gamma (beta, mean, var follow)
+  int Cout = 0, Cin = 0, taps = 0;
+  bool transposed = false, mfma = false;
+  size_t w_off = 0, b_off = 0;
+};
+struct PlanarConv { int w = -1, b = -1; int Cout = 0, Cin = 0; size_t w_off = 0, b_off = 0; };
+struct Mlp { int w1, b1, w2, b2, dim; size_t o_w1, o_b1, o_w2, o_b2; int temb_off; };
+
+struct WsTensor {
+  std::string name;
+  size_t off;  // bytes into workspace
+  int n, c, h, w;
+  int cs, co;   // channel stride / offset (NHWC); planar tensors have cs = 0
+  bool planar;
+};
+
+struct ResBlock { ConvLayer conv1, conv2, shortcut, skip; bool has_skip; Mlp mlp; };
+struct DecStage { ConvLayer gate, wg, wx, psi, result, conv, transform, upconv; Mlp mlp; };
+
+}  // namespace
+
+struct drs_plan {
+  drs_unet_config cfg;
+  std::vector<Param> params;
+  std::vector<ConvLayer*> convs;
+  std::vector<PlanarConv*> planars;
+  std::vector<Mlp*> mlps;
+  std::vector<WsTensor> tensors;
+
+  PlanarConv rrdb[7];
+  PlanarConv stem0, stemc;  // conv0, conv_upsampled_lr_img (raw torch layout)
+  ResBlock enc[4];          // conv_blocks.0..2, bottle_neck
+  ConvLayer downs[3];
+  DecStage dec[3];
+  ConvLayer output;
+
+  size_t packed_bytes = 0, ws_bytes = 0;
+  size_t o_inv_freq = 0;
+  int temb_total = 0;
+  bool packed_ok = false;
+  const void* packed_ptr = nullptr;
+
+  // optional per-op timing (drs_unet_profile_*): events recorded on the forward's stream
+  struct OpRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
+  bool profiling = false;
+  std::vector<OpRec> ops;
+
+  // workspace offsets
+  size_t o_lr[3], o_up, o_temb;
+  int t_cond, t_x0, t_S[4], t_K0, t_H[4], t_R[4], t_D[3];
+  int t_G[3], t_Q[3], t_P[3], t_PSI[3], t_U[3], t_CAT[3], t_X[3];
+  int t_lrenc, t_up;
+
+  int P(const std::string& name, int64_t numel) {
+    params.push_back({name, numel});
+    return (int)params.size() - 1;
+  }
+  ConvLayer mk_conv(const std::string& pfx, int Cout, int Cin, int taps, const std::string& bn_pfx = "",
+                    bool transposed = false) {
+    ConvLayer L;
+    L.Cout = Cout; L.Cin = Cin; L.taps = taps; L.transposed = transposed;
+    L.w = P(pfx + ".weight", (int64_t)Cout * Cin * taps);
+    L.b = P(pfx + ".bias", Cout);
+    if (!bn_pfx.empty()) {
+      L.bn = P(bn_pfx + ".weight", Cout);
+      P(bn_pfx + ".bias", Cout);
+      P(bn_pfx + ".running_mean", Cout);
+      P(bn_pfx + ".running_var", Cout);
+    }
+    return L;
+  }
+  PlanarConv mk_planar(const std::string& pfx, int Cout, int Cin) {
+    PlanarConv L;
+    L.Cout = Cout; L.Cin = Cin;
+    L.w = P(pfx + ".weight", (int64_t)Cout * Cin * 9);
+    L.b = P(pfx + ".bias", Cout);
+    return L;
+  }
+  Mlp mk_mlp(const std::string& pfx, int dim) {
+    Mlp m;
+    m.dim = dim;
+    m.w1 = P(pfx + ".0.weight", (int64_t)dim * 100);
+    m.b1 = P(pfx + ".0.bias", dim);
+    m.w2 = P(pfx + ".2.weight", (int64_t)dim * dim);
+    m.b2 = P(pfx + ".2.bias", dim);
+    m.temb_off = temb_total;
+    temb_total += dim;
+    return m;
+  }
+  int T(const std::string& name, size_t& cursor, int n, int c, int h, int w, bool planar = false) {
+    WsTensor t{name, cursor, n, c, h, w, planar ? 0 : c, 0, planar};
+    cursor += align_up((size_t)n * c * h * w * 4);
+    tensors.push_back(t);
+    return (int)tensors.size() - 1;
+  }
+  int Tview(const std::string& name, int base, int c, int co) {
+    WsTensor t = tensors[base];
+    t.name = name; t.c = c; t.co = co;
+    tensors.push_back(t);
+    return (int)tensors.size() - 1;
+  }
+  float* tp(void* ws, int i) const { return (float*)((char*)ws + tensors[i].off); }
+};
+
+static const int kDown[5] = {16, 32, 64, 128, 256};
+static const int kUp[5] = {256, 128, 64, 32, 16};
+
+extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) {
+  DRS_REQUIRE(out && cfg, DRS_ERR_ARG, "plan_create: null pointer");
+  DRS_REQUIRE(cfg->batch >= 1 && (cfg->lr_batch == cfg->batch || cfg->lr_batch == 1), DRS_ERR_SHAPE,
+              "plan_create: batch=%d lr_batch=%d (lr batch must equal batch or be 1)", cfg->batch, cfg->lr_batch);
+  DRS_REQUIRE(cfg->image_channels >= 1 && cfg->image_channels <= 4 && cfg->out_dim >= 1, DRS_ERR_SHAPE,
+              "plan_create: image_channels=%d out_dim=%d", cfg->image_channels, cfg->out_dim);
+  DRS_REQUIRE(cfg->magnification >= 1 && cfg->height > 0 && cfg->width > 0 && cfg->height % 8 == 0 &&
+                  cfg->width % 8 == 0 && cfg->height % cfg->magnification == 0 && cfg->width % cfg->magnification == 0,
+              DRS_ERR_SHAPE, "plan_create: H=%d W=%d must be divisible by 8 and by magnification=%d", cfg->height,
+              cfg->width, cfg->magnification);
+  DRS_REQUIRE(cfg->impl >= DRS_IMPL_DIRECT && cfg->impl <= DRS_IMPL_MFMA_F16, DRS_ERR_ARG, "plan_create: impl=%d",
+              cfg->impl);
+  drs_plan* p = new drs_plan();
+  p->cfg = *cfg;
+  if (p->cfg.bn_eps <= 0.f) p->cfg.bn_eps = 1e-5f;
+  const int C = cfg->image_channels;
+
+  // ---- parameters, in a fixed canonical order (names = reference state_dict keys) ----
+  p->stem0 = p->mk_planar("conv0", kDown[0], C);
+  for (int i = 0; i < 3; ++i) {
+    p->rrdb[2 * i] = p->mk_planar("LR_encoder.blocks." + std::to_string(i) + ".conv1", C, C);
+    p->rrdb[2 * i + 1] = p->mk_planar("LR_encoder.blocks." + std::to_string(i) + ".conv2", C, C);
+  }
+  p->rrdb[6] = p->mk_planar("LR_encoder.conv_out", C, C);
+  p->stemc = p->mk_planar("conv_upsampled_lr_img", kDown[0], C);
+  for (int i = 0; i < 4; ++i) {
+    const std::string pfx = i < 3 ? "conv_blocks." + std::to_string(i) : std::string("bottle_neck");
+    const int ci = kDown[i], co = kDown[i + 1];
+    ResBlock& rb = p->enc[i];
+    rb.mlp = p->mk_mlp(pfx + ".time_mlp", co);
+    rb.conv1 = p->mk_conv(pfx + ".conv1.0", co, ci, 9, pfx + ".batch_norm1");
+    rb.conv2 = p->mk_conv(pfx + ".conv2.0", co, co, 9, pfx + ".batch_norm2");
+    rb.shortcut = p->mk_conv(pfx + ".shortcut_conv.0", co, ci, 1, pfx + ".shortcut_batch_norm");
+    rb.has_skip = (i == 0);
+    if (rb.has_skip) rb.skip = p->mk_conv(pfx + ".conv_upsampled_lr_img", co, ci, 9);
+    if (i < 3) p->downs[i] = p->mk_conv("downs." + std::to_string(i), co, co, 9);
+  }
+  for (int i = 0; i < 3; ++i) {
+    const std::string si = std::to_string(i);
+    const int Cc = kUp[i], Ch = kUp[i + 1];
+    DecStage& d = p->dec[i];
+    d.gate = p->mk_conv("gating_signals." + si + ".conv", Ch, Cc, 1, "gating_signals." + si + ".batch_norm");
+    d.wg = p->mk_conv("attention_blocks." + si + ".w_g.0", Ch, Ch, 1);
+    d.wx = p->mk_conv("attention_blocks." + si + ".w_x.0", Ch, Ch, 4);
+    d.psi = p->mk_conv("attention_blocks." + si + ".psi.0", 1, Ch, 1);
+    d.result = p->mk_conv("attention_blocks." + si + ".result.0", Ch, Ch, 1, "attention_blocks." + si + ".result.1");
+    d.mlp = p->mk_mlp("ups." + si + ".time_mlp", Cc);
+    d.conv = p->mk_conv("ups." + si + ".conv", Cc, Cc, 9, "ups." + si + ".batch_norm");
+    d.transform = p->mk_conv("ups." + si + ".transform", Cc, Cc, 9, "", true);
+    d.upconv = p->mk_conv("up_convs." + si, Ch, Cc + Ch, 9);
+  }
+  p->output = p->mk_conv("output", cfg->out_dim, kUp[3], 1);
+
+  // ---- registries ----
+  for (int i = 0; i < 4; ++i) {
+    p->convs.push_back(&p->enc[i].conv1);
+    p->convs.push_back(&p->enc[i].conv2);
+    p->convs.push_back(&p->enc[i].shortcut);
+    if (p->enc[i].has_skip) p->convs.push_back(&p->enc[i].skip);
+    p->mlps.push_back(&p->enc[i].mlp);
+    if (i < 3) p->convs.push_back(&p->downs[i]);
+  }
+  for (int i = 0; i < 3; ++i) {
+    DecStage& d = p->dec[i];
+    ConvLayer* ls[] = {&d.gate, &d.wg, &d.wx, &d.psi, &d.result, &d.conv, &d.transform, &d.upconv};
+    for (ConvLayer* l : ls) p->convs.push_back(l);
+    p->mlps.push_back(&d.mlp);
+  }
+  p->convs.push_back(&p->output);
+  p->planars.push_back(&p->stem0);
+  for (int i = 0; i < 7; ++i) p->planars.push_back(&p->rrdb[i]);
+  p->planars.push_back(&p->stemc);
+
+  // ---- packed buffer layout ----
+  size_t cur = 0;
+  p->o_inv_freq = cur; cur += align_up(50 * 4);
+  for (ConvLayer* L : p->convs) {
+    L->w_off = cur; cur += 2 * align_up((size_t)L->Cout * L->Cin * L->taps * 4);  // room for a split/aux image
+    L->b_off = cur; cur += align_up((size_t)L->Cout * 4);
+  }
+  for (PlanarConv* L : p->planars) {
+    L->w_off = cur; cur += align_up((size_t)L->Cout * L->Cin * 9 * 4);
+    L->b_off = cur; cur += align_up((size_t)L->Cout * 4);
+  }
+  for (Mlp* m : p->mlps) {
+    m->o_w1 = cur; cur += align_up((size_t)m->dim * 100 * 4);
+    m->o_b1 = cur; cur += align_up((size_t)m->dim * 4);
+    m->o_w2 = cur; cur += align_up((size_t)m->dim * m->dim * 4);
+    m->o_b2 = cur; cur += align_up((size_t)m->dim * 4);
+  }
+  p->packed_bytes = cur;
+
+  // ---- workspace layout ----
+  const int B = cfg->batch, Bl = cfg->lr_batch, H = cfg->height, W = cfg->width, mag = cfg->magnification;
+  const int h = H / mag, w = W / mag;
+  size_t ws = 0;
+  for (int i = 0; i < 3; ++i) { p->o_lr[i] = ws; ws += align_up((size_t)Bl * C * h * w * 4); }
+  p->o_temb = ws; ws += align_up((size_t)B * p->temb_total * 4);
+  p->t_lrenc = p->T("LR_encoder", ws, Bl, C, h, w, true);
+  p->t_up = p->T("upsampled_lr_img", ws, Bl, C, H, W, true);
+  p->t_cond = p->T("cond", ws, Bl, kDown[0], H, W);
+  p->t_x0 = p->T("x0", ws, B, kDown[0], H, W);
+  for (int i = 0; i < 4; ++i) {
+    const int co = kDown[i + 1], hh = H >> i, ww = W >> i;
+    const std::string nm = i < 3 ? "conv_blocks." + std::to_string(i) : std::string("bottle_neck");
+    p->t_S[i] = p->T(nm + ".shortcut", ws, B, co, hh, ww);
+    if (i == 0) p->t_K0 = p->T(nm + ".skip", ws, B, co, hh, ww);
+    p->t_H[i] = p->T(nm + ".h", ws, B, co, hh, ww);
+    p->t_R[i] = p->T(nm, ws, B, co, hh, ww);
+    if (i < 3) p->t_D[i] = p->T("downs." + std::to_string(i), ws, B, co, hh / 2, ww / 2);
+  }
+  for (int i = 0; i < 3; ++i) {
+    const std::string si = std::to_string(i);
+    const int Cc = kUp[i], Ch = kUp[i + 1];
+    const int lh = H >> (3 - i), lw = W >> (3 - i);
+    p->t_G[i] = p->T("gating_signals." + si, ws, B, Ch, lh, lw);
+    p->t_Q[i] = p->T("attention_blocks." + si + ".g1", ws, B, Ch, lh, lw);
+    p->t_P[i] = p->T("attention_blocks." + si + ".relu", ws, B, Ch, lh, lw);
+    p->t_PSI[i] = p->T("attention_blocks." + si + ".psi", ws, B, 1, lh, lw);
+    p->t_U[i] = p->T("ups." + si + ".conv", ws, B, Cc, lh, lw);
+    p->t_CAT[i] = p->T("cat." + si, ws, B, Cc + Ch, 2 * lh, 2 * lw);
+    p->Tview("ups." + si, p->t_CAT[i], Cc, 0);
+    p->Tview("attention_blocks." + si, p->t_CAT[i], Ch, Cc);
+    p->t_X[i] = p->T("up_convs." + si, ws, B, Ch, 2 * lh, 2 * lw);
+  }
+  p->ws_bytes = ws + 256;
+  *out = p;
+  return DRS_OK;
+}
+
+extern "C" void drs_unet_plan_destroy(drs_plan* plan) { delete plan; }
+extern "C" int drs_unet_num_params(const drs_plan* plan) { return plan ? (int)plan->params.size() : 0; }
+extern "C" const char* drs_unet_param_name(const drs_plan* plan, int i) {
+  return (plan && i >= 0 && i < (int)plan->params.size()) ? plan->params[i].name.c_str() : nullptr;
+}
+extern "C" int64_t drs_unet_param_numel(const drs_plan* plan, int i) {
+  return (plan && i >= 0 && i < (int)plan->params.size()) ? plan->params[i].numel : -1;
+}
+extern "C" size_t drs_unet_packed_bytes(const drs_plan* plan) { return plan ? plan->packed_bytes + 256 : 0; }
+extern "C" size_t drs_unet_workspace_bytes(const drs_plan* plan) { return plan ? plan->ws_bytes : 0; }
+
+static inline char* aligned_base(const void* p) { return (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
+
+extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, const float* inv_freq_host,
+                                     void* packed, size_t packed_bytes, drs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DRS_REQUIRE(plan && params && inv_freq_host && packed, DRS_ERR_ARG, "pack_weights: null pointer");
+  DRS_REQUIRE(packed_bytes >= drs_unet_packed_bytes(plan), DRS_ERR_WORKSPACE, "pack_weights: packed buffer too small");
+  for (size_t i = 0; i < plan->params.size(); ++i)
+    DRS_REQUIRE(params[i], DRS_ERR_ARG, "pack_weights: param %s is null", plan->params[i].name.c_str());
+  char* base = aligned_base(packed);
+  auto F = [&](int i) { return (const float*)params[i]; };
+  int rc;
+  DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_inv_freq, inv_freq_host, 50 * 4, hipMemcpyHostToDevice, s));
+  const int impl = plan->cfg.impl;
+  for (ConvLayer* L : plan->convs) {
+    // kernel family per layer: decided on shape alone
+    TapConv probe = {};
+    probe.Cin = L->Cin; probe.Cout = L->Cout; probe.ntaps = L->taps;
+    L->mfma = impl != DRS_IMPL_DIRECT && drs_tapconv_mfma_supported(probe, impl);
+    const float *g = nullptr, *be = nullptr, *rm = nullptr, *rv = nullptr;
+    if (L->bn >= 0) { g = F(L->bn); be = F(L->bn + 1); rm = F(L->bn + 2); rv = F(L->bn + 3); }
+    if ((rc = drs_launch_pack_conv(F(L->w), F(L->b), g, be, rm, rv, plan->cfg.bn_eps, (float*)(base + L->w_off),
+                                   (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0,
+                                   L->mfma ? 1 : 0, s)))
+      return rc;
+  }
+  for (PlanarConv* L : plan->planars) {
+    DRS_CHECK_HIP(hipMemcpyAsync(base + L->w_off, F(L->w), (size_t)L->Cout * L->Cin * 9 * 4, hipMemcpyDeviceToDevice, s));
+    DRS_CHECK_HIP(hipMemcpyAsync(base + L->b_off, F(L->b), (size_t)L->Cout * 4, hipMemcpyDeviceToDevice, s));
+  }
+  for (Mlp* m : plan->mlps) {
+    DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_w1, F(m->w1), (size_t)m->dim * 100 * 4, hipMemcpyDeviceToDevice, s));
+    DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_b1, F(m->b1), (size_t)m->dim * 4, hipMemcpyDeviceToDevice, s));
+    DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_w2, F(m->w2), (size_t)m->dim * m->dim * 4, hipMemcpyDeviceToDevice, s));
+    DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_b2, F(m->b2), (size_t)m->dim * 4, hipMemcpyDeviceToDevice, s));
+  }
+  plan->packed_ok = true;
+  plan->packed_ptr = packed;
+  return DRS_OK;
+}
+
+static void prof_begin(drs_plan* plan, const std::string& name, double flops, double bytes, hipStream_t s) {
+  if (!plan->profiling) return;
+  drs_plan::OpRec r{name, flops, bytes, nullptr, nullptr};
+  hipEventCreate(&r.e0);
+  hipEventCreate(&r.e1);
+  hipEventRecord(r.e0, s);
+  plan->ops.push_back(r);
+}
+static void prof_end(drs_plan* plan, hipStream_t s) {
+  if (plan->profiling) hipEventRecord(plan->ops.back().e1, s);
+}
+static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d, hipStream_t s) {
+  std::string name = plan->params[L.w].name;
+  name = name.substr(0, name.size() - 7);  // strip ".weight"
+  if (d.out_scale == 2) name += ".phase" + std::to_string(d.out_oy * 2 + d.out_ox);
+  prof_begin(plan, name, conv_flops(d), conv_bytes(d), s);
+  const int rc = run_conv(d, L.mfma ? plan->cfg.impl : DRS_IMPL_DIRECT, s);
+  prof_end(plan, s);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward schedule
+// ------------------------------------------------------------------------------------------------
+extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float* x, const int64_t* t,
+                                const float* lr_img, float* out, void* workspace, size_t workspace_bytes, int flags,
+                                drs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DRS_REQUIRE(plan && packed && x && t && out && workspace, DRS_ERR_ARG, "forward: null pointer");
+  DRS_REQUIRE(plan->packed_ok && plan->packed_ptr == packed, DRS_ERR_STATE,
+              "forward: weights not packed into this buffer (call drs_unet_pack_weights first)");
+  DRS_REQUIRE(workspace_bytes >= plan->ws_bytes, DRS_ERR_WORKSPACE, "forward: workspace %zu < %zu", workspace_bytes,
+              plan->ws_bytes);
+  const bool reuse_cond = (flags & DRS_FWD_REUSE_COND) != 0;
+  DRS_REQUIRE(reuse_cond || lr_img, DRS_ERR_ARG, "forward: lr_img is null");
+  const drs_unet_config& c = plan->cfg;
+  const int B = c.batch, Bl = c.lr_batch, C = c.image_channels, H = c.height, W = c.width, mag = c.magnification;
+  const int h = H / mag, w = W / mag;
+  const int impl = c.impl;
+  char* pk = aligned_base(packed);
+  void* ws = aligned_base(workspace);
+  auto PW = [&](const ConvLayer& L) { return (const float*)(pk + L.w_off); };
+  auto PB = [&](const ConvLayer& L) { return (const float*)(pk + L.b_off); };
+  auto TP = [&](int i) { return plan->tp(ws, i); };
+  auto CI = [&](const ConvLayer& L) { return L.mfma ? impl : DRS_IMPL_DIRECT; };
+  int rc;
+  if (plan->profiling) {
+    for (auto& r : plan->ops) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    plan->ops.clear();
+  }
+#define RUN(expr) do { if ((rc = (expr))) return rc; } while (0)
+
+  // --- time embeddings for the 7 blocks (reference :338-339 + every time_mlp) ---
+  float* temb = (float*)((char*)ws + plan->o_temb);
+  const float* inv_freq = (const float*)(pk + plan->o_inv_freq);
+  prof_begin(plan, "time_mlp", 0, 0, s);
+  for (Mlp* m : plan->mlps)
+    RUN(drs_launch_time_mlp(t, inv_freq, (const float*)(pk + m->o_w1), (const float*)(pk + m->o_b1),
+                            (const float*)(pk + m->o_w2), (const float*)(pk + m->o_b2), temb + m->temb_off,
+                            plan->temb_total, B, 100, m->dim, s));
+  prof_end(plan, s);
+
+  // --- LR conditioning branch: RRDB -> bicubic -> conv (reference :345-353), constant per sampling chain ---
+  if (!reuse_cond) {
+    prof_begin(plan, "lr_branch", 2.0 * Bl * (7.0 * h * w * C * C * 9 + (double)H * W * C * kDown[0] * 9),
+               4.0 * Bl * (15.0 * h * w * C + (double)H * W * (2 * C + kDown[0])), s);
+    float* a = (float*)((char*)ws + plan->o_lr[0]);
+    float* b = (float*)((char*)ws + plan->o_lr[1]);
+    float* r = (float*)((char*)ws + plan->o_lr[2]);
+    const float* cur = lr_img;
+    for (int i = 0; i < 3; ++i) {
+      const PlanarConv& c1 = plan->rrdb[2 * i];
+      const PlanarConv& c2 = plan->rrdb[2 * i + 1];
+      RUN(drs_launch_conv3x3_planar(cur, (const float*)(pk + c1.w_off), (const float*)(pk + c1.b_off), nullptr, a, Bl,
+                                    C, C, h, w, 1, s));
+      float* dst = (cur == b) ? r : b;  // ping-pong so the residual source stays intact
+      RUN(drs_launch_conv3x3_planar(a, (const float*)(pk + c2.w_off), (const float*)(pk + c2.b_off), cur, dst, Bl, C,
+                                    C, h, w, 0, s));
+      cur = dst;
+    }
+    const PlanarConv& co = plan->rrdb[6];
+    RUN(drs_launch_conv3x3_planar(cur, (const float*)(pk + co.w_off), (const float*)(pk + co.b_off), lr_img,
+                                  TP(plan->t_lrenc), Bl, C, C, h, w, 0, s));
+    RUN(drs_launch_bicubic(TP(plan->t_lrenc), TP(plan->t_up), Bl, C, h, w, mag, s));
+    RUN(drs_launch_stem(TP(plan->t_up), (const float*)(pk + plan->stemc.w_off), (const float*)(pk + plan->stemc.b_off),
+                        nullptr, 0, TP(plan->t_cond), Bl, C, kDown[0], H, W, s));
+    prof_end(plan, s);
+  }
+  // --- x = conv0(x) + cond (reference :342,:355) ---
+  prof_begin(plan, "conv0", 2.0 * B * H * W * C * kDown[0] * 9, 4.0 * B * H * W * (C + 2.0 * kDown[0]), s);
+  RUN(drs_launch_stem(x, (const float*)(pk + plan->stem0.w_off), (const float*)(pk + plan->stem0.b_off),
+                      TP(plan->t_cond), Bl, TP(plan->t_x0), B, C, kDown[0], H, W, s));
+  prof_end(plan, s);
+
+  // --- encoder + bottleneck: ResConvBlock (reference :153-172), downs (:366) ---
+  const float* xin = TP(plan->t_x0);
+  for (int i = 0; i < 4; ++i) {
+    const ResBlock& rb = plan->enc[i];
+    const int ci = kDown[i], co = kDown[i + 1], hh = H >> i, ww = W >> i;
+    {  // shortcut = BNs(conv1x1(x))
+      TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.shortcut), PB(rb.shortcut), TP(plan->t_S[i]), co, co, 0, 1,
+                            1, 1, 0);
+      RUN(plan_conv(plan, rb.shortcut, d, s));
+    }
+    if (rb.has_skip) {  // conv_upsampled_lr_img(x_skip), x_skip == block input
+      TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.skip), PB(rb.skip), TP(plan->t_K0), co, co, 0, 3, 3, 1, 1);
+      RUN(plan_conv(plan, rb.skip, d, s));
+    }
+    {  // h = relu(BN1(conv1(x))) [+ skip] + relu(time_mlp(t))
+      TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.conv1), PB(rb.conv1), TP(plan->t_H[i]), co, co, 0, 3, 3, 1,
+                            1);
+      d.relu_pre = 1;
+      d.post_add = temb + rb.mlp.temb_off; d.post_cs = plan->temb_total;
+      if (rb.has_skip) { d.res = TP(plan->t_K0); d.res_cs = co; d.res_co = 0; }
+      RUN(plan_conv(plan, rb.conv1, d, s));
+    }
+    {  // out = relu(shortcut + BN2(conv2(h)))
+      TapConv d = conv_desc(TP(plan->t_H[i]), B, hh, ww, co, co, 0, PW(rb.conv2), PB(rb.conv2), TP(plan->t_R[i]), co,
+                            co, 0, 3, 3, 1, 1);
+      d.res = TP(plan->t_S[i]); d.res_cs = co; d.res_co = 0;
+      d.relu_post = 1;
+      RUN(plan_conv(plan, rb.conv2, d, s));
+    }
+    if (i < 3) {
+      TapConv d = conv_desc(TP(plan->t_R[i]), B, hh, ww, co, co, 0, PW(plan->downs[i]), PB(plan->downs[i]),
+                            TP(plan->t_D[i]), co, co, 0, 3, 3, 2, 1);
+      RUN(plan_conv(plan, plan->downs[i], d, s));
+      xin = TP(plan->t_D[i]);
+    }
+  }
+
+  // --- decoder (reference :372-377) ---
+  const float* xcur = TP(plan->t_R[3]);
+  for (int i = 0; i < 3; ++i) {
+    const DecStage& st = plan->dec[i];
+    const int Cc = kUp[i], Ch = kUp[i + 1];
+    const int lh = H >> (3 - i), lw = W >> (3 - i);
+    const float* xres = TP(plan->t_R[2 - i]);  // residual_inputs[-(i+1)]: (B, Ch, 2lh, 2lw)
+    float* cat = TP(plan->t_CAT[i]);
+    {  // gating = relu(BN(conv1x1(x)))   (:222-225)
+      TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.gate), PB(st.gate), TP(plan->t_G[i]), Ch, Ch, 0, 1, 1, 1,
+                            0);
+      d.relu_pre = 1;
+      RUN(plan_conv(plan, st.gate, d, s));
+    }
+    {  // g1 = w_g(g)   (:101)
+      TapConv d = conv_desc(TP(plan->t_G[i]), B, lh, lw, Ch, Ch, 0, PW(st.wg), PB(st.wg), TP(plan->t_Q[i]), Ch, Ch, 0, 1,
+                            1, 1, 0);
+      RUN(plan_conv(plan, st.wg, d, s));
+    }
+    {  // relu(g1 + w_x(x))   (:102-103)
+      TapConv d = conv_desc(xres, B, 2 * lh, 2 * lw, Ch, Ch, 0, PW(st.wx), PB(st.wx), TP(plan->t_P[i]), Ch, Ch, 0, 2, 2,
+                            2, 0);
+      d.res = TP(plan->t_Q[i]); d.res_cs = Ch; d.res_co = 0;
+      d.relu_post = 1;
+      RUN(plan_conv(plan, st.wx, d, s));
+    }
+    {  // psi = sigmoid(conv1x1 -> 1 channel)   (:104)
+      TapConv d = conv_desc(TP(plan->t_P[i]), B, lh, lw, Ch, Ch, 0, PW(st.psi), PB(st.psi), TP(plan->t_PSI[i]), 1, 1, 0,
+                            1, 1, 1, 0);
+      d.sigmoid = 1;
+      RUN(plan_conv(plan, st.psi, d, s));
+    }
+    {  // attention = BN(conv1x1(nearest2x(psi) * x))  == nearest2x(psi) * (W' x) + b'   (:105-107), into cat[:, Cc:]
+      TapConv d = conv_desc(xres, B, 2 * lh, 2 * lw, Ch, Ch, 0, PW(st.result), PB(st.result), cat, Ch, Cc + Ch, Cc, 1, 1,
+                            1, 0);
+      d.gate = TP(plan->t_PSI[i]);
+      RUN(plan_conv(plan, st.result, d, s));
+    }
+    {  // UpConvBlock: relu(BN(conv(x + relu(time_mlp(t)))))   (:199-205)
+      TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.conv), PB(st.conv), TP(plan->t_U[i]), Cc, Cc, 0, 3, 3, 1,
+                            1);
+      d.relu_pre = 1;
+      d.in_add = temb + st.mlp.temb_off; d.in_add_cs = plan->temb_total;
+      RUN(plan_conv(plan, st.conv, d, s));
+    }
+    for (int py = 0; py < 2; ++py)  // transform: ConvTranspose2d, into cat[:, :Cc]   (:206, :376)
+      for (int px = 0; px < 2; ++px) {
+        TapConv d = convT_phase_desc(TP(plan->t_U[i]), B, lh, lw, Cc, Cc, 0, PW(st.transform), PB(st.transform), cat, Cc,
+                                     Cc + Ch, 0, py, px);
+        RUN(plan_conv(plan, st.transform, d, s));
+      }
+    {  // up_conv over the concatenation (:377), no norm / activation
+      TapConv d = conv_desc(cat, B, 2 * lh, 2 * lw, Cc + Ch, Cc + Ch, 0, PW(st.upconv), PB(st.upconv), TP(plan->t_X[i]),
+                            Ch, Ch, 0, 3, 3, 1, 1);
+      RUN(plan_conv(plan, st.upconv, d, s));
+    }
+    xcur = TP(plan->t_X[i]);
+  }
+  {  // output 1x1 conv (:379), straight to the caller's NCHW tensor
+    TapConv d = conv_desc(xcur, B, H, W, kUp[3], kUp[3], 0, PW(plan->output), PB(plan->output), out, c.out_dim, c.out_dim,
+                          0, 1, 1, 1, 0);
+    d.out_nchw = 1;
+    RUN(plan_conv(plan, plan->output, d, s));
+  }
+#undef RUN
+  return DRS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// introspection
+// ------------------------------------------------------------------------------------------------
+extern "C" int drs_unet_num_tensors(const drs_plan* plan) { return plan ? (int)plan->tensors.size() : 0; }
+extern "C" const char* drs_unet_tensor_name(const drs_plan* plan, int i) {
+  return (plan && i >= 0 && i < (int)plan->tensors.size()) ? plan->tensors[i].name.c_str() : nullptr;
+}
+extern "C" int drs_unet_tensor_shape(const drs_plan* plan, int i, int* n, int* c, int* h, int* w) {
+  DRS_REQUIRE(plan && i >= 0 && i < (int)plan->tensors.size() && n && c && h && w, DRS_ERR_ARG, "tensor_shape: bad index");
+  const WsTensor& t = plan->tensors[i];
+  *n = t.n; *c = t.c; *h = t.h; *w = t.w;
+  return DRS_OK;
+}
+extern "C" int drs_unet_read_tensor(const drs_plan* plan, int i, const void* workspace, float* dst, drs_stream_t stream) {
+  DRS_REQUIRE(plan && workspace && dst && i >= 0 && i < (int)plan->tensors.size(), DRS_ERR_ARG, "read_tensor: bad args");
+  const WsTensor& t = plan->tensors[i];
+  const float* src = (const float*)(aligned_base(workspace) + t.off);
+  if (t.planar) {
+    DRS_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)t.n * t.c * t.h * t.w * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DRS_OK;
+  }
+  return drs_launch_nhwc_to_nchw(src, dst, t.n, t.c, t.h, t.w, t.cs, t.co, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-op timing
+// ------------------------------------------------------------------------------------------------
+extern "C" int drs_unet_profile_enable(drs_plan* plan, int on) {
+  DRS_REQUIRE(plan, DRS_ERR_ARG, "profile_enable: null plan");
+  plan->profiling = on != 0;
+  return DRS_OK;
+}
+extern "C" int drs_unet_profile_num_ops(const drs_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
+extern "C" int drs_unet_profile_read(drs_plan* plan, int i, char* name, int name_len, float* ms, double* flops,
+                                     double* bytes) {
+  DRS_REQUIRE(plan && i >= 0 && i < (int)plan->ops.size() && name && ms && flops && bytes, DRS_ERR_ARG,
+              "profile_read: bad args");
+  drs_plan::OpRec& r = plan->ops[i];
+  DRS_CHECK_HIP(hipEventSynchronize(r.e1));
+  DRS_CHECK_HIP(hipEventElapsedTime(ms, r.e0, r.e1));
+  snprintf(name, name_len, "%s", r.name.c_str());
+  *flops = r.flops;
+  *bytes = r.bytes;
+  return DRS_OK;
+}

@@ -1,0 +1,189 @@
+"""Host side of the UNet plan: owns device buffers (through torch), keeps the packed weights in
+sync with the module's parameters and calls `drs_unet_forward` (include/drs_hip.h).
+
+One `_Plan` per (batch, lr_batch, H, W, magnification, device); buffers are sized for the
+288 GB of an MI355X: every intermediate activation keeps its own slot in one workspace
+(about 1.6 GB at batch 16, 256x256), nothing is re-allocated between calls.
+"""
+import ctypes as C
+import os
+import weakref
+
+import torch
+
+from . import _lib
+from .hip_ops import inv_freq_table
+
+DEFAULT_IMPL = os.environ.get("DRS_IMPL", "direct")
+
+
+class _Plan:
+    def __init__(self, lib, cfg, device):
+        self.lib = lib
+        self.device = device
+        self.handle = C.c_void_p()
+        _lib.check(lib.drs_unet_plan_create(C.byref(self.handle), C.byref(cfg)), "drs_unet_plan_create")
+        self.cfg = cfg
+        n = lib.drs_unet_num_params(self.handle)
+        self.param_names = [lib.drs_unet_param_name(self.handle, i).decode() for i in range(n)]
+        self.param_numels = [lib.drs_unet_param_numel(self.handle, i) for i in range(n)]
+        self.packed_bytes = lib.drs_unet_packed_bytes(self.handle)
+        self.ws_bytes = lib.drs_unet_workspace_bytes(self.handle)
+        self.packed = torch.empty(self.packed_bytes, dtype=torch.uint8, device=device)
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.signature = None
+        self.cond_key = None
+        nt = lib.drs_unet_num_tensors(self.handle)
+        self.tensor_index = {lib.drs_unet_tensor_name(self.handle, i).decode(): i for i in range(nt)}
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.drs_unet_plan_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+
+class HipUNetEngine:
+    """Runs reference `Residual_Attention_UNet_superres.forward` (UNet_model_superres.py:337-379)
+    on the HIP plan.  Eval-mode BatchNorm only in this build: a train-mode call raises."""
+
+    def __init__(self, module, variant="superres", impl=None):
+        if variant != "superres":
+            raise NotImplementedError(f"UNet variant {variant!r} is not built yet")
+        self._module = weakref.ref(module)
+        self.impl = _lib.IMPL_BY_NAME[impl or DEFAULT_IMPL]
+        self._plans = {}
+        self._inv_freq = inv_freq_table(module.time_emb_dim)
+        self._inv_freq_c = (C.c_float * self._inv_freq.numel())(*self._inv_freq.tolist())
+
+    # -- plan / weights -------------------------------------------------------------------
+    def _get_plan(self, B, Bl, H, W, mag, device):
+        key = (B, Bl, H, W, mag, device.index, self.impl)
+        plan = self._plans.get(key)
+        if plan is None:
+            m = self._module()
+            cfg = _lib.UNetConfig(B, Bl, m.image_channels, m.out_dim, H, W, mag, self.impl, 1e-5)
+            plan = _Plan(_lib.load(), cfg, device)
+            self._plans[key] = plan
+        return plan
+
+    def set_impl(self, impl):
+        self.impl = _lib.IMPL_BY_NAME[impl]
+
+    def _sync_weights(self, plan):
+        """Re-pack (BatchNorm fold + re-layout) when any parameter or buffer changed."""
+        m = self._module()
+        sd = m.state_dict(keep_vars=True)
+        tensors = []
+        for name, numel in zip(plan.param_names, plan.param_numels):
+            t = sd[name]
+            if t.device != plan.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"parameter {name} must be a contiguous fp32 tensor on {plan.device}, "
+                                   f"found {t.dtype} on {t.device}")
+            if t.numel() != numel:
+                raise RuntimeError(f"parameter {name} has {t.numel()} elements, plan expects {numel}")
+            tensors.append(t)
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        if sig == plan.signature:
+            return
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        stream = C.c_void_p(torch.cuda.current_stream(plan.device).cuda_stream)
+        st = plan.lib.drs_unet_pack_weights(plan.handle, arr, self._inv_freq_c, C.c_void_p(plan.packed.data_ptr()),
+                                            plan.packed_bytes, stream)
+        _lib.check(st, "drs_unet_pack_weights")
+        plan.signature = sig
+        plan.cond_key = None
+
+    # -- forward ----------------------------------------------------------------------------
+    def forward(self, x, timestep, lr_img, magnification_factor, reuse_cond=False, check_weights=True):
+        m = self._module()
+        if m.training:
+            raise NotImplementedError(
+                "train-mode forward (batch-statistics BatchNorm + backward) is not part of this build; call "
+                "model.eval() — Diffusion.sample does")
+        for name, t in (("x", x), ("timestep", timestep), ("lr_img", lr_img)):
+            if not isinstance(t, torch.Tensor) or not t.is_cuda:
+                raise RuntimeError(f"{name} must be a tensor on a ROCm device: the UNet forward has no CPU fallback")
+        if x.dtype != torch.float32 or lr_img.dtype != torch.float32:
+            raise RuntimeError("x and lr_img must be float32 (the reference forward is fp32-only)")
+        if x.dim() != 4 or lr_img.dim() != 4:
+            raise RuntimeError("x and lr_img must be NCHW")
+        B, Cx, H, W = x.shape
+        Bl = lr_img.shape[0]
+        mag = int(magnification_factor)
+        if Cx != m.image_channels or lr_img.shape[1] != m.image_channels:
+            raise RuntimeError(f"expected {m.image_channels} channels, got x {Cx}, lr_img {lr_img.shape[1]}")
+        if lr_img.shape[2] * mag != H or lr_img.shape[3] * mag != W:
+            raise RuntimeError(f"lr_img {tuple(lr_img.shape)} x{mag} does not match x {tuple(x.shape)}")
+        if timestep.shape != (B,):
+            raise RuntimeError(f"timestep must have shape ({B},), got {tuple(timestep.shape)}")
+        x = x.contiguous()
+        lr_img = lr_img.contiguous()
+        timestep = timestep.to(torch.int64).contiguous()
+        plan = self._get_plan(B, Bl, H, W, mag, x.device)
+        with torch.cuda.device(x.device):
+            if check_weights or plan.signature is None:
+                self._sync_weights(plan)
+            flags = 0
+            if reuse_cond:
+                if plan.cond_key != (lr_img.data_ptr(), lr_img._version):
+                    raise RuntimeError("reuse_cond=True but the conditioning in the workspace belongs to another lr_img")
+                flags |= _lib.FWD_REUSE_COND
+            out = torch.empty((B, m.out_dim, H, W), dtype=torch.float32, device=x.device)
+            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            st = plan.lib.drs_unet_forward(plan.handle, C.c_void_p(plan.packed.data_ptr()), C.c_void_p(x.data_ptr()),
+                                           C.c_void_p(timestep.data_ptr()), C.c_void_p(lr_img.data_ptr()),
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(plan.workspace.data_ptr()),
+                                           plan.ws_bytes, flags, stream)
+            _lib.check(st, "drs_unet_forward")
+            plan.cond_key = (lr_img.data_ptr(), lr_img._version)
+        self._last_plan = plan
+        return out
+
+    # -- per-op timing (bench.py roofline) ------------------------------------------------------
+    def profile_forward(self, x, timestep, lr_img, magnification_factor, iters=5, **kw):
+        """Run `iters` forwards with HIP events around every op of the schedule (recorded on the launch stream)
+        and return [(op name, mean ms, algorithmic flops, algorithmic bytes)]."""
+        self.forward(x, timestep, lr_img, magnification_factor, **kw)
+        plan = self._last_plan
+        lib = plan.lib
+        acc = {}
+        order = []
+        _lib.check(lib.drs_unet_profile_enable(plan.handle, 1), "drs_unet_profile_enable")
+        try:
+            for _ in range(iters):
+                self.forward(x, timestep, lr_img, magnification_factor, **kw)
+                n = lib.drs_unet_profile_num_ops(plan.handle)
+                name = C.create_string_buffer(128)
+                ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+                for i in range(n):
+                    _lib.check(lib.drs_unet_profile_read(plan.handle, i, name, 128, C.byref(ms), C.byref(fl),
+                                                         C.byref(by)), "drs_unet_profile_read")
+                    key = name.value.decode()
+                    if key not in acc:
+                        acc[key] = [0.0, fl.value, by.value]
+                        order.append(key)
+                    acc[key][0] += ms.value
+        finally:
+            lib.drs_unet_profile_enable(plan.handle, 0)
+        return [(k, acc[k][0] / iters, acc[k][1], acc[k][2]) for k in order]
+
+    # -- introspection (parity tests) ---------------------------------------------------------
+    def tensor_names(self):
+        return list(self._last_plan.tensor_index)
+
+    def read_tensor(self, name):
+        """NCHW copy of an intermediate activation left by the last forward."""
+        plan = self._last_plan
+        i = plan.tensor_index[name]
+        dims = [C.c_int() for _ in range(4)]
+        _lib.check(plan.lib.drs_unet_tensor_shape(plan.handle, i, *[C.byref(d) for d in dims]), "drs_unet_tensor_shape")
+        shape = tuple(d.value for d in dims)
+        dst = torch.empty(shape, dtype=torch.float32, device=plan.device)
+        with torch.cuda.device(plan.device):
+            stream = C.c_void_p(torch.cuda.current_stream(plan.device).cuda_stream)
+            _lib.check(plan.lib.drs_unet_read_tensor(plan.handle, i, C.c_void_p(plan.workspace.data_ptr()),
+                                                     C.c_void_p(dst.data_ptr()), stream), "drs_unet_read_tensor")
+        return dst

@@ -1,0 +1,121 @@
+"""Thin torch-tensor wrappers over the operator-level C-ABI entries (include/drs_hip.h).
+
+PyTorch is used only for device memory and the current stream.  Every wrapper requires
+ROCm-device fp32 contiguous tensors and raises otherwise: there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _req(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the HIP path needs a ROCm device tensor (no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def conv2d(x, w, b=None, stride=1, padding=0, transposed=False, output_padding=0, relu=False, impl="direct"):
+    """F.conv2d / F.conv_transpose2d for the flavours the UNet uses (NCHW, fp32)."""
+    lib = _lib.load()
+    x = _req(x, "x"); w = _req(w, "w")
+    if b is not None:
+        b = _req(b, "b")
+    N, Cin, H, W = x.shape
+    if transposed:
+        if w.shape[0] != Cin:
+            raise RuntimeError(f"conv_transpose2d: weight {tuple(w.shape)} does not match Cin={Cin}")
+        Cout = w.shape[1]
+    else:
+        if w.shape[1] != Cin:
+            raise RuntimeError(f"conv2d: weight {tuple(w.shape)} does not match Cin={Cin}")
+        Cout = w.shape[0]
+    KH, KW = w.shape[2], w.shape[3]
+    if transposed:
+        OH = (H - 1) * stride - 2 * padding + KH + output_padding
+        OW = (W - 1) * stride - 2 * padding + KW + output_padding
+    else:
+        OH = (H + 2 * padding - KH) // stride + 1
+        OW = (W + 2 * padding - KW) // stride + 1
+    y = torch.empty((N, Cout, max(OH, 0), max(OW, 0)), dtype=torch.float32, device=x.device)
+    args = (N, Cin, H, W, Cout, KH, KW, stride, padding, int(transposed), output_padding)
+    nbytes = lib.drs_conv2d_workspace_bytes(*args)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    impl_id = _lib.IMPL_BY_NAME[impl] if isinstance(impl, str) else int(impl)
+    with torch.cuda.device(x.device):
+        st = lib.drs_conv2d_nchw(_ptr(x), _ptr(w), _ptr(b), _ptr(y), *args, int(relu), _ptr(ws), nbytes, impl_id,
+                                 _stream(x.device))
+    _lib.check(st, "drs_conv2d_nchw")
+    return y
+
+
+def bicubic_upsample(x, scale):
+    lib = _lib.load()
+    x = _req(x, "x")
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, Cc, H * scale, W * scale), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.drs_bicubic_upsample_nchw(_ptr(x), _ptr(y), N, Cc, H, W, int(scale), _stream(x.device))
+    _lib.check(st, "drs_bicubic_upsample_nchw")
+    return y
+
+
+def inv_freq_table(channels=100):
+    """Same expression as reference pos_encoding (UNet_model_superres.py:329-331), on the host."""
+    return (1.0 / (10000 ** (torch.arange(0, channels, 2).float() / channels))).contiguous()
+
+
+def time_mlp(t, W1, b1, W2, b2):
+    lib = _lib.load()
+    t = _req(t, "t", torch.int64)
+    W1, b1, W2, b2 = (_req(a, n) for a, n in ((W1, "W1"), (b1, "b1"), (W2, "W2"), (b2, "b2")))
+    dim_out, dim_in = W1.shape
+    inv = inv_freq_table(dim_in).to(t.device)
+    out = torch.empty((t.shape[0], dim_out), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        st = lib.drs_time_mlp(_ptr(t), _ptr(inv), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(out), t.shape[0], dim_in,
+                              dim_out, _stream(t.device))
+    _lib.check(st, "drs_time_mlp")
+    return out
+
+
+def noise_images(x0, eps, t, alpha_hat):
+    lib = _lib.load()
+    x0 = _req(x0, "x0"); eps = _req(eps, "eps"); t = _req(t, "t", torch.int64); alpha_hat = _req(alpha_hat, "alpha_hat")
+    if eps.shape != x0.shape or t.shape[0] != x0.shape[0]:
+        raise RuntimeError("noise_images: shape mismatch")
+    out = torch.empty_like(x0)
+    n = x0.shape[0]
+    chw = x0.numel() // n if n else 0
+    with torch.cuda.device(x0.device):
+        st = lib.drs_noise_images(_ptr(x0), _ptr(eps), _ptr(t), _ptr(alpha_hat), alpha_hat.numel(), _ptr(out), n, chw,
+                                  _stream(x0.device))
+    _lib.check(st, "drs_noise_images")
+    return out
+
+
+def sampler_step_(x, eps_pred, noise, t, alpha, alpha_hat, beta):
+    """In-place ancestral update of x for the scalar timestep t (noise may be None)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
+        raise RuntimeError("sampler_step_: x must be a contiguous fp32 ROCm tensor (no CPU fallback)")
+    eps_pred = _req(eps_pred, "eps_pred")
+    noise = _req(noise, "noise") if noise is not None else None
+    with torch.cuda.device(x.device):
+        st = lib.drs_sampler_step(_ptr(x), _ptr(eps_pred), _ptr(noise), int(t), _ptr(alpha), _ptr(alpha_hat),
+                                  _ptr(beta), alpha.numel(), x.numel(), _stream(x.device))
+    _lib.check(st, "drs_sampler_step")
+    return x

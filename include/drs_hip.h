@@ -1,0 +1,159 @@
+/*
+ * drs_hip.h — C-ABI of the MI355X (gfx950) DDPM denoising hot path.
+ *
+ * This is the drop-in boundary: every entry point takes raw DEVICE pointers, explicit
+ * shapes and a HIP stream, and returns an int status (0 = ok).  No torch types, no
+ * exceptions, no ownership transfer: the caller (PyTorch's allocator in the shipped
+ * host code) owns every buffer including the workspaces passed in.  The only opaque
+ * state is `drs_plan`, created and destroyed explicitly.
+ *
+ * Each declaration cites the reference code it replaces.  Paths are relative to the
+ * reference checkout of AdrianoEttari/DiffusionRemoteSensing (2024-10-22).
+ *
+ * Conventions: all floating tensors are fp32, row-major contiguous; images at the
+ * boundary are NCHW exactly like the reference; timesteps are int64.  Internally the
+ * plan keeps activations channels-last (NHWC) in the caller's workspace.
+ */
+#ifndef DRS_HIP_H
+#define DRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* drs_stream_t; /* hipStream_t; NULL = default stream */
+typedef struct drs_plan drs_plan;
+
+enum {
+  DRS_OK = 0,
+  DRS_ERR_ARG = 1,       /* null pointer / bad enum */
+  DRS_ERR_SHAPE = 2,     /* shape the kernels do not support (e.g. H,W not divisible by 8) */
+  DRS_ERR_HIP = 3,       /* a HIP runtime call failed; see drs_last_error() */
+  DRS_ERR_WORKSPACE = 4, /* workspace / packed buffer too small */
+  DRS_ERR_STATE = 5      /* plan used before its weights were packed */
+};
+
+/* Convolution implementations (same arithmetic, different kernels). */
+enum {
+  DRS_IMPL_DIRECT = 0, /* fp32 VALU direct convolution: the on-device reference path */
+  DRS_IMPL_MFMA_F32 = 1, /* LDS-tiled implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32) */
+  DRS_IMPL_MFMA_BF16X3 = 2, /* implicit GEMM, operands split hi+lo bf16, 3 MFMAs per product */
+  DRS_IMPL_MFMA_F16 = 3  /* implicit GEMM, fp16 operands, fp32 accumulate */
+};
+
+/* Human-readable message for the last non-zero status returned on this thread. */
+const char* drs_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int drs_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Diffusion arithmetic
+ * ------------------------------------------------------------------------------------------ */
+
+/* Forward process q(x_t | x_0): x_t[i] = sqrt(alpha_hat[t[i]]) * x0[i] + sqrt(1 - alpha_hat[t[i]]) * eps[i]
+ * for n images of `chw` elements each.  `eps` is supplied by the caller (torch.randn_like).
+ * Replaces Diffusion.noise_images, train_diffusion_superres.py:171-190. */
+int drs_noise_images(const float* x0, const float* eps, const int64_t* t, const float* alpha_hat,
+                     int noise_steps, float* x_t, int n, int64_t chw, drs_stream_t stream);
+
+/* One ancestral sampling update, in place on x:
+ *   x = 1/sqrt(alpha[t]) * (x - (1 - alpha[t]) / sqrt(1 - alpha_hat[t]) * eps_pred) + sqrt(beta[t]) * noise
+ * `noise` may be NULL (last step: reference uses zeros).  `t` is one scalar timestep shared by the
+ * batch (the reference builds ones(n)*i).  Replaces the loop body at train_diffusion_superres.py:240-249. */
+int drs_sampler_step(float* x, const float* eps_pred, const float* noise, int t, const float* alpha,
+                     const float* alpha_hat, const float* beta, int noise_steps, int64_t numel,
+                     drs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points (used by the parity tests for every convolution flavour
+ * the UNet contains, at arbitrary/ragged shapes)
+ * ------------------------------------------------------------------------------------------ */
+
+/* y = conv2d(x, w, b) or conv_transpose2d(x, w, b), NCHW in/out like torch.
+ *   x: (N,Cin,H,W)   w: (Cout,Cin,KH,KW) [transposed: (Cin,Cout,KH,KW)]   b: (Cout) or NULL
+ *   y: (N,Cout,OH,OW) with OH = (H + 2*pad - KH)/stride + 1, transposed: (H-1)*stride - 2*pad + KH + out_pad
+ * Supported flavours (all the reference uses): 3x3 s1 p1; 3x3 s2 p1; 1x1; 2x2 s2 p0;
+ * transposed 3x3 s2 p1 out_pad 1.  `relu` != 0 applies max(.,0).
+ * workspace: device scratch of at least drs_conv2d_workspace_bytes() bytes.
+ * Replaces nn.Conv2d / nn.ConvTranspose2d calls at UNet_model_superres.py:70-85,123-141,184-185,217,298,321,325. */
+size_t drs_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
+                                  int pad, int transposed, int out_pad);
+int drs_conv2d_nchw(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
+                    int Cout, int KH, int KW, int stride, int pad, int transposed, int out_pad, int relu,
+                    void* workspace, size_t workspace_bytes, int impl, drs_stream_t stream);
+
+/* y = F.interpolate(x, scale_factor=scale, mode='bicubic') (align_corners=False, A=-0.75, border clamp),
+ * integer scale.  x: (N,C,H,W) -> y: (N,C,H*scale,W*scale).  Replaces UNet_model_superres.py:349. */
+int drs_bicubic_upsample_nchw(const float* x, float* y, int N, int C, int H, int W, int scale,
+                              drs_stream_t stream);
+
+/* out[b, :] = relu(W2 @ silu(W1 @ posenc(t[b]) + b1) + b2), posenc = [sin(t*f_j) | cos(t*f_j)], j < dim_in/2,
+ * inv_freq[j] = f_j supplied by the caller (dim_in/2 floats).  W1: (dim_out, dim_in), W2: (dim_out, dim_out).
+ * Replaces pos_encoding + time_mlp + ReLU, UNet_model_superres.py:328-335,143-151,161 (and :187-199). */
+int drs_time_mlp(const int64_t* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
+                 const float* b2, float* out, int B, int dim_in, int dim_out, drs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-network plan: Residual_Attention_UNet_superres.forward (UNet_model_superres.py:337-379)
+ * in eval mode (BatchNorm running statistics folded into the convolutions at pack time).
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct drs_unet_config {
+  int batch;          /* n images in x */
+  int lr_batch;       /* batch of lr_img: == batch, or 1 (broadcast, Diffusion.sample :224) */
+  int image_channels; /* reference ctor arg (3) */
+  int out_dim;        /* reference ctor arg (3) */
+  int height, width;  /* of x; divisible by 8 and by magnification */
+  int magnification;  /* lr_img is (height/mag, width/mag) */
+  int impl;           /* DRS_IMPL_* used for the wide convolutions */
+  float bn_eps;       /* 1e-5 */
+} drs_unet_config;
+
+int drs_unet_plan_create(drs_plan** plan, const drs_unet_config* cfg);
+void drs_unet_plan_destroy(drs_plan* plan);
+
+/* The state_dict entries the plan consumes, in the order drs_unet_pack_weights expects. */
+int drs_unet_num_params(const drs_plan* plan);
+const char* drs_unet_param_name(const drs_plan* plan, int i);
+int64_t drs_unet_param_numel(const drs_plan* plan, int i);
+
+size_t drs_unet_packed_bytes(const drs_plan* plan);
+size_t drs_unet_workspace_bytes(const drs_plan* plan);
+
+/* Fold BatchNorm (eval) into conv weights/biases and re-lay every weight for the kernels.
+ * params[i] = device pointer of state_dict[drs_unet_param_name(i)] (fp32).  inv_freq = 50 floats (host
+ * pointer) computed like reference :329-331.  Must be re-run whenever the parameters change. */
+int drs_unet_pack_weights(drs_plan* plan, const void* const* params, const float* inv_freq_host, void* packed,
+                          size_t packed_bytes, drs_stream_t stream);
+
+/* eps_pred = model(x, t, lr_img, magnification).  x: (batch,C,H,W)  t: (batch) int64
+ * lr_img: (lr_batch,C,H/mag,W/mag)  out: (batch,out_dim,H,W).
+ * flags bit 0 (DRS_FWD_REUSE_COND): skip the LR-conditioning branch (RRDB -> bicubic -> conv, reference
+ * :345-353) and reuse the one left in the workspace by the previous call — valid while lr_img and the weights
+ * are unchanged, i.e. inside one Diffusion.sample chain (the reference recomputes it every step). */
+#define DRS_FWD_REUSE_COND 1
+int drs_unet_forward(drs_plan* plan, const void* packed, const float* x, const int64_t* t, const float* lr_img,
+                     float* out, void* workspace, size_t workspace_bytes, int flags, drs_stream_t stream);
+
+/* Introspection for block-level parity tests: intermediate activations left in the workspace by the last
+ * forward, converted to NCHW into `dst`.  Names follow the reference module tree
+ * ("conv_blocks.0", "downs.1", "attention_blocks.2", ...). */
+int drs_unet_num_tensors(const drs_plan* plan);
+const char* drs_unet_tensor_name(const drs_plan* plan, int i);
+int drs_unet_tensor_shape(const drs_plan* plan, int i, int* n, int* c, int* h, int* w);
+int drs_unet_read_tensor(const drs_plan* plan, int i, const void* workspace, float* dst_nchw, drs_stream_t stream);
+
+/* Per-op timing of the forward schedule: with profiling on, drs_unet_forward brackets every op with HIP events on
+ * the stream it launches on; afterwards read (name, milliseconds, algorithmic FLOPs, algorithmic bytes) per op.
+ * Used by bench.py for the roofline of the dominant kernel.  Not for use inside graph capture. */
+int drs_unet_profile_enable(drs_plan* plan, int on);
+int drs_unet_profile_num_ops(const drs_plan* plan);
+int drs_unet_profile_read(drs_plan* plan, int i, char* name, int name_len, float* ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRS_HIP_H */

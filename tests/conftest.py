@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "superres_golden.npz")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return dict(np.load(GOLDEN))
+
+
+@pytest.fixture(scope="session")
+def seeded_sd():
+    """Seeded state_dict (CPU tensors) keyed like the reference's, from the build-owned module tree."""
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    m = Residual_Attention_UNet_superres(3, 3, "cpu")
+    return synthetic.seeded_state_dict(m.state_dict(), 0)
+
+
+def golden_inputs(tag, B, Bl, C, S, mag, T, seed=0):
+    from diffusionremotesensing_amd import synthetic
+    x = synthetic.tensor_normal(f"{tag}.x", (B, C, S, S), seed)
+    lr = synthetic.tensor_uniform(f"{tag}.lr", (Bl, C, S // mag, S // mag), seed)
+    t = synthetic.tensor_randint(f"{tag}.t", (B,), 1, T, seed)
+    return x, t, lr
+
+
+def rel_errors(a, b):
+    """(max-abs / max-abs-ref, rel-L2): the acceptance metric of SURVEY.md section 8(c)."""
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    denom = b.abs().max().clamp_min(1e-30)
+    return ((a - b).abs().max() / denom).item(), ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def replay_noise_source(seed):
+    """Replays torch's CPU generator in the order reference Diffusion.sample draws from it
+    (train_diffusion_superres.py:230,246): x_T first, then one randn per step."""
+    gen = torch.Generator().manual_seed(seed)
+
+    def src(i, shape):
+        return torch.randn(shape, generator=gen)
+    return src
