@@ -36,7 +36,12 @@ def cpu_baseline(sd, x, t, lr):
     """The oracle (CPU port of the reference graph, stock torch ops) on this box's host cores: bounded sample of
     the same workload = 1 warm-up + 2 timed 16-image forwards."""
     from oracle import unet_oracle
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # a 1-GPU box owns a 16-core share of the host however many cores it can see
+    cores = max(1, min(avail, int(os.environ.get("DRS_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     with torch.no_grad():
         unet_oracle.unet_forward(sd, x, t, lr, MAG)
@@ -56,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--impl", default=os.environ.get("DRS_IMPL", "direct"))
+    ap.add_argument("--impl", default=os.environ.get("DRS_IMPL", "mfma_bf16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -160,6 +165,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, x_cpu, torch.full((BATCH,), 750, dtype=torch.int64), lr_cpu)
+        if os.environ.get("DRS_BENCH_OPS"):
+            with open(os.environ["DRS_BENCH_OPS"], "w") as f:
+                for n_, ms_, fl_, by_ in ops:
+                    f.write(f"{n_:40s} {ms_*1e3:9.1f} us  {fl_/1e9:8.3f} GF  {by_/1e6:8.1f} MB  "
+                            f"{(fl_/ms_/1e9 if ms_ > 0 else 0):8.1f} TF/s  {(by_/ms_/1e6 if ms_ > 0 else 0):8.1f} GB/s\n")
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         torch.distributed.barrier()

@@ -43,6 +43,13 @@ struct TapConv {
   const float* gate;     // [N][OH/2][OW/2] or null
   int relu_pre, relu_post, sigmoid;
   int out_nchw;          // 1: out is (N,Cout,OH,OW) planar
+  // optional fused 1x1 projection of the epilogue result (the UNet's `output` conv): fuse_out[n][j][oy][ox] =
+  // fuse_b[j] + sum_co v[co] * fuse_w[j][co], j < fuse_dim <= 4; planar NCHW.  MFMA family only, Cout == 32.
+  // With fuse_out set, `out` may be null (the wide tensor is then never written).
+  const float* fuse_w;
+  const float* fuse_b;
+  float* fuse_out;
+  int fuse_dim;
 };
 
 struct DrsErr {
@@ -80,6 +87,12 @@ int drs_launch_pack_conv(const float* w, const float* b, const float* gamma, con
                          const float* rvar, float eps, float* dst_w, float* dst_b, int Cout, int Cin, int taps,
                          int transposed, int mfma_layout, hipStream_t s);
 
+// MFMA-family packing: dst image(s) [chunk][tap][kgroup][Cout][slot]; see conv_mfma.hip
+size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl);
+int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
+                              const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
+                              int transposed, int impl, hipStream_t s);
+
 int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
                             hipStream_t s);
 int drs_launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int src_cs, int src_co,
@@ -93,3 +106,5 @@ int drs_launch_stem(const float* in_nchw, const float* w, const float* b, const 
 int drs_launch_bicubic(const float* x, float* y, int N, int C, int H, int W, int scale, hipStream_t s);
 int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
                         const float* b2, float* out, int out_stride, int B, int dim_in, int dim_out, hipStream_t s);
+int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const char* packed, const long long* table,
+                              int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in, hipStream_t s);

@@ -1,0 +1,80 @@
+// Operand policies and launch geometry shared by the MFMA tap-convolution kernels (conv_mfma.hip, conv_mfma_ws.hip).
+#pragma once
+#include "drs_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- operand policies -------------------------------------------------------------------------------------------
+struct PolicyF32 {  // exact fp32: 4 x v_mfma_f32_16x16x4_f32 per slot pair
+  static constexpr int SLOT_CH = 4, IMAGES = 1, IMPL = DRS_IMPL_MFMA_F32;
+  struct Frag { f32x4 v; };
+  __device__ static void cvt_store(char* base, size_t img_stride, size_t off, const float* x) {
+    *reinterpret_cast<f32x4*>(base + off) = f32x4{x[0], x[1], x[2], x[3]};
+  }
+  __device__ static Frag load(const char* base, size_t img_stride, size_t off) {
+    return Frag{*reinterpret_cast<const f32x4*>(base + off)};
+  }
+  __device__ static f32x4 mma(const Frag& w, const Frag& a, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[j], a.v[j], c, 0, 0, 0);
+    return c;
+  }
+};
+struct PolicyF16 {  // fp16 operands, fp32 accumulate: 1 x v_mfma_f32_16x16x32_f16
+  static constexpr int SLOT_CH = 8, IMAGES = 1, IMPL = DRS_IMPL_MFMA_F16;
+  struct Frag { half8 v; };
+  __device__ static void cvt_store(char* base, size_t img_stride, size_t off, const float* x) {
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)x[j];
+    *reinterpret_cast<half8*>(base + off) = h;
+  }
+  __device__ static Frag load(const char* base, size_t img_stride, size_t off) {
+    return Frag{*reinterpret_cast<const half8*>(base + off)};
+  }
+  __device__ static f32x4 mma(const Frag& w, const Frag& a, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(w.v, a.v, c, 0, 0, 0);
+  }
+};
+struct PolicyBF16X3 {  // x = hi + lo (both bf16, 16 mantissa bits together): w*a ~ wl*ah + wh*al + wh*ah
+  static constexpr int SLOT_CH = 8, IMAGES = 2, IMPL = DRS_IMPL_MFMA_BF16X3;
+  struct Frag { bf16x8 hi, lo; };
+  __device__ static void cvt_store(char* base, size_t img_stride, size_t off, const float* x) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      h[j] = (__bf16)x[j];
+      l[j] = (__bf16)(x[j] - (float)h[j]);
+    }
+    *reinterpret_cast<bf16x8*>(base + off) = h;
+    *reinterpret_cast<bf16x8*>(base + img_stride + off) = l;
+  }
+  __device__ static Frag load(const char* base, size_t img_stride, size_t off) {
+    return Frag{*reinterpret_cast<const bf16x8*>(base + off), *reinterpret_cast<const bf16x8*>(base + img_stride + off)};
+  }
+  __device__ static f32x4 mma(const Frag& w, const Frag& a, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, a.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, a.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, a.hi, c, 0, 0, 0);
+  }
+};
+
+struct MfmaGeom {
+  int IH, IW;            // staged input window (rows, cols)
+  int dy_min, dx_min;    // smallest tap offsets
+  int tiles_x, tiles_y;  // patches per image
+  int nchunks;           // ceil(Cin / KC)
+  int a_plane;           // bytes of one activation k-group plane (multiple of 256)
+  int a_image;           // bytes of one activation image (4 planes)
+  int w_image;           // bytes of one weight image in LDS (ntaps*4*BN*16)
+  int w_gimage;          // bytes of one weight image in global memory
+  int debug;             // ablation switches (DRS_DEBUG_FLAGS): 1 skip MFMA phase, 2 skip LDS staging stores, 4 skip global loads
+};
+
+
+// conv_mfma_ws.hip: persistent wave-specialised variant for stride-1 flavours
+bool drs_tapconv_mfma_ws_geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, size_t* lds);
+int drs_launch_tapconv_mfma_ws(const TapConv& d, int impl, const MfmaGeom& g, int bn, size_t lds, hipStream_t s);

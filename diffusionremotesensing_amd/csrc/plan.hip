@@ -74,8 +74,9 @@ static TapConv convT_phase_desc(const float* in, int N, int H, int W, int Cin, i
   return d;
 }
 
+// impl is the family the weights of this layer were packed for: no silent switch at launch time
 static int run_conv(const TapConv& d, int impl, hipStream_t s) {
-  if (impl != DRS_IMPL_DIRECT && drs_tapconv_mfma_supported(d, impl)) return drs_launch_tapconv_mfma(d, impl, s);
+  if (impl != DRS_IMPL_DIRECT) return drs_launch_tapconv_mfma(d, impl, s);
   return drs_launch_tapconv_direct(d, s);
 }
 // algorithmic work of one tap-convolution (SURVEY.md 8(d) model: 2*MACs; fp32 input + output + weights)
@@ -114,7 +115,7 @@ extern "C" size_t drs_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
   size_t b = 0;
   b += align_up((size_t)N * H * W * Cin * 4);
   b += align_up((size_t)N * OH * OW * Cout * 4);
-  b += 2 * align_up((size_t)Cout * Cin * KH * KW * 4);
+  b += align_up(drs_pack_conv_mfma_bytes(Cout, Cin, KH * KW, DRS_IMPL_MFMA_BF16X3) + (size_t)Cout * Cin * KH * KW * 4);
   b += align_up((size_t)Cout * 4);
   return b + 256;
 }
@@ -123,6 +124,7 @@ extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, f
                                int Cout, int KH, int KW, int stride, int pad, int transposed, int out_pad, int relu,
                                void* workspace, size_t workspace_bytes, int impl, drs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (N == 0) return DRS_OK;  // empty batch: nothing to do (torch hands out null pointers for empty tensors)
   DRS_REQUIRE(x && w && y && workspace, DRS_ERR_ARG, "conv2d: null pointer");
   DRS_REQUIRE(N >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DRS_ERR_SHAPE, "conv2d: bad dims");
   DRS_REQUIRE(conv_flavour_ok(KH, KW, stride, pad, transposed, out_pad), DRS_ERR_SHAPE,
@@ -138,7 +140,8 @@ extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, f
   char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   float* xin = (float*)base; base += align_up((size_t)N * H * W * Cin * 4);
   float* yout = (float*)base; base += align_up((size_t)N * OH * OW * Cout * 4);
-  float* pw = (float*)base; base += 2 * align_up((size_t)Cout * Cin * KH * KW * 4);
+  float* pw = (float*)base;
+  base += align_up(drs_pack_conv_mfma_bytes(Cout, Cin, KH * KW, DRS_IMPL_MFMA_BF16X3) + (size_t)Cout * Cin * KH * KW * 4);
   float* pb = (float*)base;
   int rc;
   if ((rc = drs_launch_nchw_to_nhwc(x, xin, N, Cin, H, W, Cin, 0, s))) return rc;
@@ -147,9 +150,12 @@ extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, f
   TapConv probe = transposed ? convT_phase_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0, 1, 1)
                              : conv_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0, KH, KW, stride, pad);
   const bool mfma = impl != DRS_IMPL_DIRECT && drs_tapconv_mfma_supported(probe, impl);
-  if ((rc = drs_launch_pack_conv(w, b, nullptr, nullptr, nullptr, nullptr, 0.f, pw, pb, Cout, Cin, KH * KW, transposed,
-                                 mfma ? 1 : 0, s)))
-    return rc;
+  if (mfma)
+    rc = drs_launch_pack_conv_mfma(w, b, nullptr, nullptr, nullptr, nullptr, 0.f, pw, pb, Cout, Cin, KH * KW, transposed,
+                                   impl, s);
+  else
+    rc = drs_launch_pack_conv(w, b, nullptr, nullptr, nullptr, nullptr, 0.f, pw, pb, Cout, Cin, KH * KW, transposed, 0, s);
+  if (rc) return rc;
   const int use_impl = mfma ? impl : DRS_IMPL_DIRECT;
   if (!transposed) {
     TapConv d = probe;
@@ -211,8 +217,9 @@ struct drs_plan {
   ConvLayer output;
 
   size_t packed_bytes = 0, ws_bytes = 0;
-  size_t o_inv_freq = 0;
+  size_t o_inv_freq = 0, o_mlp_table = 0, o_out_w = 0, o_out_b = 0;
   int temb_total = 0;
+  std::vector<long long> mlp_table_host;
   bool packed_ok = false;
   const void* packed_ptr = nullptr;
 
@@ -358,7 +365,15 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
   size_t cur = 0;
   p->o_inv_freq = cur; cur += align_up(50 * 4);
   for (ConvLayer* L : p->convs) {
-    L->w_off = cur; cur += 2 * align_up((size_t)L->Cout * L->Cin * L->taps * 4);  // room for a split/aux image
+    L->w_off = cur;  // room for whichever kernel family's image is largest
+    {
+      size_t need = (size_t)L->Cout * L->Cin * L->taps * 4;
+      for (int im = DRS_IMPL_MFMA_F32; im <= DRS_IMPL_MFMA_F16; ++im) {
+        const size_t m = drs_pack_conv_mfma_bytes(L->Cout, L->Cin, L->taps, im);
+        need = m > need ? m : need;
+      }
+      cur += align_up(need);
+    }
     L->b_off = cur; cur += align_up((size_t)L->Cout * 4);
   }
   for (PlanarConv* L : p->planars) {
@@ -371,6 +386,9 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     m->o_w2 = cur; cur += align_up((size_t)m->dim * m->dim * 4);
     m->o_b2 = cur; cur += align_up((size_t)m->dim * 4);
   }
+  p->o_mlp_table = cur; cur += align_up(p->mlps.size() * 6 * sizeof(long long));
+  p->o_out_w = cur; cur += align_up((size_t)cfg->out_dim * kUp[3] * 4);
+  p->o_out_b = cur; cur += align_up((size_t)cfg->out_dim * 4);
   p->packed_bytes = cur;
 
   // ---- workspace layout ----
@@ -443,10 +461,13 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     L->mfma = impl != DRS_IMPL_DIRECT && drs_tapconv_mfma_supported(probe, impl);
     const float *g = nullptr, *be = nullptr, *rm = nullptr, *rv = nullptr;
     if (L->bn >= 0) { g = F(L->bn); be = F(L->bn + 1); rm = F(L->bn + 2); rv = F(L->bn + 3); }
-    if ((rc = drs_launch_pack_conv(F(L->w), F(L->b), g, be, rm, rv, plan->cfg.bn_eps, (float*)(base + L->w_off),
-                                   (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0,
-                                   L->mfma ? 1 : 0, s)))
-      return rc;
+    if (L->mfma)
+      rc = drs_launch_pack_conv_mfma(F(L->w), F(L->b), g, be, rm, rv, plan->cfg.bn_eps, base + L->w_off,
+                                     (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0, impl, s);
+    else
+      rc = drs_launch_pack_conv(F(L->w), F(L->b), g, be, rm, rv, plan->cfg.bn_eps, (float*)(base + L->w_off),
+                                (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0, 0, s);
+    if (rc) return rc;
   }
   for (PlanarConv* L : plan->planars) {
     DRS_CHECK_HIP(hipMemcpyAsync(base + L->w_off, F(L->w), (size_t)L->Cout * L->Cin * 9 * 4, hipMemcpyDeviceToDevice, s));
@@ -457,6 +478,21 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_b1, F(m->b1), (size_t)m->dim * 4, hipMemcpyDeviceToDevice, s));
     DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_w2, F(m->w2), (size_t)m->dim * m->dim * 4, hipMemcpyDeviceToDevice, s));
     DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_b2, F(m->b2), (size_t)m->dim * 4, hipMemcpyDeviceToDevice, s));
+  }
+  {
+    std::vector<long long> table;
+    for (Mlp* m : plan->mlps) {
+      const long long row[6] = {(long long)m->o_w1, (long long)m->o_b1, (long long)m->o_w2, (long long)m->o_b2, m->dim,
+                                m->temb_off};
+      table.insert(table.end(), row, row + 6);
+    }
+    plan->mlp_table_host = table;  // must outlive the async copy
+    DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_mlp_table, plan->mlp_table_host.data(), table.size() * sizeof(long long),
+                                 hipMemcpyHostToDevice, s));
+    DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_w, F(plan->output.w), (size_t)plan->cfg.out_dim * kUp[3] * 4,
+                                 hipMemcpyDeviceToDevice, s));
+    DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_b, F(plan->output.b), (size_t)plan->cfg.out_dim * 4,
+                                 hipMemcpyDeviceToDevice, s));
   }
   plan->packed_ok = true;
   plan->packed_ptr = packed;
@@ -501,13 +537,11 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
   const drs_unet_config& c = plan->cfg;
   const int B = c.batch, Bl = c.lr_batch, C = c.image_channels, H = c.height, W = c.width, mag = c.magnification;
   const int h = H / mag, w = W / mag;
-  const int impl = c.impl;
   char* pk = aligned_base(packed);
   void* ws = aligned_base(workspace);
   auto PW = [&](const ConvLayer& L) { return (const float*)(pk + L.w_off); };
   auto PB = [&](const ConvLayer& L) { return (const float*)(pk + L.b_off); };
   auto TP = [&](int i) { return plan->tp(ws, i); };
-  auto CI = [&](const ConvLayer& L) { return L.mfma ? impl : DRS_IMPL_DIRECT; };
   int rc;
   if (plan->profiling) {
     for (auto& r : plan->ops) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
@@ -519,10 +553,8 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
   float* temb = (float*)((char*)ws + plan->o_temb);
   const float* inv_freq = (const float*)(pk + plan->o_inv_freq);
   prof_begin(plan, "time_mlp", 0, 0, s);
-  for (Mlp* m : plan->mlps)
-    RUN(drs_launch_time_mlp(t, inv_freq, (const float*)(pk + m->o_w1), (const float*)(pk + m->o_b1),
-                            (const float*)(pk + m->o_w2), (const float*)(pk + m->o_b2), temb + m->temb_off,
-                            plan->temb_total, B, 100, m->dim, s));
+  RUN(drs_launch_time_mlp_multi(t, inv_freq, pk, (const long long*)(pk + plan->o_mlp_table), (int)plan->mlps.size(), 256,
+                                temb, plan->temb_total, B, 100, s));
   prof_end(plan, s);
 
   // --- LR conditioning branch: RRDB -> bicubic -> conv (reference :345-353), constant per sampling chain ---
@@ -596,6 +628,7 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
 
   // --- decoder (reference :372-377) ---
   const float* xcur = TP(plan->t_R[3]);
+  bool fused_output = false;
   for (int i = 0; i < 3; ++i) {
     const DecStage& st = plan->dec[i];
     const int Cc = kUp[i], Ch = kUp[i + 1];
@@ -648,11 +681,18 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
     {  // up_conv over the concatenation (:377), no norm / activation
       TapConv d = conv_desc(cat, B, 2 * lh, 2 * lw, Cc + Ch, Cc + Ch, 0, PW(st.upconv), PB(st.upconv), TP(plan->t_X[i]),
                             Ch, Ch, 0, 3, 3, 1, 1);
+      if (i == 2 && st.upconv.mfma && c.out_dim <= 4) {  // output 1x1 conv (:379) rides in the epilogue
+        d.fuse_w = (const float*)(pk + plan->o_out_w);
+        d.fuse_b = (const float*)(pk + plan->o_out_b);
+        d.fuse_out = out;
+        d.fuse_dim = c.out_dim;
+        fused_output = true;
+      }
       RUN(plan_conv(plan, st.upconv, d, s));
     }
     xcur = TP(plan->t_X[i]);
   }
-  {  // output 1x1 conv (:379), straight to the caller's NCHW tensor
+  if (!fused_output) {  // output 1x1 conv (:379), straight to the caller's NCHW tensor
     TapConv d = conv_desc(xcur, B, H, W, kUp[3], kUp[3], 0, PW(plan->output), PB(plan->output), out, c.out_dim, c.out_dim,
                           0, 1, 1, 1, 0);
     d.out_nchw = 1;

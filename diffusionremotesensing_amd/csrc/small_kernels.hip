@@ -328,6 +328,58 @@ int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1
   return DRS_OK;
 }
 
+// All time-embedding MLPs of one forward in ONE launch: grid (B, number of MLPs).  `table` (device memory, written at
+// pack time) holds per MLP: {byte offset of W1, b1, W2, b2 inside `packed`, dim, output column offset}.
+__global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __restrict__ t,
+                                                             const float* __restrict__ inv_freq,
+                                                             const char* __restrict__ packed,
+                                                             const long long* __restrict__ table,
+                                                             float* __restrict__ out, int out_stride, int dim_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* e = smem;
+  float* h = smem + dim_in;
+  const int b = blockIdx.x;
+  const long long* row = table + (size_t)blockIdx.y * 6;
+  const float* W1 = reinterpret_cast<const float*>(packed + row[0]);
+  const float* b1 = reinterpret_cast<const float*>(packed + row[1]);
+  const float* W2 = reinterpret_cast<const float*>(packed + row[2]);
+  const float* b2 = reinterpret_cast<const float*>(packed + row[3]);
+  const int dim_out = (int)row[4];
+  float* o = out + (size_t)b * out_stride + row[5];
+  const float tf = (float)t[b];
+  const int half = dim_in / 2;
+  for (int j = threadIdx.x; j < half; j += blockDim.x) {
+    const float arg = tf * inv_freq[j];
+    e[j] = sinf(arg);
+    e[half + j] = cosf(arg);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < dim_out; c += blockDim.x) {
+    const float* wr = W1 + (size_t)c * dim_in;
+    float acc = 0.f;
+    for (int k = 0; k < dim_in; ++k) acc = fmaf(wr[k], e[k], acc);
+    acc += b1[c];
+    h[c] = acc / (1.f + expf(-acc));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < dim_out; c += blockDim.x) {
+    const float* wr = W2 + (size_t)c * dim_out;
+    float acc = 0.f;
+    for (int k = 0; k < dim_out; ++k) acc = fmaf(wr[k], h[k], acc);
+    acc += b2[c];
+    o[c] = fmaxf(acc, 0.f);
+  }
+}
+int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const char* packed, const long long* table,
+                              int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in, hipStream_t s) {
+  if (B == 0 || nmlp == 0) return DRS_OK;
+  const size_t shmem = (size_t)(dim_in + max_dim) * sizeof(float);
+  hipLaunchKernelGGL(time_mlp_multi_kernel, dim3(B, nmlp), dim3(256), shmem, s, t, inv_freq, packed, table, out,
+                     out_stride, dim_in);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Diffusion element-wise updates (float4 streaming, HBM-bound)
 // ---------------------------------------------------------------------------------------------

@@ -13,10 +13,16 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-3
 TOL_F32 = 2e-5
-IMPLS = [i for i in os.environ.get("DRS_TEST_IMPLS", "direct").split(",") if i]
+# mfma_f16 (single fp16 MFMA per product) measured 1.1e-3 max-rel / 8e-4 rel-L2 on these weights: outside the 1e-3
+# bar, so it is NOT the shipped default and not in the default test list; DRS_TEST_IMPLS=...,mfma_f16 runs it against
+# a 2.5e-3 bound to keep the opt-in mode from regressing.
+TOL_F16_OPT_IN = 2.5e-3
+IMPLS = [i for i in os.environ.get("DRS_TEST_IMPLS", "direct,mfma_f32,mfma_bf16x3").split(",") if i]
 
 
 def _tol(impl):
+    if impl == "mfma_f16":
+        return TOL_F16_OPT_IN
     return TOL_F32 if impl in ("direct", "mfma_f32") else TOL
 
 
