@@ -14,12 +14,13 @@ IMPL_DIRECT, IMPL_MFMA_F32, IMPL_MFMA_BF16X3, IMPL_MFMA_F16 = 0, 1, 2, 3
 IMPL_BY_NAME = {"direct": IMPL_DIRECT, "mfma_f32": IMPL_MFMA_F32, "mfma_bf16x3": IMPL_MFMA_BF16X3,
                 "mfma_f16": IMPL_MFMA_F16}
 FWD_REUSE_COND = 1
+PLAN_KEEP_ALL = 1
 
 
 class UNetConfig(C.Structure):
     _fields_ = [("batch", C.c_int), ("lr_batch", C.c_int), ("image_channels", C.c_int), ("out_dim", C.c_int),
                 ("height", C.c_int), ("width", C.c_int), ("magnification", C.c_int), ("impl", C.c_int),
-                ("bn_eps", C.c_float)]
+                ("bn_eps", C.c_float), ("flags", C.c_int)]
 
 
 # name -> (restype, argtypes); kept in one table so the symbol-export test can walk it

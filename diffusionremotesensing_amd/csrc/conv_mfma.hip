@@ -4,33 +4,211 @@
 //   M = Cout (A operand = weights), N = output positions (B operand = activations), K = taps x Cin.
 // Weights are the MFMA A operand so that the accumulator of a lane holds 4 CONSECUTIVE output channels of one
 // pixel (C/D layout: col = lane&15 -> pixel, row = 4*(lane>>4)+reg -> cout): the epilogue reads bias / residual
-// and writes the channels-last output as 16-byte vectors.
+// and writes the channels-last output as 16-byte vectors, full 128-byte lines per store instruction.
 //
 // Block = 256 threads = 4 waves; output patch = (4*RPW) rows x 16 columns of logical output positions,
 // BN output channels.  Wave w owns rows [w*RPW, (w+1)*RPW) of the patch (one 16-pixel MFMA column block each) and
 // all BN channels.  K loop over chunks of KC input channels:
 //   stage  : the input window (patch + halo of all taps) of KC channels -> LDS, converted to the policy's operand
-//            type; the chunk's weights for all taps and BN channels -> LDS (pre-converted at pack time);
-//   compute: for every tap, MFMA over the window shifted by (dy, dx) - the 3x3 window is re-read from LDS, never
-//            from HBM.
+//            type; the chunk's weights for all taps and BN channels -> LDS (pre-converted at pack time).  The
+//            global loads of chunk c+1 are issued before chunk c is multiplied and live in registers meanwhile;
+//   compute: MFMA over the window shifted by each tap - the window is re-read from LDS, never from HBM.
+// Three compute schedules share the staging and the epilogue:
+//   GENERIC  runtime tap list (1x1, 2x2 s2, 3x3 s2, single ConvTranspose phases);
+//   CONV3X3  3x3 stride 1: each window-row fragment is read from LDS once and feeds the (up to 3) output rows it
+//            belongs to - half the activation LDS reads of the generic schedule;
+//   CONVT    all 4 output phases of ConvTranspose2d(k3, s2, p1, op1) from ONE staged window: 4 accumulator sets,
+//            each of the 9 weight taps goes to the phase it belongs to (reference UpConvBlock.transform).
 // LDS layout: "slot" = the 16 bytes a lane feeds to one MFMA operand register group (8 x 16-bit or 4 x f32 = the
-// lane's K-group).  Activations: [image][kgroup(4)][window pixel] slots; weights: [image][tap][kgroup(4)][BN]
-// slots.  16 lanes with consecutive pixels (or channels) read 256 contiguous bytes: conflict-free ds_read_b128.
-// No intra-block software pipeline: the footprint is sized for 2 blocks per CU, whose stage/compute phases overlap.
+// lane's K-group).  Activations: [image][kgroup(4)][window pixel] slots, k-groups 2,3 shifted by 128 B; weights:
+// [image][tap][kgroup(4)][BN] slots.  16 lanes with consecutive pixels (or channels) read 256 contiguous bytes:
+// conflict-free ds_read_b128; the staging lane order makes the ds_write_b128 conflict-free as well.
+// The footprint is sized for 2 blocks per CU.
 #include <stdlib.h>
-
-#include "drs_common.h"
 
 #include "mfma_policy.h"
 
-template <class P, int BN, int RPW>
+enum { MODE_GENERIC = 0, MODE_CONV3X3 = 1, MODE_CONVT = 2, MODE_CONV3X3_FUSE = 3 };
+
+// ---- epilogue of RPW rows x NT channel tiles held in MFMA layout ---------------------------------------------------
+// Lane (lr, kg) holds channels t*16 + kg*4 .. +3 of pixel lr for every n-tile t.  Pairs of n-tiles are exchanged
+// between lanes lr and lr^8 (one DPP row rotate) so that each store instruction covers 8 pixels x 32 channels =
+// full 128-byte lines: pass h=0 writes pixels 0..7 of the row, pass h=1 pixels 8..15; lanes lr < 8 carry the even
+// n-tile of the pair, lanes lr >= 8 the odd one.  Residual / gate loads use the same mapping and are issued per
+// row group before the arithmetic (addresses clamped, stores predicated).
+template <int RPW, int NT, bool FUSE>
+__device__ __forceinline__ void tile_epilogue(const TapConv& d, f32x4 (&acc)[RPW][NT], int n, int n0, int ty0, int tx0,
+                                              int wave, int lr, int kg, int out_oy, int out_ox) {
+  constexpr int NP = NT / 2;
+  constexpr int RG = RPW > 2 ? 2 : RPW;  // rows whose loads are in flight together (bounded register footprint)
+  const bool lo = lr < 8;
+  const int pl = lr & 7;
+  const int csel = (lo ? 0 : 16) + kg * 4;
+  float4 bias4[NP], post4[NP];
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) {
+    const int co = n0 + pr * 32 + csel;
+    bias4[pr] = d.bias ? *reinterpret_cast<const float4*>(d.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    post4[pr] = d.post_add ? *reinterpret_cast<const float4*>(d.post_add + (size_t)n * d.post_cs + co)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 fw[4][NP];
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr)
+        fw[j][pr] = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)min(j, d.fuse_dim - 1) * d.Cout + n0 + pr * 32 + csel);
+  }
+#pragma unroll
+  for (int rg = 0; rg < RPW; rg += RG) {
+    bool valid[RG][2];
+    unsigned opix[RG][2];
+    int oyx[RG][2][2];
+    float gv[RG][2];
+    float4 res4[RG][2][NP];
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ty = ty0 + wave * RPW + rg + rr, tx = tx0 + pl + 8 * h;
+        valid[rr][h] = ty < d.TH && tx < d.TW;
+        const int oy = min(ty, d.TH - 1) * d.out_scale + out_oy, ox = min(tx, d.TW - 1) * d.out_scale + out_ox;
+        oyx[rr][h][0] = oy; oyx[rr][h][1] = ox;
+        opix[rr][h] = ((unsigned)n * d.OH + oy) * d.OW + ox;
+        if (d.gate) gv[rr][h] = d.gate[((size_t)n * (d.OH >> 1) + (oy >> 1)) * (d.OW >> 1) + (ox >> 1)];
+        if (d.res) {
+          const size_t rp = d.res_bstride_zero ? (size_t)((unsigned)oy * d.OW + ox) : (size_t)opix[rr][h];
+#pragma unroll
+          for (int pr = 0; pr < NP; ++pr)
+            res4[rr][h][pr] = *reinterpret_cast<const float4*>(d.res + rp * d.res_cs + d.res_co + n0 + pr * 32 + csel);
+        }
+      }
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr) {
+      const int r = rg + rr;
+      f32x4 val[2][NP];
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) {
+        f32x4 mine, theirs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float send = lo ? acc[r][2 * pr + 1][j] : acc[r][2 * pr][j];
+          theirs[j] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xf, 0xf, false));
+          mine[j] = lo ? acc[r][2 * pr][j] : acc[r][2 * pr + 1][j];
+        }
+        val[0][pr] = lo ? mine : theirs;   // pass 0: pixel pl     (lo: own even tile,      hi: partner's odd tile)
+        val[1][pr] = lo ? theirs : mine;   // pass 1: pixel pl + 8 (lo: partner's even tile, hi: own odd tile)
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float fz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+          f32x4 v = val[h][pr];
+          if (d.gate) v *= gv[rr][h];
+          v[0] += bias4[pr].x; v[1] += bias4[pr].y; v[2] += bias4[pr].z; v[3] += bias4[pr].w;
+          if (d.relu_pre) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          v[0] += post4[pr].x; v[1] += post4[pr].y; v[2] += post4[pr].z; v[3] += post4[pr].w;
+          if (d.res) {
+            v[0] += res4[rr][h][pr].x; v[1] += res4[rr][h][pr].y; v[2] += res4[rr][h][pr].z; v[3] += res4[rr][h][pr].w;
+          }
+          if (d.relu_post) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (d.out && valid[rr][h])
+            *reinterpret_cast<float4*>(d.out + (size_t)opix[rr][h] * d.out_cs + d.out_co + n0 + pr * 32 + csel) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          if constexpr (FUSE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              fz[j] += v[0] * fw[j][pr].x + v[1] * fw[j][pr].y + v[2] * fw[j][pr].z + v[3] * fw[j][pr].w;
+          }
+        }
+        if constexpr (FUSE) {  // y[j] = sum over the pixel's 32 channels = 8 lanes: lr^8 (tile of the pair) x 4 k-groups
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            fz[j] += __shfl_xor(fz[j], 8);
+            fz[j] += __shfl_xor(fz[j], 16);
+            fz[j] += __shfl_xor(fz[j], 32);
+          }
+          if (valid[rr][h] && lo && kg == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < d.fuse_dim)
+                d.fuse_out[(((size_t)n * d.fuse_dim + j) * d.OH + oyx[rr][h][0]) * d.OW + oyx[rr][h][1]] = fz[j] + d.fuse_b[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- fused 1x1 projection epilogue (the UNet's `output` conv riding on up_convs.2) ------------------------------
+// Works in MFMA layout: lane (lr, kg) holds channels t*16 + kg*4 .. +3 of pixel lr.  y[j] = fuse_b[j] + sum over the 32
+// channels of (acc + bias) * fuse_w[j][co]: 8 in-lane products, then 2 cross-lane steps over the 4 k-group lanes.
+// The 32-channel tensor itself is written only if d.out is set (parity taps); production runs never store it.
+template <int RPW, int NT>
+__device__ __forceinline__ void fuse_epilogue(const TapConv& d, f32x4 (&acc)[RPW][NT], int n, int n0, int ty0, int tx0,
+                                              int wave, int lr, int kg) {
+  float4 bias4[NT], fw[4][NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int co = n0 + t * 16 + kg * 4;
+    bias4[t] = d.bias ? *reinterpret_cast<const float4*>(d.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fw[j][t] = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)min(j, d.fuse_dim - 1) * d.Cout + co);
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int ty = ty0 + wave * RPW + r, tx = tx0 + lr;
+    const bool valid = ty < d.TH && tx < d.TW;
+    const int oy = min(ty, d.TH - 1) * d.out_scale + d.out_oy, ox = min(tx, d.TW - 1) * d.out_scale + d.out_ox;
+    float fz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 v = acc[r][t];
+      v[0] += bias4[t].x; v[1] += bias4[t].y; v[2] += bias4[t].z; v[3] += bias4[t].w;
+      if (d.out && valid)
+        *reinterpret_cast<float4*>(d.out + (((size_t)n * d.OH + oy) * d.OW + ox) * d.out_cs + d.out_co + n0 + t * 16 + kg * 4) =
+            make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fz[j] += v[0] * fw[j][t].x + v[1] * fw[j][t].y + v[2] * fw[j][t].z + v[3] * fw[j][t].w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fz[j] += __shfl_xor(fz[j], 16);
+      fz[j] += __shfl_xor(fz[j], 32);
+    }
+    if (valid && kg == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < d.fuse_dim) d.fuse_out[(((size_t)n * d.fuse_dim + j) * d.OH + oy) * d.OW + ox] = fz[j] + d.fuse_b[j];
+    }
+  }
+}
+
+template <int MODE, int RPW>
+struct ModeTraits {
+  // window slots per thread: generic stride 1 <= 384 px, stride 2 <= 576 px, conv3x3 18x18, convT 9x17
+  static constexpr int A_ITERS = MODE == MODE_CONVT ? 3 : (RPW == 4 ? 6 : 9);
+  static constexpr int NACC = MODE == MODE_CONVT ? 4 : 1;
+};
+
+template <class P, int BN, int RPW, int MODE>
 __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KC = 4 * P::SLOT_CH;
   constexpr int TH = 4 * RPW, TW = 16, NT = BN / 16;
-  constexpr int A_ITERS = (RPW == 4) ? 6 : 9;            // window slots per thread (stride 1: <= 384 px, stride 2: <= 576 px)
+  constexpr int A_ITERS = ModeTraits<MODE, RPW>::A_ITERS;
+  constexpr int NACC = ModeTraits<MODE, RPW>::NACC;
   constexpr int W_ITERS = (DRS_MAX_TAPS * 4 * BN + 255) / 256;
-  constexpr int V4 = P::SLOT_CH / 4;                     // float4 loads per activation slot
+  constexpr int V4 = P::SLOT_CH / 4;  // float4 loads per activation slot
   char* sA = smem;
   char* sW = smem + (size_t)P::IMAGES * g.a_image;
   // tap tables live in LDS: indexing the by-value kernel argument with a runtime tap would go through scratch
@@ -48,81 +226,101 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
     sTapW[tid] = wt;
   }
   __syncthreads();
-  // XCD-aware patch order: hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD (= each
-  // private L2) a contiguous run of patches so neighbouring halos and the layer's weights hit in L2.
-  int bid = blockIdx.x;
-  {
-    const int nb = gridDim.x;
-    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-  }
-  const int tile_x = bid % g.tiles_x;
-  bid /= g.tiles_x;
-  const int tile_y = bid % g.tiles_y;
-  const int n = bid / g.tiles_y;
-  const int n0 = blockIdx.y * BN;
-  const int ty0 = tile_y * TH, tx0 = tile_x * TW;
-  const int iy0 = ty0 * d.in_stride + g.dy_min, ix0 = tx0 * d.in_stride + g.dx_min;
-  const int nslots = g.IH * g.IW * 4;
+  // Persistent blocks: the grid is 2 blocks per CU (a multiple of 8) and every block walks over its share of the
+  // (patch, channel-group) items.  XCD-aware order: hardware deals consecutive block ids round-robin over the 8 XCDs,
+  // so the blocks with equal blockIdx % 8 (one XCD = one private L2) sweep one contiguous eighth of the items, a run
+  // of consecutive patches at a time: neighbouring halos and the layer's weights are served by that L2.  The loop
+  // below is software-pipelined ACROSS items: the loads of the next item's first chunk are in flight while the
+  // current item is multiplied and written out, so HBM reads, MFMA and HBM writes overlap instead of alternating.
+  const int ngroups = d.Cout / BN;
+  const int nitems = d.N * g.tiles_y * g.tiles_x * ngroups;
+  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+  const int per = (nitems + 7) >> 3;  // items per XCD range
+  const int lo_item = xcd * per, hi_item = min(nitems, lo_item + per);
+  const int span = hi_item - lo_item - j8;
+  const int my_items = span > 0 ? (span + nb8 - 1) / nb8 : 0;
+  const int S = my_items * g.nchunks;  // steps (item x chunk) of this block
+  if (S == 0) return;
+  auto item_of = [&](int ordinal, int& n_, int& ty0_, int& tx0_, int& n0_) {
+    int it = lo_item + ordinal * nb8 + j8;
+    n0_ = (it % ngroups) * BN;
+    it /= ngroups;
+    tx0_ = (it % g.tiles_x) * TW;
+    it /= g.tiles_x;
+    ty0_ = (it % g.tiles_y) * TH;
+    n_ = it / g.tiles_y;
+  };
+  const int npix = g.IH * g.IW;
   const int wslots = d.ntaps * 4 * BN;
 
-  f32x4 acc[RPW][NT];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[NACC][RPW][NT];
 
   // ---- per-thread staging descriptors (chunk independent).  Every address is clamped to a legal one and validity is
   //      a bit mask, so the loads below are straight-line code (no exec-masked branches, no serialising waits). ----
-  // activation slot s = (window pixel p, k-group q), q fastest: 4 lanes read 4*SLOT_CH consecutive channels of a pixel
-  int a_base[A_ITERS];  // element offset of channel 0 of the (clamped) pixel inside image n
-  unsigned a_ok = 0;    // bit it: the slot's pixel lies inside the image
-  const int aq = tid & 3;  // 256 % 4 == 0: the k-group of a thread's slots does not depend on `it`
+  // Lane order inside a group of 16 staging lanes (4 window pixels x 4 k-groups): lanes 0-7 carry k-groups 0 and 2,
+  // lanes 8-15 k-groups 1 and 3, so that the 8 lanes of one ds_write_b128 pass hit 8 different 16-byte bank slots
+  // (k-groups 2,3 sit 128 B further) while a wave still covers whole 128-byte pixel rows in global memory.
+  const int ai = tid & 15;
+  const int aq = ((ai & 1) << 1) | (ai >> 3);  // k-group of all of this thread's slots
+  const int ap0 = (tid >> 4) * 4 + ((ai & 7) >> 1);
+  int a_pyx[A_ITERS];  // window coordinates (row << 16 | col) of this thread's slots (item independent)
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) {
-    const int s = tid + it * 256;
-    const int p = s >> 2;
-    const int py = p / g.IW, px = p - py * g.IW;
-    const int iy = iy0 + py, ix = ix0 + px;
-    const bool ok = s < nslots && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-    const int iyc = min(max(iy, 0), d.H - 1), ixc = min(max(ix, 0), d.W - 1);
-    a_base[it] = (iyc * d.W + ixc) * d.in_cs + d.in_co;
-    a_ok |= (ok ? 1u : 0u) << it;
+    const int p = min(ap0 + it * 64, npix - 1);
+    const int py = p / g.IW;
+    a_pyx[it] = (py << 16) | (p - py * g.IW);
   }
-  int w_goff[W_ITERS];  // byte offset of the slot inside one chunk of one global weight image (clamped)
+  int w_goff[W_ITERS];  // byte offset of the slot inside one chunk of one global weight image, channel group 0
 #pragma unroll
   for (int it = 0; it < W_ITERS; ++it) {
     const int s = min(tid + it * 256, wslots - 1);
     const int nn = s % BN, q = (s / BN) & 3, tap = s / (BN * 4);
-    w_goff[it] = ((sTapW[tap] * 4 + q) * d.Cout + n0 + nn) * 16;
+    w_goff[it] = ((sTapW[tap] * 4 + q) * d.Cout + nn) * 16;
   }
-  const float* in_n = d.in + (size_t)n * d.H * d.W * d.in_cs;
   const bool has_add = d.in_add != nullptr;
-  const float* addp = has_add ? d.in_add + (size_t)n * d.in_add_cs : nullptr;
   const char* wg = reinterpret_cast<const char*>(d.w);
   const size_t w_chunk = (size_t)d.wtaps_total * 4 * d.Cout * 16;
+  const int a_qoff = aq * g.a_plane + (aq >> 1) * 128;  // byte offset of this thread's k-group plane
 
   float4 areg[A_ITERS][V4];
   float4 addreg[V4];
   u32x4 wreg[W_ITERS][P::IMAGES];
+  unsigned a_ok = 0;  // bit it: the slot held in areg[it] lies inside the image
 
-  auto load_chunk = [&](int c) {  // global -> registers, everything issued back to back
+  auto load_step = [&](int k) {  // global -> registers for step k, everything issued back to back
+    const int c = k % g.nchunks;
+    int ln, lty0, ltx0, ln0;
+    item_of(k / g.nchunks, ln, lty0, ltx0, ln0);
+    const int iy0 = lty0 * d.in_stride + g.dy_min, ix0 = ltx0 * d.in_stride + g.dx_min;
+    const float* in_n = d.in + (size_t)ln * d.H * d.W * d.in_cs;
+    int a_base[A_ITERS];  // element offset of channel 0 of the (clamped) pixel inside the image
+    a_ok = 0;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      const int iy = iy0 + (a_pyx[it] >> 16), ix = ix0 + (a_pyx[it] & 0xffff);
+      const bool ok = (ap0 + it * 64) < npix && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+      const int iyc = min(max(iy, 0), d.H - 1), ixc = min(max(ix, 0), d.W - 1);
+      a_base[it] = (iyc * d.W + ixc) * d.in_cs + d.in_co;
+      a_ok |= (ok ? 1u : 0u) << it;
+    }
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
       const int ch = min(c * KC + aq * P::SLOT_CH + 4 * v, d.Cin - 4);
 #pragma unroll
       for (int it = 0; it < A_ITERS; ++it) areg[it][v] = *reinterpret_cast<const float4*>(in_n + a_base[it] + ch);
-      if (has_add) addreg[v] = *reinterpret_cast<const float4*>(addp + ch);
+      if (has_add) addreg[v] = *reinterpret_cast<const float4*>(d.in_add + (size_t)ln * d.in_add_cs + ch);
     }
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it)
 #pragma unroll
       for (int im = 0; im < P::IMAGES; ++im)
-        wreg[it][im] = *reinterpret_cast<const u32x4*>(wg + (size_t)im * g.w_gimage + (size_t)c * w_chunk + w_goff[it]);
+        wreg[it][im] = *reinterpret_cast<const u32x4*>(wg + (size_t)im * g.w_gimage + (size_t)c * w_chunk +
+                                                       (size_t)ln0 * 16 + w_goff[it]);
   };
   auto store_chunk = [&](int c) {  // registers -> LDS (operand conversion happens here)
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-      const int s = tid + it * 256;
+      const int p = ap0 + it * 64;
       const bool pix_ok = (a_ok >> it) & 1u;
       float x[P::SLOT_CH];
 #pragma unroll
@@ -134,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
         }
         x[4 * v] = ok ? a.x : 0.f; x[4 * v + 1] = ok ? a.y : 0.f; x[4 * v + 2] = ok ? a.z : 0.f; x[4 * v + 3] = ok ? a.w : 0.f;
       }
-      if (s < nslots) P::cvt_store(sA, g.a_image, (size_t)aq * g.a_plane + (size_t)(s >> 2) * 16, x);
+      if (p < npix) P::cvt_store(sA, g.a_image, (size_t)a_qoff + (size_t)p * 16, x);
     }
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it)
@@ -144,152 +342,105 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
           *reinterpret_cast<u32x4*>(sW + (size_t)im * g.w_image + (size_t)(tid + it * 256) * 16) = wreg[it][im];
       }
   };
+  const int kg_off = kg * g.a_plane + (kg >> 1) * 128;  // fragment reads: this lane's k-group plane
+  auto a_frag = [&](int wrow, int wcol) {               // window pixel (wrow, wcol) of this lane's k-group
+    return P::load(sA, g.a_image, (size_t)kg_off + (size_t)(wrow * g.IW + wcol) * 16);
+  };
+  auto w_frag = [&](int tap, int t) { return P::load(sW, g.w_image, ((size_t)(tap * 4 + kg) * BN + t * 16 + lr) * 16); };
 
-  if (!(g.debug & 4)) load_chunk(0);
-  for (int c = 0; c < g.nchunks; ++c) {
-    if (c) __syncthreads();  // everyone finished reading the previous chunk's LDS image
+  if (!(g.debug & 4)) load_step(0);
+  int n = 0, ty0 = 0, tx0 = 0, n0 = 0;
+  for (int k = 0; k < S; ++k) {
+    const int c = k % g.nchunks;
+    if (c == 0) {
+      item_of(k / g.nchunks, n, ty0, tx0, n0);
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[a][r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (k) __syncthreads();  // everyone finished reading the previous step's LDS image
     if (!(g.debug & 2)) store_chunk(c);
     __syncthreads();
-    if (c + 1 < g.nchunks && !(g.debug & 4)) load_chunk(c + 1);  // next chunk's loads fly while this one is multiplied
-    if (!(g.debug & 1))
+    if (k + 1 < S && !(g.debug & 4)) load_step(k + 1);  // next step's loads fly while this one is multiplied / written
+    if (!(g.debug & 1)) {
+    if constexpr (MODE == MODE_GENERIC || MODE == MODE_CONV3X3_FUSE) {
       for (int tap = 0; tap < d.ntaps; ++tap) {
         typename P::Frag wf[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          wf[t] = P::load(sW, g.w_image, ((size_t)(tap * 4 + kg) * BN + t * 16 + lr) * 16);
+        for (int t = 0; t < NT; ++t) wf[t] = w_frag(tap, t);
         const int toff = sTapOff[tap];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
           const int py = (wave * RPW + r) * d.in_stride;
           const int px = lr * d.in_stride;
-          const typename P::Frag af = P::load(sA, g.a_image, (size_t)kg * g.a_plane + (size_t)(py * g.IW + px) * 16 + toff);
+          const typename P::Frag af = P::load(sA, g.a_image, (size_t)kg_off + (size_t)(py * g.IW + px) * 16 + toff);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[t], af, acc[r][t]);
+          for (int t = 0; t < NT; ++t) acc[0][r][t] = P::mma(wf[t], af, acc[0][r][t]);
         }
       }
-  }
+    } else if constexpr (MODE == MODE_CONV3X3) {
+      // window row wr (0 .. RPW+1) of this wave feeds output row r = wr - ky with the weights of kernel row ky
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        typename P::Frag wf[3][NT];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wf[ky][t] = w_frag(ky * 3 + kx, t);
+#pragma unroll
+        for (int wr = 0; wr < RPW + 2; ++wr) {
+          const typename P::Frag af = a_frag(wave * RPW + wr, lr + kx);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int r = wr - ky;
+            if (r >= 0 && r < RPW) {
+#pragma unroll
+              for (int t = 0; t < NT; ++t) acc[0][r][t] = P::mma(wf[ky][t], af, acc[0][r][t]);
+            }
+          }
+        }
+      }
+    } else {  // MODE_CONVT: out[2*iy - 1 + ky][2*ix - 1 + kx] += in[iy][ix] * w[ky][kx]
+      // output phase (py, px): py = 0 takes ky = 1 from input row t; py = 1 takes ky = 0 from row t+1 and ky = 2 from row t
+#pragma unroll
+      for (int dyi = 0; dyi < 2; ++dyi)
+#pragma unroll
+        for (int dxi = 0; dxi < 2; ++dxi) {
+          typename P::Frag af[RPW];
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) af[r] = a_frag(wave * RPW + r + dyi, lr + dxi);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              if (((ky == 0) ? 1 : 0) != dyi || ((kx == 0) ? 1 : 0) != dxi) continue;
+              const int ph = ((ky == 1) ? 0 : 1) * 2 + ((kx == 1) ? 0 : 1);
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                const typename P::Frag wf = w_frag(ky * 3 + kx, t);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[ph][r][t] = P::mma(wf, af[r], acc[ph][r][t]);
+              }
+            }
+        }
+    }
+    }  // !(debug & 1)
 
-  // ---- epilogue ----
-  // MFMA layout: lane (lr, kg) holds channels t*16 + kg*4 .. +3 of pixel lr for every n-tile t.  Pairs of n-tiles are
-  // exchanged between lanes lr and lr^8 (one DPP row rotate) so that each store instruction covers 8 pixels x 32
-  // channels = full 128-byte lines: pass h=0 writes pixels 0..7 of the row, pass h=1 pixels 8..15; lanes lr < 8 carry
-  // the even n-tile of the pair, lanes lr >= 8 the odd one.  Residual / gate loads use the same mapping and are all
-  // issued before the arithmetic (addresses clamped, stores predicated).
-  if (g.debug & 8) return;
-  constexpr int NP = NT / 2;
-  const bool lo = lr < 8;
-  const int pl = lr & 7;
-  f32x4 val[RPW][2][NP];
+    if (c == g.nchunks - 1 && !(g.debug & 8)) {  // item complete
+      if constexpr (MODE == MODE_CONVT) {
 #pragma unroll
-  for (int r = 0; r < RPW; ++r)
-#pragma unroll
-    for (int pr = 0; pr < NP; ++pr) {
-      f32x4 mine, theirs;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float send = lo ? acc[r][2 * pr + 1][j] : acc[r][2 * pr][j];
-        theirs[j] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xf, 0xf, false));
-        mine[j] = lo ? acc[r][2 * pr][j] : acc[r][2 * pr + 1][j];
-      }
-      val[r][0][pr] = lo ? mine : theirs;   // pass 0: pixel pl     (lo lanes: own even tile; hi lanes: partner's odd tile)
-      val[r][1][pr] = lo ? theirs : mine;   // pass 1: pixel pl + 8 (lo lanes: partner's even tile; hi lanes: own odd tile)
-    }
-  const int csel = (lo ? 0 : 16) + kg * 4;  // channel offset inside a pair of n-tiles
-  bool valid[RPW][2];
-  size_t opix[RPW][2];
-  int oyx[RPW][2][2];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ty = ty0 + wave * RPW + r, tx = tx0 + pl + 8 * h;
-      valid[r][h] = ty < d.TH && tx < d.TW;
-      const int oy = min(ty, d.TH - 1) * d.out_scale + d.out_oy, ox = min(tx, d.TW - 1) * d.out_scale + d.out_ox;
-      oyx[r][h][0] = oy; oyx[r][h][1] = ox;
-      opix[r][h] = ((size_t)n * d.OH + oy) * d.OW + ox;
-    }
-  float4 bias4[NP], post4[NP];
-#pragma unroll
-  for (int pr = 0; pr < NP; ++pr) {
-    const int co = n0 + pr * 32 + csel;
-    bias4[pr] = d.bias ? *reinterpret_cast<const float4*>(d.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-    post4[pr] = d.post_add ? *reinterpret_cast<const float4*>(d.post_add + (size_t)n * d.post_cs + co)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float gv[RPW][2];
-  float4 res4[RPW][2][NP];
-  if (d.gate) {
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        gv[r][h] = d.gate[((size_t)n * (d.OH >> 1) + (oyx[r][h][0] >> 1)) * (d.OW >> 1) + (oyx[r][h][1] >> 1)];
-  }
-  if (d.res) {
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const size_t rp = d.res_bstride_zero ? ((size_t)oyx[r][h][0] * d.OW + oyx[r][h][1]) : opix[r][h];
-#pragma unroll
-        for (int pr = 0; pr < NP; ++pr)
-          res4[r][h][pr] = *reinterpret_cast<const float4*>(d.res + rp * d.res_cs + d.res_co + n0 + pr * 32 + csel);
-      }
-  }
-  float4 fw[4][NP];
-  if (d.fuse_out) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int pr = 0; pr < NP; ++pr)
-        fw[j][pr] = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)min(j, d.fuse_dim - 1) * d.Cout + n0 + pr * 32 + csel);
-  }
-#pragma unroll
-  for (int r = 0; r < RPW; ++r)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float fz[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int pr = 0; pr < NP; ++pr) {
-        f32x4 v = val[r][h][pr];
-        if (d.gate) v *= gv[r][h];
-        v[0] += bias4[pr].x; v[1] += bias4[pr].y; v[2] += bias4[pr].z; v[3] += bias4[pr].w;
-        if (d.relu_pre) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        v[0] += post4[pr].x; v[1] += post4[pr].y; v[2] += post4[pr].z; v[3] += post4[pr].w;
-        if (d.res) {
-          v[0] += res4[r][h][pr].x; v[1] += res4[r][h][pr].y; v[2] += res4[r][h][pr].z; v[3] += res4[r][h][pr].w;
-        }
-        if (d.relu_post) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        if (d.out && valid[r][h])
-          *reinterpret_cast<float4*>(d.out + opix[r][h] * d.out_cs + d.out_co + n0 + pr * 32 + csel) =
-              make_float4(v[0], v[1], v[2], v[3]);
-        if (d.fuse_out) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            fz[j] += v[0] * fw[j][pr].x + v[1] * fw[j][pr].y + v[2] * fw[j][pr].z + v[3] * fw[j][pr].w;
-        }
-      }
-      if (d.fuse_out) {  // y[j] = sum over the pixel's 32 channels = 8 lanes: lr^8 (n-tile of the pair) x 4 k-groups
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          fz[j] += __shfl_xor(fz[j], 8);
-          fz[j] += __shfl_xor(fz[j], 16);
-          fz[j] += __shfl_xor(fz[j], 32);
-        }
-        if (valid[r][h] && lo && kg == 0) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < d.fuse_dim)
-              d.fuse_out[(((size_t)n * d.fuse_dim + j) * d.OH + oyx[r][h][0]) * d.OW + oyx[r][h][1]] = fz[j] + d.fuse_b[j];
-        }
+        for (int ph = 0; ph < 4; ++ph) tile_epilogue<RPW, NT, false>(d, acc[ph], n, n0, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
+      } else {
+        if constexpr (MODE == MODE_CONV3X3_FUSE)
+          fuse_epilogue<RPW, NT>(d, acc[0], n, n0, ty0, tx0, wave, lr, kg);
+        else
+          tile_epilogue<RPW, NT, false>(d, acc[0], n, n0, ty0, tx0, wave, lr, kg, d.out_oy, d.out_ox);
       }
     }
+  }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
@@ -297,35 +448,45 @@ static constexpr int kLdsLimit = 160 * 1024;
 
 static int slot_ch(int impl) { return impl == DRS_IMPL_MFMA_F32 ? 4 : 8; }
 static int images(int impl) { return impl == DRS_IMPL_MFMA_BF16X3 ? 2 : 1; }
-static int pick_bn(const TapConv& d, int impl) {
-  if (impl == DRS_IMPL_MFMA_BF16X3) return 32;
-  return d.Cout % 64 == 0 ? 64 : 32;
-}
-static int pick_rpw(const TapConv& d) { return d.in_stride == 1 ? 4 : 2; }
 
-static bool geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, int* rpw, size_t* lds) {
-  *bn = pick_bn(d, impl);
-  *rpw = pick_rpw(d);
-  int dy0 = 1 << 30, dy1 = -(1 << 30), dx0 = 1 << 30, dx1 = -(1 << 30);
-  for (int i = 0; i < d.ntaps; ++i) {
-    dy0 = d.dy[i] < dy0 ? d.dy[i] : dy0; dy1 = d.dy[i] > dy1 ? d.dy[i] : dy1;
-    dx0 = d.dx[i] < dx0 ? d.dx[i] : dx0; dx1 = d.dx[i] > dx1 ? d.dx[i] : dx1;
-  }
+static bool is_std3x3(const TapConv& d) {
+  if (d.mode != 0 || d.ntaps != 9 || d.in_stride != 1 || d.out_scale != 1) return false;
+  for (int i = 0; i < 9; ++i)
+    if (d.dy[i] != i / 3 - 1 || d.dx[i] != i % 3 - 1 || d.wtap[i] != i) return false;
+  return true;
+}
+
+static bool geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, int* rpw, int* mode, size_t* lds) {
+  *mode = d.mode == DRS_TAPMODE_CONVT ? MODE_CONVT : (is_std3x3(d) ? MODE_CONV3X3 : MODE_GENERIC);
+  if (*mode == MODE_CONV3X3 && d.fuse_out) *mode = MODE_CONV3X3_FUSE;
+  *bn = 32;  // BN = 64 would need > 256 VGPRs with the prefetch registers live across the epilogue
+  *rpw = (*mode == MODE_CONVT || d.in_stride != 1) ? 2 : 4;
   const int TH = 4 * *rpw, TW = 16;
-  g->dy_min = dy0; g->dx_min = dx0;
-  g->IH = (TH - 1) * d.in_stride + (dy1 - dy0) + 1;
-  g->IW = (TW - 1) * d.in_stride + (dx1 - dx0) + 1;
+  if (*mode == MODE_CONVT) {
+    g->dy_min = 0; g->dx_min = 0; g->IH = TH + 1; g->IW = TW + 1;
+  } else {
+    int dy0 = 1 << 30, dy1 = -(1 << 30), dx0 = 1 << 30, dx1 = -(1 << 30);
+    for (int i = 0; i < d.ntaps; ++i) {
+      dy0 = d.dy[i] < dy0 ? d.dy[i] : dy0; dy1 = d.dy[i] > dy1 ? d.dy[i] : dy1;
+      dx0 = d.dx[i] < dx0 ? d.dx[i] : dx0; dx1 = d.dx[i] > dx1 ? d.dx[i] : dx1;
+    }
+    g->dy_min = dy0; g->dx_min = dx0;
+    g->IH = (TH - 1) * d.in_stride + (dy1 - dy0) + 1;
+    g->IW = (TW - 1) * d.in_stride + (dx1 - dx0) + 1;
+  }
+  const int a_iters = *mode == MODE_CONVT ? 3 : (*rpw == 4 ? 6 : 9);
+  if (g->IH * g->IW > a_iters * 64) return false;
   g->tiles_x = drs_cdiv(d.TW, TW);
   g->tiles_y = drs_cdiv(d.TH, TH);
   const int KC = 4 * slot_ch(impl);
   g->nchunks = drs_cdiv(d.Cin, KC);
   g->a_plane = (g->IH * g->IW * 16 + 255) / 256 * 256;
-  g->a_image = 4 * g->a_plane;
+  g->a_image = 4 * g->a_plane + 128;
   g->w_image = d.ntaps * 4 * *bn * 16;
   g->w_gimage = g->nchunks * d.wtaps_total * 4 * d.Cout * 16;
-  *lds = (size_t)images(impl) * ((size_t)g->a_image + g->w_image) + 128;  // + tap tables
   static const int dbg = getenv("DRS_DEBUG_FLAGS") ? atoi(getenv("DRS_DEBUG_FLAGS")) : 0;
   g->debug = dbg;
+  *lds = (size_t)images(impl) * ((size_t)g->a_image + g->w_image) + 128;  // + tap tables
   return *lds <= (size_t)kLdsLimit;
 }
 
@@ -334,55 +495,65 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
   if (d.Cout % 32 != 0 || d.Cin % 4 != 0) return false;
   if (d.out_nchw || d.sigmoid) return false;
   if (d.ntaps < 1) return false;
-  if (d.fuse_out && (d.Cout != 32 || d.fuse_dim > 4)) return false;
+  if (d.fuse_out && (d.Cout != 32 || d.fuse_dim > 4 || (d.in && !is_std3x3(d)) || d.res || d.gate || d.post_add ||
+                     d.relu_pre || d.relu_post))
+    return false;
   if (d.in == nullptr) return true;  // shape-only probe (weight packing): spatial details decided per launch
   if ((d.in_cs & 3) || (d.in_co & 3) || (d.out_cs & 3) || (d.out_co & 3)) return false;
   if (d.res && ((d.res_cs & 3) || (d.res_co & 3))) return false;
   if (d.post_add && (d.post_cs & 3)) return false;
   if (d.in_add && (d.in_add_cs & 3)) return false;
   if (d.in_stride != 1 && d.in_stride != 2) return false;
-  MfmaGeom g; int bn, rpw; size_t lds;
-  return geom(d, impl, &g, &bn, &rpw, &lds);
+  if (d.mode == DRS_TAPMODE_CONVT && (d.ntaps != 9 || d.in_stride != 1 || d.out_scale != 2)) return false;
+  MfmaGeom g; int bn, rpw, mode; size_t lds;
+  return geom(d, impl, &g, &bn, &rpw, &mode, &lds);
 }
 
-template <class P, int BN, int RPW>
+template <class P, int BN, int RPW, int MODE>
 static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t s) {
-  auto kern = tapconv_mfma_kernel<P, BN, RPW>;
+  auto kern = tapconv_mfma_kernel<P, BN, RPW, MODE>;
   static bool attr_done = false;  // per instantiation
+  static int num_cu = 0;
   if (!attr_done) {
     DRS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kLdsLimit));
+    int dev = 0;
+    DRS_CHECK_HIP(hipGetDevice(&dev));
+    DRS_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_done = true;
   }
-  dim3 grid((unsigned)((size_t)d.N * g.tiles_x * g.tiles_y), d.Cout / BN);
+  // persistent grid: 2 blocks per CU (what the LDS footprint admits), a multiple of the 8 XCDs, never more than items
+  const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / BN);
+  static const int per_cu = getenv("DRS_BLOCKS_PER_CU") ? atoi(getenv("DRS_BLOCKS_PER_CU")) : 2;
+  long long blocks = (long long)num_cu * per_cu;
+  if (blocks > nitems) blocks = nitems;
+  blocks = (blocks + 7) / 8 * 8;
+  dim3 grid((unsigned)blocks);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d, g);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
 
 template <class P>
-static int launch_p(const TapConv& d, const MfmaGeom& g, int bn, int rpw, size_t lds, hipStream_t s) {
-  if constexpr (P::IMAGES == 1) {  // the split-bf16 policy always runs BN = 32 (LDS budget for 2 blocks per CU)
-    if (bn == 64 && rpw == 4) return launch_t<P, 64, 4>(d, g, lds, s);
-    if (bn == 64 && rpw == 2) return launch_t<P, 64, 2>(d, g, lds, s);
-  }
-  if (bn == 32 && rpw == 4) return launch_t<P, 32, 4>(d, g, lds, s);
-  if (bn == 32 && rpw == 2) return launch_t<P, 32, 2>(d, g, lds, s);
-  DrsErr::set("tapconv_mfma: no kernel for BN=%d RPW=%d", bn, rpw);
+static int launch_p(const TapConv& d, const MfmaGeom& g, int bn, int rpw, int mode, size_t lds, hipStream_t s) {
+  if (mode == MODE_CONVT) return launch_t<P, 32, 2, MODE_CONVT>(d, g, lds, s);
+  if (bn == 32 && mode == MODE_CONV3X3) return launch_t<P, 32, 4, MODE_CONV3X3>(d, g, lds, s);
+  if (bn == 32 && mode == MODE_CONV3X3_FUSE) return launch_t<P, 32, 4, MODE_CONV3X3_FUSE>(d, g, lds, s);
+  if (bn == 32 && rpw == 4) return launch_t<P, 32, 4, MODE_GENERIC>(d, g, lds, s);
+  if (bn == 32 && rpw == 2) return launch_t<P, 32, 2, MODE_GENERIC>(d, g, lds, s);
+  DrsErr::set("tapconv_mfma: no kernel for BN=%d RPW=%d mode=%d", bn, rpw, mode);
   return DRS_ERR_SHAPE;
 }
 
 int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
-  DRS_REQUIRE(d.in && d.w && d.out, DRS_ERR_ARG, "tapconv_mfma: null tensor");
+  DRS_REQUIRE(d.in && d.w && (d.out || d.fuse_out), DRS_ERR_ARG, "tapconv_mfma: null tensor");
   DRS_REQUIRE(drs_tapconv_mfma_supported(d, impl), DRS_ERR_SHAPE, "tapconv_mfma: unsupported shape");
   if ((size_t)d.N * d.TH * d.TW == 0) return DRS_OK;
-  MfmaGeom g; int bn, rpw; size_t lds;
-  static const bool no_ws = getenv("DRS_NO_WS") != nullptr;
-  if (!no_ws && drs_tapconv_mfma_ws_geom(d, impl, &g, &bn, &lds)) return drs_launch_tapconv_mfma_ws(d, impl, g, bn, lds, s);
-  geom(d, impl, &g, &bn, &rpw, &lds);
-  if (impl == DRS_IMPL_MFMA_F32) return launch_p<PolicyF32>(d, g, bn, rpw, lds, s);
-  if (impl == DRS_IMPL_MFMA_F16) return launch_p<PolicyF16>(d, g, bn, rpw, lds, s);
-  return launch_p<PolicyBF16X3>(d, g, bn, rpw, lds, s);
+  MfmaGeom g; int bn, rpw, mode; size_t lds;
+  geom(d, impl, &g, &bn, &rpw, &mode, &lds);
+  if (impl == DRS_IMPL_MFMA_F32) return launch_p<PolicyF32>(d, g, bn, rpw, mode, lds, s);
+  if (impl == DRS_IMPL_MFMA_F16) return launch_p<PolicyF16>(d, g, bn, rpw, mode, lds, s);
+  return launch_p<PolicyBF16X3>(d, g, bn, rpw, mode, lds, s);
 }
 
 // ---- weight packing for the MFMA kernels ------------------------------------------------------------------------

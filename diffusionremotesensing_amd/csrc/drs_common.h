@@ -7,6 +7,7 @@
 #include "../../include/drs_hip.h"
 
 #define DRS_MAX_TAPS 9
+#define DRS_TAPMODE_CONVT 2  // TapConv::mode: all 4 phases of ConvTranspose2d(k3,s2,p1,op1) in one launch (MFMA family)
 
 // One fused "tap convolution" over channels-last activations.  Every convolution flavour of the
 // UNet (3x3 s1, 3x3 s2, 1x1, 2x2 s2, and each of the 4 output phases of ConvTranspose 3x3 s2) is
@@ -43,6 +44,7 @@ struct TapConv {
   const float* gate;     // [N][OH/2][OW/2] or null
   int relu_pre, relu_post, sigmoid;
   int out_nchw;          // 1: out is (N,Cout,OH,OW) planar
+  int mode;              // 0 = plain tap list; DRS_TAPMODE_CONVT = fused transposed convolution (TH,TW = input size)
   // optional fused 1x1 projection of the epilogue result (the UNet's `output` conv): fuse_out[n][j][oy][ox] =
   // fuse_b[j] + sum_co v[co] * fuse_w[j][co], j < fuse_dim <= 4; planar NCHW.  MFMA family only, Cout == 32.
   // With fuse_out set, `out` may be null (the wide tensor is then never written).

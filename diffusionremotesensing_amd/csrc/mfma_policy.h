@@ -71,10 +71,7 @@ struct MfmaGeom {
   int a_image;           // bytes of one activation image (4 planes)
   int w_image;           // bytes of one weight image in LDS (ntaps*4*BN*16)
   int w_gimage;          // bytes of one weight image in global memory
-  int debug;             // ablation switches (DRS_DEBUG_FLAGS): 1 skip MFMA phase, 2 skip LDS staging stores, 4 skip global loads
+  int debug;             // ablation switches (DRS_DEBUG_FLAGS): 1 skip MFMA phase, 2 skip LDS staging stores, 4 skip global loads, 8 skip epilogue
 };
 
 
-// conv_mfma_ws.hip: persistent wave-specialised variant for stride-1 flavours
-bool drs_tapconv_mfma_ws_geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, size_t* lds);
-int drs_launch_tapconv_mfma_ws(const TapConv& d, int impl, const MfmaGeom& g, int bn, size_t lds, hipStream_t s);

@@ -18,7 +18,7 @@ void DrsErr::set(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* drs_last_error(void) { return g_err; }
-extern "C" int drs_abi_version(void) { return 1; }
+extern "C" int drs_abi_version(void) { return 2; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -74,6 +74,17 @@ static TapConv convT_phase_desc(const float* in, int N, int H, int W, int Cin, i
   return d;
 }
 
+// All four phases in one MFMA launch: TH x TW = input size, out_scale 2, the 9 weight taps in storage order.
+static TapConv convT_fused_desc(const float* in, int N, int H, int W, int Cin, int in_cs, int in_co, const float* w,
+                                const float* bias, float* out, int Cout, int out_cs, int out_co) {
+  TapConv d = convT_phase_desc(in, N, H, W, Cin, in_cs, in_co, w, bias, out, Cout, out_cs, out_co, 1, 1);
+  d.mode = DRS_TAPMODE_CONVT;
+  d.out_oy = 0; d.out_ox = 0;
+  d.ntaps = 9;
+  for (int i = 0; i < 9; ++i) { d.dy[i] = 0; d.dx[i] = 0; d.wtap[i] = i; }
+  return d;
+}
+
 // impl is the family the weights of this layer were packed for: no silent switch at launch time
 static int run_conv(const TapConv& d, int impl, hipStream_t s) {
   if (impl != DRS_IMPL_DIRECT) return drs_launch_tapconv_mfma(d, impl, s);
@@ -82,7 +93,8 @@ static int run_conv(const TapConv& d, int impl, hipStream_t s) {
 // algorithmic work of one tap-convolution (SURVEY.md 8(d) model: 2*MACs; fp32 input + output + weights)
 static double conv_flops(const TapConv& d) { return 2.0 * d.N * d.TH * d.TW * (double)d.Cout * d.Cin * d.ntaps; }
 static double conv_bytes(const TapConv& d, bool count_out_once = true) {
-  const double in = (double)d.N * d.H * d.W * d.Cin, out = (double)d.N * d.TH * d.TW * d.Cout;
+  const double in = (double)d.N * d.H * d.W * d.Cin;
+  const double out = (double)d.N * d.TH * d.TW * d.Cout * (d.mode == DRS_TAPMODE_CONVT ? 4 : 1);
   (void)count_out_once;
   return 4.0 * (in + out + (double)d.ntaps * d.Cin * d.Cout);
 }
@@ -147,7 +159,7 @@ extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, f
   if ((rc = drs_launch_nchw_to_nhwc(x, xin, N, Cin, H, W, Cin, 0, s))) return rc;
 
   // decide the kernel family on a probe descriptor, then pack in that family's layout
-  TapConv probe = transposed ? convT_phase_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0, 1, 1)
+  TapConv probe = transposed ? convT_fused_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0)
                              : conv_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0, KH, KW, stride, pad);
   const bool mfma = impl != DRS_IMPL_DIRECT && drs_tapconv_mfma_supported(probe, impl);
   if (mfma)
@@ -159,6 +171,10 @@ extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, f
   const int use_impl = mfma ? impl : DRS_IMPL_DIRECT;
   if (!transposed) {
     TapConv d = probe;
+    d.relu_pre = relu;
+    if ((rc = run_conv(d, use_impl, s))) return rc;
+  } else if (mfma) {
+    TapConv d = convT_fused_desc(xin, N, H, W, Cin, Cin, 0, pw, pb, yout, Cout, Cout, 0);
     d.relu_pre = relu;
     if ((rc = run_conv(d, use_impl, s))) return rc;
   } else {
@@ -513,7 +529,7 @@ static void prof_end(drs_plan* plan, hipStream_t s) {
 static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d, hipStream_t s) {
   std::string name = plan->params[L.w].name;
   name = name.substr(0, name.size() - 7);  // strip ".weight"
-  if (d.out_scale == 2) name += ".phase" + std::to_string(d.out_oy * 2 + d.out_ox);
+  if (d.out_scale == 2 && d.mode != DRS_TAPMODE_CONVT) name += ".phase" + std::to_string(d.out_oy * 2 + d.out_ox);
   prof_begin(plan, name, conv_flops(d), conv_bytes(d), s);
   const int rc = run_conv(d, L.mfma ? plan->cfg.impl : DRS_IMPL_DIRECT, s);
   prof_end(plan, s);
@@ -672,7 +688,12 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
       d.in_add = temb + st.mlp.temb_off; d.in_add_cs = plan->temb_total;
       RUN(plan_conv(plan, st.conv, d, s));
     }
-    for (int py = 0; py < 2; ++py)  // transform: ConvTranspose2d, into cat[:, :Cc]   (:206, :376)
+    if (st.transform.mfma) {  // transform: ConvTranspose2d, into cat[:, :Cc]   (:206, :376), 4 phases in one launch
+      TapConv d = convT_fused_desc(TP(plan->t_U[i]), B, lh, lw, Cc, Cc, 0, PW(st.transform), PB(st.transform), cat, Cc,
+                                   Cc + Ch, 0);
+      RUN(plan_conv(plan, st.transform, d, s));
+    } else
+    for (int py = 0; py < 2; ++py)
       for (int px = 0; px < 2; ++px) {
         TapConv d = convT_phase_desc(TP(plan->t_U[i]), B, lh, lw, Cc, Cc, 0, PW(st.transform), PB(st.transform), cat, Cc,
                                      Cc + Ch, 0, py, px);
@@ -686,6 +707,7 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
         d.fuse_b = (const float*)(pk + plan->o_out_b);
         d.fuse_out = out;
         d.fuse_dim = c.out_dim;
+        if (!(c.flags & DRS_PLAN_KEEP_ALL)) d.out = nullptr;  // the wide tensor is only a parity tap
         fused_output = true;
       }
       RUN(plan_conv(plan, st.upconv, d, s));

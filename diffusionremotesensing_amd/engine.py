@@ -57,16 +57,18 @@ class HipUNetEngine:
         self._module = weakref.ref(module)
         self.impl = _lib.IMPL_BY_NAME[impl or DEFAULT_IMPL]
         self._plans = {}
+        self.keep_intermediates = False  # True: every block output stays readable (read_tensor), used by parity tests
         self._inv_freq = inv_freq_table(module.time_emb_dim)
         self._inv_freq_c = (C.c_float * self._inv_freq.numel())(*self._inv_freq.tolist())
 
     # -- plan / weights -------------------------------------------------------------------
     def _get_plan(self, B, Bl, H, W, mag, device):
-        key = (B, Bl, H, W, mag, device.index, self.impl)
+        key = (B, Bl, H, W, mag, device.index, self.impl, self.keep_intermediates)
         plan = self._plans.get(key)
         if plan is None:
             m = self._module()
-            cfg = _lib.UNetConfig(B, Bl, m.image_channels, m.out_dim, H, W, mag, self.impl, 1e-5)
+            cfg = _lib.UNetConfig(B, Bl, m.image_channels, m.out_dim, H, W, mag, self.impl, 1e-5,
+                                  _lib.PLAN_KEEP_ALL if self.keep_intermediates else 0)
             plan = _Plan(_lib.load(), cfg, device)
             self._plans[key] = plan
         return plan

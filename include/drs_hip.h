@@ -110,7 +110,11 @@ typedef struct drs_unet_config {
   int magnification;  /* lr_img is (height/mag, width/mag) */
   int impl;           /* DRS_IMPL_* used for the wide convolutions */
   float bn_eps;       /* 1e-5 */
+  int flags;          /* DRS_PLAN_* */
 } drs_unet_config;
+/* Keep every intermediate activation readable through drs_unet_read_tensor (parity tests).  Without it the
+ * 32-channel output of up_convs.2 is never written: the final 1x1 `output` conv is fused into its epilogue. */
+#define DRS_PLAN_KEEP_ALL 1
 
 int drs_unet_plan_create(drs_plan** plan, const drs_unet_config* cfg);
 void drs_unet_plan_destroy(drs_plan* plan);

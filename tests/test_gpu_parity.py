@@ -155,8 +155,12 @@ def test_unet_blocks_golden(dev, model, golden, impl):
     x, t, lr = golden_inputs("g3", 2, 2, 3, 16, 2, 1500)
     eng = model.hip_engine()
     eng.set_impl(impl)
-    with torch.no_grad():
-        out = model(x.to(dev), t.to(dev), lr.to(dev), 2)
+    eng.keep_intermediates = True  # production plans never write up_convs.2 (fused with the output conv)
+    try:
+        with torch.no_grad():
+            out = model(x.to(dev), t.to(dev), lr.to(dev), 2)
+    finally:
+        eng.keep_intermediates = False
     _assert_close(out, torch.from_numpy(golden["g3_out"]), _tol(impl), "g3 output")
     checked = 0
     for k, v in golden.items():

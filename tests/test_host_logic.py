@@ -36,7 +36,7 @@ def test_plan_param_names_exist_in_state_dict():
     import ctypes as C
     from diffusionremotesensing_amd import _lib
     lib = _lib.load()
-    cfg = _lib.UNetConfig(2, 1, 3, 3, 64, 64, 2, 0, 1e-5)
+    cfg = _lib.UNetConfig(2, 1, 3, 3, 64, 64, 2, 0, 1e-5, 0)
     h = C.c_void_p()
     assert lib.drs_unet_plan_create(C.byref(h), C.byref(cfg)) == 0
     sd = _model().state_dict()
@@ -49,12 +49,12 @@ def test_plan_param_names_exist_in_state_dict():
     live = {k for k, _ in _model().named_parameters()} - set(names)
     assert sorted(live) == sorted(f"{b}.conv_upsampled_lr_img.{w}" for b in ("conv_blocks.1", "conv_blocks.2", "bottle_neck")
                                   for w in ("weight", "bias"))
-    assert lib.drs_unet_workspace_bytes(h) > 0 and lib.drs_unet_packed_bytes(h) > 4383058 * 4
+    assert lib.drs_unet_workspace_bytes(h) > 0 and lib.drs_unet_packed_bytes(h) > (4383058 - 387520) * 4
     lib.drs_unet_plan_destroy(h)
-    bad = _lib.UNetConfig(2, 3, 3, 3, 64, 64, 2, 0, 1e-5)
+    bad = _lib.UNetConfig(2, 3, 3, 3, 64, 64, 2, 0, 1e-5, 0)
     assert lib.drs_unet_plan_create(C.byref(h), C.byref(bad)) == 2
     assert b"lr batch" in lib.drs_last_error()
-    bad = _lib.UNetConfig(2, 2, 3, 3, 60, 64, 2, 0, 1e-5)
+    bad = _lib.UNetConfig(2, 2, 3, 3, 60, 64, 2, 0, 1e-5, 0)
     assert lib.drs_unet_plan_create(C.byref(h), C.byref(bad)) == 2
 
 
