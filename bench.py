@@ -136,19 +136,44 @@ def main():
         with torch.no_grad():
             x.copy_(x_cpu)
             ops = engine.profile_forward(x, t.fill_(750), lr, MAG, iters=5)
-        conv = [(n, ms, fl, by) for n, ms, fl, by in ops if fl > 0 and n not in ("lr_branch", "conv0")]
+        # dominant kernel = the 3x3 stride-1 implicit-GEMM instantiation (tapconv_mfma_kernel<policy, 32, 4, CONV3X3>):
+        # every conv1 / conv2 / skip conv of the residual blocks, ups.*.conv and up_convs.0/1 (up_convs.2 is the
+        # fused-projection instantiation and is listed separately).  achieved = algorithmic FLOPs of those launches
+        # (2*MACs) / their HIP-event durations, i.e. FLOPs per launch / average launch duration.
+        def is_dom(name):
+            return (name.endswith((".conv1.0", ".conv2.0", ".conv_upsampled_lr_img")) or
+                    (name.startswith("ups.") and name.endswith(".conv")) or name in ("up_convs.0", "up_convs.1"))
+        conv = [o for o in ops if o[2] > 0 and o[0] not in ("lr_branch", "conv0")]
+        dom = [o for o in conv if is_dom(o[0])] if args.impl != "direct" else conv
         conv_ms = sum(o[1] for o in conv)
-        conv_fl = sum(o[2] for o in conv)
-        all_ms = sum(o[1] for o in ops)
+        dom_ms = sum(o[1] for o in dom)
+        dom_fl = sum(o[2] for o in dom)
+        dom_by = sum(o[3] for o in dom)
+        all_ms = sum(o[1] for o in ops if o[0] != "lr_branch")  # the step reuses the cached LR conditioning
         top = sorted(ops, key=lambda o: -o[1])[:6]
-        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        achieved = dom_fl / (dom_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.impl]
-        roofline = {"bound": "mfma", "kernel": "tap-convolution family (%d launches/forward)" % len(conv),
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if args.impl == "mfma_bf16x3" and os.path.exists(tpath):  # PMC passes cannot run inside this process
+            for kname, e in json.load(open(tpath))["kernels"].items():
+                if "PolicyBF16X3, 32, 4, 1" in kname:
+                    traffic = round(e["hbm_bytes_per_launch"])
+        mfma_per_product = 3 if args.impl == "mfma_bf16x3" else 1
+        roofline = {"bound": "mfma",
+                    "kernel": ("tapconv_mfma_kernel<%s, 32, 4, CONV3X3>" % args.impl) if args.impl != "direct"
+                    else "tapconv_direct_kernel",
+                    "launches_per_forward": len(dom),
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
-                    "traffic": None,
+                    "flops_per_launch": round(dom_fl / len(dom)), "avg_launch_us": round(1e3 * dom_ms / len(dom), 2),
+                    "algorithmic_bytes_per_launch": round(dom_by / len(dom)),
+                    "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+                    if traffic else None,
+                    "mfma_instructions_per_product": mfma_per_product,
+                    "mfma_pipe_frac": round(mfma_per_product * achieved / peak, 5),
                     "forward_ms_sum_of_ops": round(all_ms, 4), "conv_ms": round(conv_ms, 4),
-                    "hbm_equiv_GBs": round(MB_PER_FWD / 1e3 / (all_ms * 1e-3), 1),
-                    "hbm_equiv_frac": round(MB_PER_FWD / 1e3 / (all_ms * 1e-3) / HBM_PEAK_GBS, 5),
+                    "forward_hbm_GBs_algorithmic": round(MB_PER_FWD / 1e3 / (all_ms * 1e-3), 1),
+                    "forward_hbm_frac_of_8TBs": round(MB_PER_FWD / 1e3 / (all_ms * 1e-3) / HBM_PEAK_GBS, 5),
                     "top_ops_ms": {n: round(ms, 4) for n, ms, _, _ in top}}
         result = {
             "metric": "unet_denoise_steps_per_s", "value": round(value, 4), "unit": "batch16_steps/s",
