@@ -49,6 +49,10 @@ __device__ __forceinline__ void tile_epilogue(const TapConv& d, f32x4 (&acc)[RPW
   for (int pr = 0; pr < NP; ++pr) {
     const int co = n0 + pr * 32 + csel;
     bias4[pr] = d.bias ? *reinterpret_cast<const float4*>(d.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias2) {
+      const float4 b2 = *reinterpret_cast<const float4*>(d.bias2 + co);
+      bias4[pr].x += b2.x; bias4[pr].y += b2.y; bias4[pr].z += b2.z; bias4[pr].w += b2.w;
+    }
     post4[pr] = d.post_add ? *reinterpret_cast<const float4*>(d.post_add + (size_t)n * d.post_cs + co)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -200,7 +204,7 @@ struct ModeTraits {
   static constexpr int NACC = MODE == MODE_CONVT ? 4 : 1;
 };
 
-template <class P, int BN, int RPW, int MODE>
+template <class P, int BN, int RPW, int MODE, bool HAS2>
 __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KC = 4 * P::SLOT_CH;
@@ -239,7 +243,8 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   const int lo_item = xcd * per, hi_item = min(nitems, lo_item + per);
   const int span = hi_item - lo_item - j8;
   const int my_items = span > 0 ? (span + nb8 - 1) / nb8 : 0;
-  const int S = my_items * g.nchunks;  // steps (item x chunk) of this block
+  const int nck = g.nchunks + (HAS2 ? g.nchunks2 : 0);  // K-chunks per item: main input, then the optional second input
+  const int S = my_items * nck;            // steps (item x chunk) of this block
   if (S == 0) return;
   auto item_of = [&](int ordinal, int& n_, int& ty0_, int& tx0_, int& n0_) {
     int it = lo_item + ordinal * nb8 + j8;
@@ -263,13 +268,12 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   const int ai = tid & 15;
   const int aq = ((ai & 1) << 1) | (ai >> 3);  // k-group of all of this thread's slots
   const int ap0 = (tid >> 4) * 4 + ((ai & 7) >> 1);
-  int a_pyx[A_ITERS];  // window coordinates (row << 16 | col) of this thread's slots (item independent)
-#pragma unroll
-  for (int it = 0; it < A_ITERS; ++it) {
+  // window coordinates of slot pixel p: py = p / IW through a 16-bit reciprocal (exact for p < 1024, IW <= 64)
+  auto win_yx = [&](int it, int& py, int& px) {
     const int p = min(ap0 + it * 64, npix - 1);
-    const int py = p / g.IW;
-    a_pyx[it] = (py << 16) | (p - py * g.IW);
-  }
+    py = (p * g.iw_magic) >> 16;
+    px = p - py * g.IW;
+  };
   int w_goff[W_ITERS];  // byte offset of the slot inside one chunk of one global weight image, channel group 0
 #pragma unroll
   for (int it = 0; it < W_ITERS; ++it) {
@@ -287,35 +291,69 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   u32x4 wreg[W_ITERS][P::IMAGES];
   unsigned a_ok = 0;  // bit it: the slot held in areg[it] lies inside the image
 
+  bool held_second = false;  // the registers hold a chunk of the second input
+  int held_cc = 0;           // its chunk index within its input
   auto load_step = [&](int k) {  // global -> registers for step k, everything issued back to back
-    const int c = k % g.nchunks;
+    const int c = k % nck;
     int ln, lty0, ltx0, ln0;
-    item_of(k / g.nchunks, ln, lty0, ltx0, ln0);
-    const int iy0 = lty0 * d.in_stride + g.dy_min, ix0 = ltx0 * d.in_stride + g.dx_min;
-    const float* in_n = d.in + (size_t)ln * d.H * d.W * d.in_cs;
+    item_of(k / nck, ln, lty0, ltx0, ln0);
+    held_second = HAS2 && c >= g.nchunks;
+    held_cc = held_second ? c - g.nchunks : c;
     int a_base[A_ITERS];  // element offset of channel 0 of the (clamped) pixel inside the image
     a_ok = 0;
+    if (!held_second) {
+      const int iy0 = lty0 * d.in_stride + g.dy_min, ix0 = ltx0 * d.in_stride + g.dx_min;
+      const float* in_n = d.in + (size_t)ln * d.H * d.W * d.in_cs;
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      const int iy = iy0 + (a_pyx[it] >> 16), ix = ix0 + (a_pyx[it] & 0xffff);
-      const bool ok = (ap0 + it * 64) < npix && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-      const int iyc = min(max(iy, 0), d.H - 1), ixc = min(max(ix, 0), d.W - 1);
-      a_base[it] = (iyc * d.W + ixc) * d.in_cs + d.in_co;
-      a_ok |= (ok ? 1u : 0u) << it;
+      for (int it = 0; it < A_ITERS; ++it) {
+        int py, px;
+        win_yx(it, py, px);
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool ok = (ap0 + it * 64) < npix && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+        const int iyc = min(max(iy, 0), d.H - 1), ixc = min(max(ix, 0), d.W - 1);
+        a_base[it] = (iyc * d.W + ixc) * d.in_cs + d.in_co;
+        a_ok |= (ok ? 1u : 0u) << it;
+      }
+#pragma unroll
+      for (int v = 0; v < V4; ++v) {
+        const int ch = min(held_cc * KC + aq * P::SLOT_CH + 4 * v, d.Cin - 4);
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) areg[it][v] = *reinterpret_cast<const float4*>(in_n + a_base[it] + ch);
+        if (has_add) addreg[v] = *reinterpret_cast<const float4*>(d.in_add + (size_t)ln * d.in_add_cs + ch);
+      }
+#pragma unroll
+      for (int it = 0; it < W_ITERS; ++it)
+#pragma unroll
+        for (int im = 0; im < P::IMAGES; ++im)
+          wreg[it][im] = *reinterpret_cast<const u32x4*>(wg + (size_t)im * g.w_gimage + (size_t)held_cc * w_chunk +
+                                                         (size_t)ln0 * 16 + w_goff[it]);
+    } else {
+      // second input: logical position (ty, tx) of the patch, embedded at the top-left of the LDS window image
+      const float* in_n = d.in2 + (size_t)ln * d.H2 * d.W2 * d.in2_cs;
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        int py, px;
+        win_yx(it, py, px);
+        const int iy = lty0 + py, ix = ltx0 + px;
+        const bool ok = (ap0 + it * 64) < npix && py < TH && px < TW && iy < d.H2 && ix < d.W2;
+        const int iyc = min(iy, d.H2 - 1), ixc = min(ix, d.W2 - 1);
+        a_base[it] = (iyc * d.W2 + ixc) * d.in2_cs + d.in2_co;
+        a_ok |= (ok ? 1u : 0u) << it;
+      }
+#pragma unroll
+      for (int v = 0; v < V4; ++v) {
+        const int ch = min(held_cc * KC + aq * P::SLOT_CH + 4 * v, d.Cin2 - 4);
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) areg[it][v] = *reinterpret_cast<const float4*>(in_n + a_base[it] + ch);
+      }
+      {  // 1 tap: 4 * BN weight slots, all in the first staging pass
+        const int s2 = min(tid, 4 * BN - 1);
+        const size_t off = ((size_t)held_cc * 4 * d.Cout + (size_t)(s2 / BN) * d.Cout + ln0 + (s2 % BN)) * 16;
+#pragma unroll
+        for (int im = 0; im < P::IMAGES; ++im)
+          wreg[0][im] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage + off);
+      }
     }
-#pragma unroll
-    for (int v = 0; v < V4; ++v) {
-      const int ch = min(c * KC + aq * P::SLOT_CH + 4 * v, d.Cin - 4);
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) areg[it][v] = *reinterpret_cast<const float4*>(in_n + a_base[it] + ch);
-      if (has_add) addreg[v] = *reinterpret_cast<const float4*>(d.in_add + (size_t)ln * d.in_add_cs + ch);
-    }
-#pragma unroll
-    for (int it = 0; it < W_ITERS; ++it)
-#pragma unroll
-      for (int im = 0; im < P::IMAGES; ++im)
-        wreg[it][im] = *reinterpret_cast<const u32x4*>(wg + (size_t)im * g.w_gimage + (size_t)c * w_chunk +
-                                                       (size_t)ln0 * 16 + w_goff[it]);
   };
   auto store_chunk = [&](int c) {  // registers -> LDS (operand conversion happens here)
 #pragma unroll
@@ -325,9 +363,9 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
       float x[P::SLOT_CH];
 #pragma unroll
       for (int v = 0; v < V4; ++v) {
-        const bool ok = pix_ok && (c * KC + aq * P::SLOT_CH + 4 * v < d.Cin);
+        const bool ok = pix_ok && (held_cc * KC + aq * P::SLOT_CH + 4 * v < (held_second ? d.Cin2 : d.Cin));
         float4 a = areg[it][v];
-        if (has_add) {  // per-(n, ci) input add applies to in-image pixels only (zero padding stays zero)
+        if (has_add && !held_second) {  // per-(n, ci) input add applies to in-image pixels only (zero padding stays zero)
           a.x += addreg[v].x; a.y += addreg[v].y; a.z += addreg[v].z; a.w += addreg[v].w;
         }
         x[4 * v] = ok ? a.x : 0.f; x[4 * v + 1] = ok ? a.y : 0.f; x[4 * v + 2] = ok ? a.z : 0.f; x[4 * v + 3] = ok ? a.w : 0.f;
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
     }
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it)
-      if (tid + it * 256 < wslots) {
+      if (tid + it * 256 < (held_second ? 4 * BN : wslots)) {
 #pragma unroll
         for (int im = 0; im < P::IMAGES; ++im)
           *reinterpret_cast<u32x4*>(sW + (size_t)im * g.w_image + (size_t)(tid + it * 256) * 16) = wreg[it][im];
@@ -351,9 +389,9 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   if (!(g.debug & 4)) load_step(0);
   int n = 0, ty0 = 0, tx0 = 0, n0 = 0;
   for (int k = 0; k < S; ++k) {
-    const int c = k % g.nchunks;
+    const int c = k % nck;
     if (c == 0) {
-      item_of(k / g.nchunks, n, ty0, tx0, n0);
+      item_of(k / nck, n, ty0, tx0, n0);
 #pragma unroll
       for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -366,6 +404,17 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
     __syncthreads();
     if (k + 1 < S && !(g.debug & 4)) load_step(k + 1);  // next step's loads fly while this one is multiplied / written
     if (!(g.debug & 1)) {
+    if (HAS2 && c >= g.nchunks) {  // second input: one tap, stride 1, window origin
+      typename P::Frag wf[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[t] = w_frag(0, t);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const typename P::Frag af = a_frag(wave * RPW + r, lr);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[0][r][t] = P::mma(wf[t], af, acc[0][r][t]);
+      }
+    } else
     if constexpr (MODE == MODE_GENERIC || MODE == MODE_CONV3X3_FUSE) {
       for (int tap = 0; tap < d.ntaps; ++tap) {
         typename P::Frag wf[NT];
@@ -429,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
     }
     }  // !(debug & 1)
 
-    if (c == g.nchunks - 1 && !(g.debug & 8)) {  // item complete
+    if (c == nck - 1 && !(g.debug & 8)) {  // item complete
       if constexpr (MODE == MODE_CONVT) {
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) tile_epilogue<RPW, NT, false>(d, acc[ph], n, n0, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
@@ -484,6 +533,9 @@ static bool geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, int* rpw, int
   g->a_image = 4 * g->a_plane + 128;
   g->w_image = d.ntaps * 4 * *bn * 16;
   g->w_gimage = g->nchunks * d.wtaps_total * 4 * d.Cout * 16;
+  g->nchunks2 = d.in2 ? drs_cdiv(d.Cin2, KC) : 0;
+  g->iw_magic = (65536 + g->IW - 1) / g->IW;
+  g->w2_gimage = g->nchunks2 * 4 * d.Cout * 16;
   static const int dbg = getenv("DRS_DEBUG_FLAGS") ? atoi(getenv("DRS_DEBUG_FLAGS")) : 0;
   g->debug = dbg;
   *lds = (size_t)images(impl) * ((size_t)g->a_image + g->w_image) + 128;  // + tap tables
@@ -505,13 +557,16 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
   if (d.in_add && (d.in_add_cs & 3)) return false;
   if (d.in_stride != 1 && d.in_stride != 2) return false;
   if (d.mode == DRS_TAPMODE_CONVT && (d.ntaps != 9 || d.in_stride != 1 || d.out_scale != 2)) return false;
+  if (d.in2 && (!is_std3x3(d) || d.fuse_out || !d.w2 || (d.Cin2 & 3) || (d.in2_cs & 3) || (d.in2_co & 3) ||
+                d.H2 != d.TH || d.W2 != d.TW))
+    return false;
   MfmaGeom g; int bn, rpw, mode; size_t lds;
   return geom(d, impl, &g, &bn, &rpw, &mode, &lds);
 }
 
-template <class P, int BN, int RPW, int MODE>
+template <class P, int BN, int RPW, int MODE, bool HAS2 = false>
 static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t s) {
-  auto kern = tapconv_mfma_kernel<P, BN, RPW, MODE>;
+  auto kern = tapconv_mfma_kernel<P, BN, RPW, MODE, HAS2>;
   static bool attr_done = false;  // per instantiation
   static int num_cu = 0;
   if (!attr_done) {
@@ -537,6 +592,7 @@ static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t
 template <class P>
 static int launch_p(const TapConv& d, const MfmaGeom& g, int bn, int rpw, int mode, size_t lds, hipStream_t s) {
   if (mode == MODE_CONVT) return launch_t<P, 32, 2, MODE_CONVT>(d, g, lds, s);
+  if (bn == 32 && mode == MODE_CONV3X3 && d.in2) return launch_t<P, 32, 4, MODE_CONV3X3, true>(d, g, lds, s);
   if (bn == 32 && mode == MODE_CONV3X3) return launch_t<P, 32, 4, MODE_CONV3X3>(d, g, lds, s);
   if (bn == 32 && mode == MODE_CONV3X3_FUSE) return launch_t<P, 32, 4, MODE_CONV3X3_FUSE>(d, g, lds, s);
   if (bn == 32 && rpw == 4) return launch_t<P, 32, 4, MODE_GENERIC>(d, g, lds, s);

@@ -45,6 +45,14 @@ struct TapConv {
   int relu_pre, relu_post, sigmoid;
   int out_nchw;          // 1: out is (N,Cout,OH,OW) planar
   int mode;              // 0 = plain tap list; DRS_TAPMODE_CONVT = fused transposed convolution (TH,TW = input size)
+  // optional second input ("K-concat", MFMA family): a 1x1 stride-1 convolution of in2 (same logical grid as the
+  // output positions: pixel (ty, tx), size H2 x W2 = TH x TW) accumulated into the same output before the epilogue:
+  //   acc[co] += sum_ci in2[n][ty][tx][ci] * w2[co][ci];  bias2 is added with bias.
+  // Used for shortcut_conv -> conv2 (reference ResConvBlock :167-171) and w_g -> w_x (AttentionBlock :101-103).
+  const float* in2;
+  int in2_cs, in2_co, Cin2, H2, W2;
+  const float* w2;
+  const float* bias2;
   // optional fused 1x1 projection of the epilogue result (the UNet's `output` conv): fuse_out[n][j][oy][ox] =
   // fuse_b[j] + sum_co v[co] * fuse_w[j][co], j < fuse_dim <= 4; planar NCHW.  MFMA family only, Cout == 32.
   // With fuse_out set, `out` may be null (the wide tensor is then never written).

@@ -71,6 +71,9 @@ struct MfmaGeom {
   int a_image;           // bytes of one activation image (4 planes)
   int w_image;           // bytes of one weight image in LDS (ntaps*4*BN*16)
   int w_gimage;          // bytes of one weight image in global memory
+  int nchunks2;          // K-chunks of the second input (0 = none)
+  int iw_magic;          // ceil(65536 / IW): p / IW == (p * iw_magic) >> 16 for p < 1024
+  int w2_gimage;         // bytes of one weight image of the second input in global memory
   int debug;             // ablation switches (DRS_DEBUG_FLAGS): 1 skip MFMA phase, 2 skip LDS staging stores, 4 skip global loads, 8 skip epilogue
 };
 

@@ -91,12 +91,15 @@ static int run_conv(const TapConv& d, int impl, hipStream_t s) {
   return drs_launch_tapconv_direct(d, s);
 }
 // algorithmic work of one tap-convolution (SURVEY.md 8(d) model: 2*MACs; fp32 input + output + weights)
-static double conv_flops(const TapConv& d) { return 2.0 * d.N * d.TH * d.TW * (double)d.Cout * d.Cin * d.ntaps; }
+static double conv_flops(const TapConv& d) {
+  return 2.0 * d.N * d.TH * d.TW * (double)d.Cout * ((double)d.Cin * d.ntaps + (d.in2 ? d.Cin2 : 0));
+}
 static double conv_bytes(const TapConv& d, bool count_out_once = true) {
   const double in = (double)d.N * d.H * d.W * d.Cin;
   const double out = (double)d.N * d.TH * d.TW * d.Cout * (d.mode == DRS_TAPMODE_CONVT ? 4 : 1);
   (void)count_out_once;
-  return 4.0 * (in + out + (double)d.ntaps * d.Cin * d.Cout);
+  const double in2 = d.in2 ? (double)d.N * d.H2 * d.W2 * d.Cin2 + (double)d.Cin2 * d.Cout : 0.0;
+  return 4.0 * (in + in2 + out + (double)d.ntaps * d.Cin * d.Cout);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -610,7 +613,9 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
   for (int i = 0; i < 4; ++i) {
     const ResBlock& rb = plan->enc[i];
     const int ci = kDown[i], co = kDown[i + 1], hh = H >> i, ww = W >> i;
-    {  // shortcut = BNs(conv1x1(x))
+    // shortcut_conv + BN (1x1) rides inside conv2 as extra K-chunks when both run on the MFMA family ("K-concat")
+    const bool fuse_shortcut = rb.conv2.mfma && rb.shortcut.mfma;
+    if (!fuse_shortcut) {  // shortcut = BNs(conv1x1(x))
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.shortcut), PB(rb.shortcut), TP(plan->t_S[i]), co, co, 0, 1,
                             1, 1, 0);
       RUN(plan_conv(plan, rb.shortcut, d, s));
@@ -630,7 +635,12 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
     {  // out = relu(shortcut + BN2(conv2(h)))
       TapConv d = conv_desc(TP(plan->t_H[i]), B, hh, ww, co, co, 0, PW(rb.conv2), PB(rb.conv2), TP(plan->t_R[i]), co,
                             co, 0, 3, 3, 1, 1);
-      d.res = TP(plan->t_S[i]); d.res_cs = co; d.res_co = 0;
+      if (fuse_shortcut) {
+        d.in2 = xin; d.in2_cs = ci; d.in2_co = 0; d.Cin2 = ci; d.H2 = hh; d.W2 = ww;
+        d.w2 = PW(rb.shortcut); d.bias2 = PB(rb.shortcut);
+      } else {
+        d.res = TP(plan->t_S[i]); d.res_cs = co; d.res_co = 0;
+      }
       d.relu_post = 1;
       RUN(plan_conv(plan, rb.conv2, d, s));
     }
@@ -657,7 +667,9 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
       d.relu_pre = 1;
       RUN(plan_conv(plan, st.gate, d, s));
     }
-    {  // g1 = w_g(g)   (:101)
+    // (fusing w_g into the stride-2 w_x kernel was measured slower: its 16x32 window staging is 4x too large for g)
+    const bool fuse_wg = false;
+    if (!fuse_wg) {  // g1 = w_g(g)   (:101)
       TapConv d = conv_desc(TP(plan->t_G[i]), B, lh, lw, Ch, Ch, 0, PW(st.wg), PB(st.wg), TP(plan->t_Q[i]), Ch, Ch, 0, 1,
                             1, 1, 0);
       RUN(plan_conv(plan, st.wg, d, s));
@@ -665,7 +677,12 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
     {  // relu(g1 + w_x(x))   (:102-103)
       TapConv d = conv_desc(xres, B, 2 * lh, 2 * lw, Ch, Ch, 0, PW(st.wx), PB(st.wx), TP(plan->t_P[i]), Ch, Ch, 0, 2, 2,
                             2, 0);
-      d.res = TP(plan->t_Q[i]); d.res_cs = Ch; d.res_co = 0;
+      if (fuse_wg) {
+        d.in2 = TP(plan->t_G[i]); d.in2_cs = Ch; d.in2_co = 0; d.Cin2 = Ch; d.H2 = lh; d.W2 = lw;
+        d.w2 = PW(st.wg); d.bias2 = PB(st.wg);
+      } else {
+        d.res = TP(plan->t_Q[i]); d.res_cs = Ch; d.res_co = 0;
+      }
       d.relu_post = 1;
       RUN(plan_conv(plan, st.wx, d, s));
     }
