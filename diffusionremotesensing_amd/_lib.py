@@ -15,6 +15,7 @@ IMPL_BY_NAME = {"direct": IMPL_DIRECT, "mfma_f32": IMPL_MFMA_F32, "mfma_bf16x3":
                 "mfma_f16": IMPL_MFMA_F16}
 FWD_REUSE_COND = 1
 PLAN_KEEP_ALL = 1
+PLAN_TRAIN = 2
 
 
 class UNetConfig(C.Structure):

@@ -118,3 +118,10 @@ int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1
                         const float* b2, float* out, int out_stride, int B, int dim_in, int dim_out, hipStream_t s);
 int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const char* packed, const long long* table,
                               int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in, hipStream_t s);
+
+// train-mode BatchNorm (bn_train.hip): statistics of Z, running-stat update, normalise + the block's epilogue
+int drs_launch_bn_train(const float* z, int z_cs, int z_co, long long npix, long long pix_per_image, int C,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, float eps,
+                        float momentum, double* sums_scratch, float* mean, float* rstd, const float* post_add,
+                        int post_cs, const float* res, int res_cs, int res_co, float* out, int out_cs, int out_co,
+                        int relu_pre, int relu_post, hipStream_t s);

@@ -203,6 +203,8 @@ struct ConvLayer {
   int Cout = 0, Cin = 0, taps = 0;
   bool transposed = false, mfma = false;
   size_t w_off = 0, b_off = 0;
+  int t_Z = -1;         // train plans: pre-BatchNorm tensor
+  size_t stats_off = 0;  // train plans: saved batch mean / rstd (2 x Cout floats) in the workspace
 };
 struct PlanarConv { int w = -1, b = -1; int Cout = 0, Cin = 0; size_t w_off = 0, b_off = 0; };
 struct Mlp { int w1, b1, w2, b2, dim; size_t o_w1, o_b1, o_w2, o_b2; int temb_off; };
@@ -239,6 +241,8 @@ struct drs_plan {
   size_t o_inv_freq = 0, o_mlp_table = 0, o_out_w = 0, o_out_b = 0;
   int temb_total = 0;
   std::vector<long long> mlp_table_host;
+  std::vector<const void*> param_ptrs;  // as given to the last drs_unet_pack_weights
+  size_t o_bn_sums = 0;                  // train plans: fp64 scratch for the BatchNorm reductions
   bool packed_ok = false;
   const void* packed_ptr = nullptr;
 
@@ -443,6 +447,26 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     p->Tview("attention_blocks." + si, p->t_CAT[i], Ch, Cc);
     p->t_X[i] = p->T("up_convs." + si, ws, B, Ch, 2 * lh, 2 * lw);
   }
+  if (cfg->flags & DRS_PLAN_TRAIN) {
+    p->o_bn_sums = ws; ws += align_up(2 * 1024 * sizeof(double));
+    auto addz = [&](ConvLayer& L, const std::string& nm, int hh, int ww) {
+      L.stats_off = ws; ws += align_up(2 * (size_t)L.Cout * 4);
+      L.t_Z = p->T(nm + ".pre_bn", ws, B, L.Cout, hh, ww);
+    };
+    for (int i = 0; i < 4; ++i) {
+      const std::string nm = i < 3 ? "conv_blocks." + std::to_string(i) : std::string("bottle_neck");
+      addz(p->enc[i].conv1, nm + ".conv1", H >> i, W >> i);
+      addz(p->enc[i].conv2, nm + ".conv2", H >> i, W >> i);
+      addz(p->enc[i].shortcut, nm + ".shortcut_conv", H >> i, W >> i);
+    }
+    for (int i = 0; i < 3; ++i) {
+      const std::string si = std::to_string(i);
+      const int lh = H >> (3 - i), lw = W >> (3 - i);
+      addz(p->dec[i].gate, "gating_signals." + si, lh, lw);
+      addz(p->dec[i].result, "attention_blocks." + si + ".result", 2 * lh, 2 * lw);
+      addz(p->dec[i].conv, "ups." + si + ".conv_bn", lh, lw);
+    }
+  }
   p->ws_bytes = ws + 256;
   *out = p;
   return DRS_OK;
@@ -479,7 +503,7 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     probe.Cin = L->Cin; probe.Cout = L->Cout; probe.ntaps = L->taps;
     L->mfma = impl != DRS_IMPL_DIRECT && drs_tapconv_mfma_supported(probe, impl);
     const float *g = nullptr, *be = nullptr, *rm = nullptr, *rv = nullptr;
-    if (L->bn >= 0) { g = F(L->bn); be = F(L->bn + 1); rm = F(L->bn + 2); rv = F(L->bn + 3); }
+    if (L->bn >= 0 && !(plan->cfg.flags & DRS_PLAN_TRAIN)) { g = F(L->bn); be = F(L->bn + 1); rm = F(L->bn + 2); rv = F(L->bn + 3); }
     if (L->mfma)
       rc = drs_launch_pack_conv_mfma(F(L->w), F(L->b), g, be, rm, rv, plan->cfg.bn_eps, base + L->w_off,
                                      (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0, impl, s);
@@ -513,6 +537,7 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_b, F(plan->output.b), (size_t)plan->cfg.out_dim * 4,
                                  hipMemcpyDeviceToDevice, s));
   }
+  plan->param_ptrs.assign(params, params + plan->params.size());
   plan->packed_ok = true;
   plan->packed_ptr = packed;
   return DRS_OK;
@@ -561,6 +586,26 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
   auto PW = [&](const ConvLayer& L) { return (const float*)(pk + L.w_off); };
   auto PB = [&](const ConvLayer& L) { return (const float*)(pk + L.b_off); };
   auto TP = [&](int i) { return plan->tp(ws, i); };
+  const bool train = (c.flags & DRS_PLAN_TRAIN) != 0;
+  // A convolution followed by BatchNorm.  Eval: BatchNorm is folded into the weights, one launch.  Train: the raw
+  // convolution writes Z (input add and gate act before the norm and stay in the conv), then batch statistics,
+  // running-stat update and the normalisation carry the rest of the block's epilogue.
+  auto conv_bn = [&](const ConvLayer& L, const TapConv& d) -> int {
+    if (!train) return plan_conv(plan, L, d, s);
+    TapConv zc = d;
+    zc.out = plan->tp(ws, L.t_Z); zc.out_cs = L.Cout; zc.out_co = 0;
+    zc.relu_pre = zc.relu_post = 0; zc.post_add = nullptr; zc.res = nullptr;
+    zc.in2 = nullptr; zc.w2 = nullptr; zc.bias2 = nullptr;
+    int r = plan_conv(plan, L, zc, s);
+    if (r) return r;
+    float* stats = (float*)((char*)ws + L.stats_off);
+    const long long ppi = (long long)d.OH * d.OW;
+    return drs_launch_bn_train(zc.out, L.Cout, 0, (long long)d.N * ppi, ppi, L.Cout,
+                               (const float*)plan->param_ptrs[L.bn], (const float*)plan->param_ptrs[L.bn + 1],
+                               (float*)plan->param_ptrs[L.bn + 2], (float*)plan->param_ptrs[L.bn + 3], c.bn_eps, 0.1f,
+                               (double*)((char*)ws + plan->o_bn_sums), stats, stats + L.Cout, d.post_add, d.post_cs, d.res,
+                               d.res_cs, d.res_co, d.out, d.out_cs, d.out_co, d.relu_pre, d.relu_post, s);
+  };
   int rc;
   if (plan->profiling) {
     for (auto& r : plan->ops) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
@@ -614,11 +659,11 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
     const ResBlock& rb = plan->enc[i];
     const int ci = kDown[i], co = kDown[i + 1], hh = H >> i, ww = W >> i;
     // shortcut_conv + BN (1x1) rides inside conv2 as extra K-chunks when both run on the MFMA family ("K-concat")
-    const bool fuse_shortcut = rb.conv2.mfma && rb.shortcut.mfma;
+    const bool fuse_shortcut = !train && rb.conv2.mfma && rb.shortcut.mfma;
     if (!fuse_shortcut) {  // shortcut = BNs(conv1x1(x))
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.shortcut), PB(rb.shortcut), TP(plan->t_S[i]), co, co, 0, 1,
                             1, 1, 0);
-      RUN(plan_conv(plan, rb.shortcut, d, s));
+      RUN(conv_bn(rb.shortcut, d));
     }
     if (rb.has_skip) {  // conv_upsampled_lr_img(x_skip), x_skip == block input
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.skip), PB(rb.skip), TP(plan->t_K0), co, co, 0, 3, 3, 1, 1);
@@ -630,7 +675,7 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
       d.relu_pre = 1;
       d.post_add = temb + rb.mlp.temb_off; d.post_cs = plan->temb_total;
       if (rb.has_skip) { d.res = TP(plan->t_K0); d.res_cs = co; d.res_co = 0; }
-      RUN(plan_conv(plan, rb.conv1, d, s));
+      RUN(conv_bn(rb.conv1, d));
     }
     {  // out = relu(shortcut + BN2(conv2(h)))
       TapConv d = conv_desc(TP(plan->t_H[i]), B, hh, ww, co, co, 0, PW(rb.conv2), PB(rb.conv2), TP(plan->t_R[i]), co,
@@ -642,7 +687,7 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
         d.res = TP(plan->t_S[i]); d.res_cs = co; d.res_co = 0;
       }
       d.relu_post = 1;
-      RUN(plan_conv(plan, rb.conv2, d, s));
+      RUN(conv_bn(rb.conv2, d));
     }
     if (i < 3) {
       TapConv d = conv_desc(TP(plan->t_R[i]), B, hh, ww, co, co, 0, PW(plan->downs[i]), PB(plan->downs[i]),
@@ -665,7 +710,7 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.gate), PB(st.gate), TP(plan->t_G[i]), Ch, Ch, 0, 1, 1, 1,
                             0);
       d.relu_pre = 1;
-      RUN(plan_conv(plan, st.gate, d, s));
+      RUN(conv_bn(st.gate, d));
     }
     // (fusing w_g into the stride-2 w_x kernel was measured slower: its 16x32 window staging is 4x too large for g)
     const bool fuse_wg = false;
@@ -696,14 +741,14 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
       TapConv d = conv_desc(xres, B, 2 * lh, 2 * lw, Ch, Ch, 0, PW(st.result), PB(st.result), cat, Ch, Cc + Ch, Cc, 1, 1,
                             1, 0);
       d.gate = TP(plan->t_PSI[i]);
-      RUN(plan_conv(plan, st.result, d, s));
+      RUN(conv_bn(st.result, d));
     }
     {  // UpConvBlock: relu(BN(conv(x + relu(time_mlp(t)))))   (:199-205)
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.conv), PB(st.conv), TP(plan->t_U[i]), Cc, Cc, 0, 3, 3, 1,
                             1);
       d.relu_pre = 1;
       d.in_add = temb + st.mlp.temb_off; d.in_add_cs = plan->temb_total;
-      RUN(plan_conv(plan, st.conv, d, s));
+      RUN(conv_bn(st.conv, d));
     }
     if (st.transform.mfma) {  // transform: ConvTranspose2d, into cat[:, :Cc]   (:206, :376), 4 phases in one launch
       TapConv d = convT_fused_desc(TP(plan->t_U[i]), B, lh, lw, Cc, Cc, 0, PW(st.transform), PB(st.transform), cat, Cc,
@@ -724,7 +769,7 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
         d.fuse_b = (const float*)(pk + plan->o_out_b);
         d.fuse_out = out;
         d.fuse_dim = c.out_dim;
-        if (!(c.flags & DRS_PLAN_KEEP_ALL)) d.out = nullptr;  // the wide tensor is only a parity tap
+        if (!(c.flags & (DRS_PLAN_KEEP_ALL | DRS_PLAN_TRAIN))) d.out = nullptr;  // the wide tensor is only a parity tap
         fused_output = true;
       }
       RUN(plan_conv(plan, st.upconv, d, s));

@@ -49,7 +49,8 @@ class _Plan:
 
 class HipUNetEngine:
     """Runs reference `Residual_Attention_UNet_superres.forward` (UNet_model_superres.py:337-379)
-    on the HIP plan.  Eval-mode BatchNorm only in this build: a train-mode call raises."""
+    on the HIP plan.  Eval mode folds BatchNorm; train mode (under no_grad) uses batch statistics and updates the
+    running statistics like nn.BatchNorm2d; autograd through the forward is not built yet."""
 
     def __init__(self, module, variant="superres", impl=None):
         if variant != "superres":
@@ -57,19 +58,22 @@ class HipUNetEngine:
         self._module = weakref.ref(module)
         self.impl = _lib.IMPL_BY_NAME[impl or DEFAULT_IMPL]
         self._plans = {}
+        self._bn_epoch = 0  # bumped by every train-mode forward (running statistics change under the eval plans)
         self.keep_intermediates = False  # True: every block output stays readable (read_tensor), used by parity tests
         self._inv_freq = inv_freq_table(module.time_emb_dim)
         self._inv_freq_c = (C.c_float * self._inv_freq.numel())(*self._inv_freq.tolist())
 
     # -- plan / weights -------------------------------------------------------------------
-    def _get_plan(self, B, Bl, H, W, mag, device):
-        key = (B, Bl, H, W, mag, device.index, self.impl, self.keep_intermediates)
+    def _get_plan(self, B, Bl, H, W, mag, device, train=False):
+        key = (B, Bl, H, W, mag, device.index, self.impl, self.keep_intermediates, train)
         plan = self._plans.get(key)
         if plan is None:
             m = self._module()
             cfg = _lib.UNetConfig(B, Bl, m.image_channels, m.out_dim, H, W, mag, self.impl, 1e-5,
-                                  _lib.PLAN_KEEP_ALL if self.keep_intermediates else 0)
+                                  (_lib.PLAN_KEEP_ALL if self.keep_intermediates else 0) |
+                                  (_lib.PLAN_TRAIN if train else 0))
             plan = _Plan(_lib.load(), cfg, device)
+            plan.train = train
             self._plans[key] = plan
         return plan
 
@@ -89,7 +93,7 @@ class HipUNetEngine:
             if t.numel() != numel:
                 raise RuntimeError(f"parameter {name} has {t.numel()} elements, plan expects {numel}")
             tensors.append(t)
-        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        sig = tuple((t.data_ptr(), t._version) for t in tensors) + (self._bn_epoch,)
         if sig == plan.signature:
             return
         arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -103,10 +107,11 @@ class HipUNetEngine:
     # -- forward ----------------------------------------------------------------------------
     def forward(self, x, timestep, lr_img, magnification_factor, reuse_cond=False, check_weights=True):
         m = self._module()
-        if m.training:
+        train = bool(m.training)
+        if train and torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()):
             raise NotImplementedError(
-                "train-mode forward (batch-statistics BatchNorm + backward) is not part of this build; call "
-                "model.eval() — Diffusion.sample does")
+                "train-mode forward with autograd (backward kernels) is not part of this build; train-mode forwards "
+                "run under torch.no_grad() (batch-statistics BatchNorm, running-stat update), eval-mode everywhere")
         for name, t in (("x", x), ("timestep", timestep), ("lr_img", lr_img)):
             if not isinstance(t, torch.Tensor) or not t.is_cuda:
                 raise RuntimeError(f"{name} must be a tensor on a ROCm device: the UNet forward has no CPU fallback")
@@ -126,7 +131,7 @@ class HipUNetEngine:
         x = x.contiguous()
         lr_img = lr_img.contiguous()
         timestep = timestep.to(torch.int64).contiguous()
-        plan = self._get_plan(B, Bl, H, W, mag, x.device)
+        plan = self._get_plan(B, Bl, H, W, mag, x.device, train)
         with torch.cuda.device(x.device):
             if check_weights or plan.signature is None:
                 self._sync_weights(plan)
@@ -143,6 +148,11 @@ class HipUNetEngine:
                                            plan.ws_bytes, flags, stream)
             _lib.check(st, "drs_unet_forward")
             plan.cond_key = (lr_img.data_ptr(), lr_img._version)
+            if train:  # the kernels updated running_mean / running_var in place; num_batches_tracked follows here
+                self._bn_epoch += 1
+                nbt = [b for k, b in m.named_buffers() if k.endswith("num_batches_tracked")]
+                with torch.no_grad():
+                    torch._foreach_add_(nbt, 1)
         self._last_plan = plan
         return out
 

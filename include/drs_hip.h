@@ -115,6 +115,10 @@ typedef struct drs_unet_config {
 /* Keep every intermediate activation readable through drs_unet_read_tensor (parity tests).  Without it the
  * 32-channel output of up_convs.2 is never written: the final 1x1 `output` conv is fused into its epilogue. */
 #define DRS_PLAN_KEEP_ALL 1
+/* Train-mode plan: BatchNorm uses batch statistics (and updates running_mean / running_var in place through the
+ * parameter pointers given to drs_unet_pack_weights), nothing is folded or fused across a BatchNorm, every
+ * pre-normalisation tensor is kept.  Reference: model.train() + nn.BatchNorm2d defaults (eps 1e-5, momentum 0.1). */
+#define DRS_PLAN_TRAIN 2
 
 int drs_unet_plan_create(drs_plan** plan, const drs_unet_config* cfg);
 void drs_unet_plan_destroy(drs_plan* plan);

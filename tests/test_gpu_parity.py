@@ -293,3 +293,35 @@ def test_end_to_end_sample_golden(dev, model, golden, impl):
     print(f"e2e sample [{impl}]: max-rel {e_max:.3e} rel-L2 {e_l2:.3e} PSNR {psnr:.1f} dB")
     # 49 chained forwards amplify rounding differences; the chain is still held to the per-forward tolerance
     assert e_l2 <= (1e-4 if impl in ("direct", "mfma_f32") else 5e-3) and psnr > 40
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_train_mode_forward_golden(dev, seeded_sd, golden, impl):
+    """model.train() under no_grad: batch-statistics BatchNorm + running-stat update (reference nn.BatchNorm2d
+    defaults) against the reference's own train-mode forward (G5) - output, MSE loss, updated running statistics."""
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    from oracle import unet_oracle as U
+    m = Residual_Attention_UNet_superres(3, 3, dev)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).train()
+    m.hip_engine().set_impl(impl)
+    x, t, lr = golden_inputs("g5", 4, 4, 3, 32, 2, 1500)
+    with torch.no_grad():
+        out = m(x.to(dev), t.to(dev), lr.to(dev), 2)
+    _assert_close(out, torch.from_numpy(golden["g5_out"]), _tol(impl) if impl != "direct" else 5e-5, "g5 train output")
+    noise = synthetic.tensor_normal("g5.noise", (4, 3, 32, 32))
+    loss = torch.nn.functional.mse_loss(out.cpu(), noise).item()
+    assert abs(loss - float(golden["g5_loss"])) <= 2e-3 * float(golden["g5_loss"])
+    sd = m.state_dict()
+    for k in ("conv_blocks.0.batch_norm1", "bottle_neck.batch_norm2", "attention_blocks.2.result.1"):
+        _assert_close(sd[k + ".running_mean"], torch.from_numpy(golden[f"g5_rm_{k}"]), 1e-3, k + " running_mean")
+        _assert_close(sd[k + ".running_var"], torch.from_numpy(golden[f"g5_rv_{k}"]), 1e-3, k + " running_var")
+        assert int(sd[k + ".num_batches_tracked"]) == 8
+    assert sd["conv_blocks.0.conv1.1.running_mean"].data_ptr() == sd["conv_blocks.0.batch_norm1.running_mean"].data_ptr()
+    # the eval plan must pick up the new running statistics (they were rewritten in place by the kernels)
+    m.eval()
+    with torch.no_grad():
+        got = m(x.to(dev), t.to(dev), lr.to(dev), 2)
+        want = U.unet_forward({k: v.cpu() for k, v in sd.items()}, x, t, lr, 2)
+    _assert_close(got, want, _tol(impl), "eval after train")
