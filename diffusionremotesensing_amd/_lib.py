@@ -48,6 +48,8 @@ SIGNATURES = {
     "drs_unet_tensor_name": (C.c_char_p, [_P, _I]),
     "drs_unet_tensor_shape": (_I, [_P, _I] + [C.POINTER(_I)] * 4),
     "drs_unet_read_tensor": (_I, [_P, _I, _P, _P, _P]),
+    "drs_unet_packed_bwd_bytes": (_Z, [_P]),
+    "drs_unet_backward": (_I, [_P, _P, _P, _Z, _P, _P, _P, C.POINTER(_P), _P, _Z, _P]),
     "drs_unet_profile_enable": (_I, [_P, _I]),
     "drs_unet_profile_num_ops": (_I, [_P]),
     "drs_unet_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -125,3 +125,32 @@ int drs_launch_bn_train(const float* z, int z_cs, int z_co, long long npix, long
                         float momentum, double* sums_scratch, float* mean, float* rstd, const float* post_add,
                         int post_cs, const float* res, int res_cs, int res_co, float* out, int out_cs, int out_co,
                         int relu_pre, int relu_post, hipStream_t s);
+
+// ---- training backward (train_kernels.hip) ------------------------------------------------------------------------
+struct WgradDesc {
+  const float* A; int a_cs, a_co, Ca, AH, AW, sa;
+  const float* B; int b_cs, b_co, Cb, BH, BW, sb;
+  int N, TH, TW, ntaps;
+  int ay[DRS_MAX_TAPS], ax[DRS_MAX_TAPS], by[DRS_MAX_TAPS], bx[DRS_MAX_TAPS];
+  const float* a_add; int a_add_cs;
+  const float* a_gate;
+  float* dW; int T_total; int wtap[DRS_MAX_TAPS]; int out_transposed;
+};
+int drs_launch_wgrad(const WgradDesc& d, hipStream_t s);
+int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, long long pix_per_image, int per_image,
+                      int out_stride, float* out, hipStream_t s);
+int drs_launch_relu_mask(float* g, int g_cs, int g_co, const float* y, int y_cs, int y_co, int C, long long npix,
+                         hipStream_t s);
+int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s_cs, int s_co, int C, long long npix,
+                         int accumulate, hipStream_t s);
+int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* sums_scratch,
+                      float* dgamma, float* dbeta, hipStream_t s);
+int drs_launch_gate_bwd(const float* x, const float* E, const float* psi, float* dx, float* dpsi_pre, int N, int LH,
+                        int LW, int C, hipStream_t s);
+int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre, float* dP, float* dw, float* db, int C,
+                       long long npix, hipStream_t s);
+int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
+                            const float* temb, const float* dtemb, int stride, int B, int dim, float* dW1, float* db1,
+                            float* dW2, float* db2, hipStream_t s);
+int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, hipStream_t s);

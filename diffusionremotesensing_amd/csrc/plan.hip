@@ -2,6 +2,7 @@
 // whole-UNet plan (weight packing + the launch schedule of one eval forward).
 #include <stdarg.h>
 #include <stdio.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -256,6 +257,10 @@ struct drs_plan {
   int t_cond, t_x0, t_S[4], t_K0, t_H[4], t_R[4], t_D[3];
   int t_G[3], t_Q[3], t_P[3], t_PSI[3], t_U[3], t_CAT[3], t_X[3];
   int t_lrenc, t_up;
+  // train plans: gradients of activations and channels-last copies of the 3-channel tensors (backward only)
+  int g_out = -1, g_X[3], g_CAT[3], g_U[3], g_G[3], g_P[3], g_PSI[3], g_E[3], g_R[4], g_D[3], g_H[4], g_x0 = -1;
+  int t_xn = -1, t_upn = -1, g_upn = -1, g_lr[4], t_rn[4], t_an[3];
+  size_t o_dtemb = 0, o_scratch = 0;
 
   int P(const std::string& name, int64_t numel) {
     params.push_back({name, numel});
@@ -467,6 +472,35 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
       addz(p->dec[i].conv, "ups." + si + ".conv_bn", lh, lw);
     }
   }
+  if (cfg->flags & DRS_PLAN_TRAIN) {
+    p->o_dtemb = ws; ws += align_up((size_t)B * p->temb_total * 4);
+    p->o_scratch = ws; ws += align_up(64 * 1024);
+    p->g_out = p->T("grad.out", ws, B, cfg->out_dim, H, W);
+    p->g_x0 = p->T("grad.x0", ws, B, kDown[0], H, W);
+    p->t_xn = p->T("x.nhwc", ws, B, C, H, W);
+    p->t_upn = p->T("upsampled_lr_img.nhwc", ws, B, C, H, W);
+    p->g_upn = p->T("grad.upsampled_lr_img", ws, B, C, H, W);
+    for (int i = 0; i < 4; ++i) p->g_lr[i] = p->T("grad.lr." + std::to_string(i), ws, B, C, h, w);
+    for (int i = 0; i < 4; ++i) p->t_rn[i] = p->T("LR_encoder.r" + std::to_string(i) + ".nhwc", ws, B, C, h, w);
+    for (int i = 0; i < 3; ++i) p->t_an[i] = p->T("LR_encoder.a" + std::to_string(i) + ".nhwc", ws, B, C, h, w);
+    for (int i = 0; i < 4; ++i) {
+      const int co = kDown[i + 1], hh = H >> i, ww = W >> i;
+      p->g_R[i] = p->T("grad.R" + std::to_string(i), ws, B, co, hh, ww);
+      p->g_H[i] = p->T("grad.H" + std::to_string(i), ws, B, co, hh, ww);
+      if (i < 3) p->g_D[i] = p->T("grad.D" + std::to_string(i), ws, B, co, hh / 2, ww / 2);
+    }
+    for (int i = 0; i < 3; ++i) {
+      const int Cc = kUp[i], Ch = kUp[i + 1];
+      const int lh = H >> (3 - i), lw = W >> (3 - i);
+      p->g_G[i] = p->T("grad.G" + std::to_string(i), ws, B, Ch, lh, lw);
+      p->g_P[i] = p->T("grad.P" + std::to_string(i), ws, B, Ch, lh, lw);
+      p->g_PSI[i] = p->T("grad.psi" + std::to_string(i), ws, B, 1, lh, lw);
+      p->g_U[i] = p->T("grad.U" + std::to_string(i), ws, B, Cc, lh, lw);
+      p->g_E[i] = p->T("grad.E" + std::to_string(i), ws, B, Ch, 2 * lh, 2 * lw);
+      p->g_CAT[i] = p->T("grad.cat" + std::to_string(i), ws, B, Cc + Ch, 2 * lh, 2 * lw);
+      p->g_X[i] = p->T("grad.X" + std::to_string(i), ws, B, Ch, 2 * lh, 2 * lw);
+    }
+  }
   p->ws_bytes = ws + 256;
   *out = p;
   return DRS_OK;
@@ -629,6 +663,7 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
     float* b = (float*)((char*)ws + plan->o_lr[1]);
     float* r = (float*)((char*)ws + plan->o_lr[2]);
     const float* cur = lr_img;
+    if (train) RUN(drs_launch_nchw_to_nhwc(lr_img, TP(plan->t_rn[0]), Bl, C, h, w, C, 0, s));
     for (int i = 0; i < 3; ++i) {
       const PlanarConv& c1 = plan->rrdb[2 * i];
       const PlanarConv& c2 = plan->rrdb[2 * i + 1];
@@ -638,6 +673,10 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
       RUN(drs_launch_conv3x3_planar(a, (const float*)(pk + c2.w_off), (const float*)(pk + c2.b_off), cur, dst, Bl, C,
                                     C, h, w, 0, s));
       cur = dst;
+      if (train) {  // the backward pass reads a_i (ReLU output) and r_{i+1} channels-last
+        RUN(drs_launch_nchw_to_nhwc(a, TP(plan->t_an[i]), Bl, C, h, w, C, 0, s));
+        RUN(drs_launch_nchw_to_nhwc(dst, TP(plan->t_rn[i + 1]), Bl, C, h, w, C, 0, s));
+      }
     }
     const PlanarConv& co = plan->rrdb[6];
     RUN(drs_launch_conv3x3_planar(cur, (const float*)(pk + co.w_off), (const float*)(pk + co.b_off), lr_img,
@@ -831,3 +870,5 @@ extern "C" int drs_unet_profile_read(drs_plan* plan, int i, char* name, int name
   *bytes = r.bytes;
   return DRS_OK;
 }
+
+#include "train_bwd.inc"

@@ -1,0 +1,438 @@
+// Backward-pass kernels of the UNet training step (reference loop body train_diffusion_superres.py:388-393:
+// loss.backward() through Residual_Attention_UNet_superres).  First correct versions: fp32, LDS-tiled, float atomics
+// for the cross-block sums.  Data gradients (dgrad) do not live here: they are tap-convolutions with re-packed
+// weights and run on the forward kernels (conv_mfma.hip / conv_direct.hip).
+#include "drs_common.h"
+
+static inline unsigned grid1d(long long total, int per_block, int cap) {
+  long long b = (total + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of a tap convolution ("correlation" of two channels-last tensors):
+//   dW[tap][a][b] = sum_{n, ty, tx} A[n][ty*sa + ay(tap)][tx*sa + ax(tap)][a] * B[n][ty*sb + by(tap)][tx*sb + bx(tap)][b]
+// with zero outside either tensor.  Regular conv: A = layer input (sa = stride, offsets = tap offsets), B = dY (sb = 1);
+// transposed conv: A = layer input at (ty, tx), B = dY at (2*ty - 1 + ky, 2*tx - 1 + kx).
+// Optional: a_add[n][a] added to in-image A pixels (UpConvBlock adds the time embedding before its conv),
+// a_gate[n][y/2][x/2] multiplied into A (the attention gate multiplies x before the `result` conv).
+// Output index = out_transposed ? (a*Cb + b)*T + tap : (b*Ca + a)*T + tap  (torch ConvTranspose2d / Conv2d layout).
+// grid = (position chunks, taps, (Ca/64)*(Cb/64) tiles); block 256 threads; thread = 4x4 block of (a, b).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradDesc d, int chunk) {
+  constexpr int TP = 16;  // positions per LDS tile
+  __shared__ float sA[TP][64 + 1];
+  __shared__ float sB[TP][64 + 1];
+  const int tap = blockIdx.y;
+  const int tiles_b = (d.Cb + 63) / 64;
+  const int a0 = (blockIdx.z / tiles_b) * 64, b0 = (blockIdx.z % tiles_b) * 64;
+  const int ta = (threadIdx.x >> 4) * 4, tb = (threadIdx.x & 15) * 4;  // this thread's 4x4 block inside the 64x64 tile
+  const long long P = (long long)d.N * d.TH * d.TW;
+  const long long p_begin = (long long)blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
+  float acc[4][4] = {};
+  for (long long p0 = p_begin; p0 < p_end; p0 += TP) {
+    // stage TP positions x 64 channels of A and of B (zero outside the image / channel range / chunk)
+    for (int i = threadIdx.x; i < TP * 64; i += 256) {
+      const int pp = i >> 6, c = i & 63;
+      const long long p = p0 + pp;
+      float va = 0.f, vb = 0.f;
+      if (p < p_end) {
+        const int tx = (int)(p % d.TW), ty = (int)((p / d.TW) % d.TH), n = (int)(p / ((long long)d.TW * d.TH));
+        const int ya = ty * d.sa + d.ay[tap], xa = tx * d.sa + d.ax[tap];
+        const int yb = ty * d.sb + d.by[tap], xb = tx * d.sb + d.bx[tap];
+        if (a0 + c < d.Ca && ya >= 0 && ya < d.AH && xa >= 0 && xa < d.AW) {
+          va = d.A[(((long long)n * d.AH + ya) * d.AW + xa) * d.a_cs + d.a_co + a0 + c];
+          if (d.a_add) va += d.a_add[(long long)n * d.a_add_cs + a0 + c];
+          if (d.a_gate) va *= d.a_gate[((long long)n * (d.AH >> 1) + (ya >> 1)) * (d.AW >> 1) + (xa >> 1)];
+        }
+        if (b0 + c < d.Cb && yb >= 0 && yb < d.BH && xb >= 0 && xb < d.BW)
+          vb = d.B[(((long long)n * d.BH + yb) * d.BW + xb) * d.b_cs + d.b_co + b0 + c];
+      }
+      sA[pp][c] = va;
+      sB[pp][c] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < TP; ++pp) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { av[j] = sA[pp][ta + j]; bv[j] = sB[pp][tb + j]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int a = a0 + ta + i, b = b0 + tb + j;
+      if (a < d.Ca && b < d.Cb) {
+        const long long idx = d.out_transposed ? ((long long)a * d.Cb + b) * d.T_total + d.wtap[tap]
+                                               : ((long long)b * d.Ca + a) * d.T_total + d.wtap[tap];
+        atomicAdd(&d.dW[idx], acc[i][j]);
+      }
+    }
+}
+
+int drs_launch_wgrad(const WgradDesc& d, hipStream_t s) {
+  const long long P = (long long)d.N * d.TH * d.TW;
+  if (P == 0) return DRS_OK;
+  const int tiles = ((d.Ca + 63) / 64) * ((d.Cb + 63) / 64);
+  // enough position chunks to fill the chip (~2048 blocks in all), at least 256 positions each
+  long long chunks = 2048 / ((long long)d.ntaps * tiles);
+  if (chunks < 1) chunks = 1;
+  long long chunk = (P + chunks - 1) / chunks;
+  if (chunk < 256) chunk = 256;
+  chunk = (chunk + 15) / 16 * 16;
+  chunks = (P + chunk - 1) / chunk;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)chunks, d.ntaps, tiles), dim3(256), 0, s, d, (int)chunk);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Column sums of a channels-last slice: out[c] += sum_p t[p][c]   (bias gradients), or per image:
+// out[n*out_stride + c] += sum over the image's pixels (time-embedding gradients).  fp32 partials + float atomics.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ t, int cs, int co, int C, long long npix,
+                                                     long long pix_per_image, int per_image, int out_stride,
+                                                     float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[256];
+  const int lanes_c = C < 256 ? C : 256;            // threads along channels
+  const int rows = 256 / lanes_c;                    // pixel rows handled concurrently
+  const int c = threadIdx.x % lanes_c, row = threadIdx.x / lanes_c;
+  const long long p_begin = (long long)blockIdx.x * rows_per_block;
+  const long long p_end = min(npix, p_begin + rows_per_block);
+  for (int cb = 0; cb < C; cb += lanes_c) {
+    float s = 0.f;
+    if (row < rows && cb + c < C)
+      for (long long p = p_begin + row; p < p_end; p += rows) s += t[p * cs + co + cb + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (row == 0 && cb + c < C) {
+      for (int r = 1; r < rows; ++r) s += red[r * lanes_c + c];
+      const long long n = per_image ? p_begin / pix_per_image : 0;
+      atomicAdd(&out[n * out_stride + cb + c], s);
+    }
+    __syncthreads();
+  }
+}
+int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, long long pix_per_image, int per_image,
+                      int out_stride, float* out, hipStream_t s) {
+  if (npix == 0) return DRS_OK;
+  long long rpb = 1024;
+  if (per_image) {  // blocks must not straddle images
+    while (pix_per_image % rpb) rpb >>= 1;
+  }
+  const long long blocks = (npix + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, cs, co, C, npix, pix_per_image, per_image,
+                     out_stride, out, (int)rpb);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Element-wise helpers on channels-last slices
+// ---------------------------------------------------------------------------------------------------------------
+// g[p][c] *= (y[p][c] > 0)
+__global__ void relu_mask_kernel(float* g, int g_cs, int g_co, const float* y, int y_cs, int y_co, int C, long long npix) {
+  const long long total = npix * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    if (!(y[p * y_cs + y_co + c] > 0.f)) g[p * g_cs + g_co + c] = 0.f;
+  }
+}
+int drs_launch_relu_mask(float* g, int g_cs, int g_co, const float* y, int y_cs, int y_co, int C, long long npix,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, y, y_cs, y_co, C,
+                     npix);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+// dst[p][c] = (accumulate ? dst : 0) + src[p][c]
+__global__ void add_slice_kernel(float* dst, int d_cs, int d_co, const float* src, int s_cs, int s_co, int C,
+                                 long long npix, int accumulate) {
+  const long long total = npix * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const float v = src[p * s_cs + s_co + c];
+    float* q = dst + p * d_cs + d_co + c;
+    *q = accumulate ? *q + v : v;
+  }
+}
+int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s_cs, int s_co, int C, long long npix,
+                         int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(add_slice_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, dst, d_cs, d_co, src, s_cs, s_co,
+                     C, npix, accumulate);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm backward (training statistics).  g = gradient w.r.t. the BatchNorm output (after the optional ReLU mask
+// that sat directly on it: relu_pre), zhat = (z - mean) * rstd:
+//   dbeta = sum g, dgamma = sum g*zhat, dz = gamma*rstd*(g - dbeta/M - zhat*dgamma/M).
+// Pass 1 reduces (fp64 atomics), pass 2 writes dz IN PLACE over z.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, int g_cs, int g_co,
+                                                            const float* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu_pre, int C,
+                                                            long long npix, double* __restrict__ sums) {
+  __shared__ float red[2][256];
+  const int lanes_c = C < 256 ? C : 256;
+  const int rows = 256 / lanes_c;
+  const int c = threadIdx.x % lanes_c, row = threadIdx.x / lanes_c;
+  float s1 = 0.f, s2 = 0.f;
+  if (row < rows) {
+    const float m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
+    for (long long p = (long long)blockIdx.x * rows + row; p < npix; p += (long long)gridDim.x * rows) {
+      const float zh = (z[p * C + c] - m) * r;
+      float gv = g[p * g_cs + g_co + c];
+      if (relu_pre && !(zh * ga + be > 0.f)) gv = 0.f;
+      s1 += gv;
+      s2 += gv * zh;
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (row == 0) {
+    double d1 = 0, d2 = 0;
+    for (int r = 0; r < rows; ++r) { d1 += (double)red[0][r * lanes_c + c]; d2 += (double)red[1][r * lanes_c + c]; }
+    atomicAdd(&sums[c], d1);
+    atomicAdd(&sums[C + c], d2);
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, int g_cs, int g_co,
+                                                           float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int relu_pre, int C,
+                                                           long long npix, const double* __restrict__ sums,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const long long total = npix * C;
+  const double inv = 1.0 / (double)npix;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const float m = mean[c], r = rstd[c], ga = gamma[c];
+    const float zh = (z[i] - m) * r;
+    float gv = g[p * g_cs + g_co + c];
+    if (relu_pre && !(zh * ga + beta[c] > 0.f)) gv = 0.f;
+    z[i] = ga * r * (gv - (float)(sums[c] * inv) - zh * (float)(sums[C + c] * inv));
+  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dbeta[c] = (float)sums[c];
+      dgamma[c] = (float)sums[C + c];
+    }
+}
+int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* sums_scratch,
+                      float* dgamma, float* dbeta, hipStream_t s) {
+  DRS_REQUIRE(C <= 1024 && (C >= 256 ? C % 256 == 0 : 256 % C == 0), DRS_ERR_SHAPE, "bn_bwd: C=%d", C);
+  DRS_CHECK_HIP(hipMemsetAsync(sums_scratch, 0, 2 * (size_t)C * sizeof(double), s));
+  if (C <= 256) {
+    const int rows = 256 / C;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid1d(npix, rows, 2048)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
+                       gamma, beta, relu_pre, C, npix, sums_scratch);
+  } else {
+    DrsErr::set("bn_bwd: C > 256 not needed by this network");
+    return DRS_ERR_SHAPE;
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
+                     gamma, beta, relu_pre, C, npix, sums_scratch, dgamma, dbeta);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention gate backward (reference AttentionBlock :104-107).  Forward: Zr = up2(psi) * (Wr x) + br.
+// With E = Wr^T dZr (a 1x1 dgrad, computed by the caller):
+//   dpsi_pre[n][y][x] = psi (1 - psi) * sum_{2x2} sum_c x[n][2y+a][2x+b][c] * E[...][c]
+//   dx[n][Y][X][c] += psi[n][Y/2][X/2] * E[n][Y][X][c]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ E,
+                                                       const float* __restrict__ psi, float* __restrict__ dx,
+                                                       float* __restrict__ dpsi_pre, int N, int LH, int LW, int C) {
+  // one wave per low-resolution position: lanes stride the 4*C products
+  const int lane = threadIdx.x & 63;
+  const long long pos = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long total = (long long)N * LH * LW;
+  if (pos >= total) return;
+  const int lx = (int)(pos % LW), ly = (int)((pos / LW) % LH), n = (int)(pos / ((long long)LW * LH));
+  const float ps = psi[pos];
+  float s = 0.f;
+  for (int i = lane; i < 4 * C; i += 64) {
+    const int sub = i / C, c = i - sub * C;
+    const long long hp = (((long long)n * 2 * LH + 2 * ly + (sub >> 1)) * 2 * LW + 2 * lx + (sub & 1)) * C + c;
+    const float e = E[hp];
+    s += x[hp] * e;
+    dx[hp] += ps * e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) dpsi_pre[pos] = s * ps * (1.f - ps);
+}
+int drs_launch_gate_bwd(const float* x, const float* E, const float* psi, float* dx, float* dpsi_pre, int N, int LH,
+                        int LW, int C, hipStream_t s) {
+  const long long total = (long long)N * LH * LW;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, x, E, psi, dx, dpsi_pre, N, LH, LW,
+                     C);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// psi conv backward (1x1 conv to one channel, reference :78,:104):  psi_pre = sum_c wpsi[c] P[p][c] + b.
+//   dP[p][c] = wpsi[c] * dpsi_pre[p] * (P[p][c] > 0)   (P is a ReLU output: its mask is applied here)
+//   dw[c] += sum_p P[p][c] * dpsi_pre[p],  db += sum_p dpsi_pre[p]
+__global__ __launch_bounds__(256) void psi_bwd_kernel(const float* __restrict__ Pm, const float* __restrict__ wpsi,
+                                                      const float* __restrict__ dpsi_pre, float* __restrict__ dP,
+                                                      float* __restrict__ dw, float* __restrict__ db, int C,
+                                                      long long npix, int rows_per_block) {
+  __shared__ float red[256];
+  const int lanes_c = C < 256 ? C : 256, rows = 256 / lanes_c;
+  const int c = threadIdx.x % lanes_c, row = threadIdx.x / lanes_c;
+  const long long p_begin = (long long)blockIdx.x * rows_per_block, p_end = min(npix, p_begin + rows_per_block);
+  float sw = 0.f, sb = 0.f;
+  if (row < rows) {
+    const float w = wpsi[c];
+    for (long long p = p_begin + row; p < p_end; p += rows) {
+      const float dp = dpsi_pre[p], pv = Pm[p * C + c];
+      dP[p * C + c] = pv > 0.f ? w * dp : 0.f;
+      sw += pv * dp;
+      if (c == 0) sb += dp;
+    }
+  }
+  red[threadIdx.x] = sw;
+  __syncthreads();
+  if (row == 0) {
+    for (int r = 1; r < rows; ++r) sw += red[r * lanes_c + c];
+    atomicAdd(&dw[c], sw);
+  }
+  __syncthreads();
+  red[threadIdx.x] = (c == 0) ? sb : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += red[r * lanes_c];
+    atomicAdd(db, t);
+  }
+}
+int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre, float* dP, float* dw, float* db, int C,
+                       long long npix, hipStream_t s) {
+  DRS_REQUIRE(C <= 256 && 256 % C == 0, DRS_ERR_SHAPE, "psi_bwd: C=%d", C);
+  const int rpb = 1024;
+  hipLaunchKernelGGL(psi_bwd_kernel, dim3((unsigned)((npix + rpb - 1) / rpb)), dim3(256), 0, s, Pm, wpsi, dpsi_pre, dP, dw,
+                     db, C, npix, rpb);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Time-embedding MLP backward (reference :143-151,:161): out = relu(W2 silu(W1 e + b1) + b2), e = posenc(t) (constant).
+// One block per MLP; loops over the batch.  dtemb = gradient w.r.t. out (already summed over pixels by the caller).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __restrict__ t,
+                                                           const float* __restrict__ inv_freq,
+                                                           const float* __restrict__ W1, const float* __restrict__ b1,
+                                                           const float* __restrict__ W2, const float* __restrict__ temb,
+                                                           const float* __restrict__ dtemb, int stride, int B, int dim,
+                                                           float* __restrict__ dW1, float* __restrict__ db1,
+                                                           float* __restrict__ dW2, float* __restrict__ db2) {
+  __shared__ float e[100], pre1[256], h1[256], d2[256], dpre1[256];
+  for (int b = 0; b < B; ++b) {
+    const float tf = (float)t[b];
+    for (int j = threadIdx.x; j < 50; j += blockDim.x) {
+      const float arg = tf * inv_freq[j];
+      e[j] = sinf(arg);
+      e[50 + j] = cosf(arg);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+      float a = b1[c];
+      for (int k = 0; k < 100; ++k) a = fmaf(W1[(size_t)c * 100 + k], e[k], a);
+      pre1[c] = a;
+      h1[c] = a / (1.f + expf(-a));
+      d2[c] = temb[(size_t)b * stride + c] > 0.f ? dtemb[(size_t)b * stride + c] : 0.f;  // ReLU mask
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+      db2[c] += d2[c];  // one block owns this MLP: plain read-modify-write
+      for (int k = 0; k < dim; ++k) dW2[(size_t)c * dim + k] += d2[c] * h1[k];
+    }
+    for (int k = threadIdx.x; k < dim; k += blockDim.x) {
+      float dh = 0.f;
+      for (int c = 0; c < dim; ++c) dh = fmaf(W2[(size_t)c * dim + k], d2[c], dh);
+      const float sg = 1.f / (1.f + expf(-pre1[k]));
+      dpre1[k] = dh * (sg * (1.f + pre1[k] * (1.f - sg)));  // d silu
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < dim; k += blockDim.x) {
+      db1[k] += dpre1[k];
+      for (int j = 0; j < 100; ++j) dW1[(size_t)k * 100 + j] += dpre1[k] * e[j];
+    }
+    __syncthreads();
+  }
+}
+int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
+                            const float* temb, const float* dtemb, int stride, int B, int dim, float* dW1, float* db1,
+                            float* dW2, float* db2, hipStream_t s) {
+  DRS_REQUIRE(dim <= 256, DRS_ERR_SHAPE, "time_mlp_bwd: dim=%d", dim);
+  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, t, inv_freq, W1, b1, W2, temb, dtemb, stride, B, dim, dW1,
+                     db1, dW2, db2);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adjoint of the bicubic up-sampling (channels-last, C channels): every output-gradient pixel scatters into its 16
+// source pixels with the same clamped indices / weights as the forward (small tensors: float atomics).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_w(float t, float c[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+  c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  c[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+__global__ void bicubic_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int C, int H, int W,
+                                   int scale) {
+  const int OH = H * scale, OW = W * scale;
+  const long long total = (long long)N * OH * OW * C;
+  const float rs = 1.f / (float)scale;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int ox = (int)((i / C) % OW), oy = (int)((i / ((long long)C * OW)) % OH);
+    const int n = (int)(i / ((long long)C * OW * OH));
+    const float sy = rs * ((float)oy + 0.5f) - 0.5f, sx = rs * ((float)ox + 0.5f) - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sx);
+    float cy[4], cx[4];
+    cubic_w(sy - fy, cy);
+    cubic_w(sx - fx, cx);
+    const float g = dy[i];
+    for (int a = 0; a < 4; ++a) {
+      const int yy = min(max((int)fy - 1 + a, 0), H - 1);
+      for (int b = 0; b < 4; ++b) {
+        const int xx = min(max((int)fx - 1 + b, 0), W - 1);
+        atomicAdd(&dx[(((long long)n * H + yy) * W + xx) * C + c], g * cy[a] * cx[b]);
+      }
+    }
+  }
+}
+int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, hipStream_t s) {
+  const long long total = (long long)N * H * W * scale * scale * C;
+  hipLaunchKernelGGL(bicubic_bwd_kernel, dim3(grid1d(total, 256, 8192)), dim3(256), 0, s, dy, dx, N, C, H, W, scale);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}

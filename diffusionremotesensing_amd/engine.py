@@ -49,14 +49,18 @@ class _Plan:
 
 class HipUNetEngine:
     """Runs reference `Residual_Attention_UNet_superres.forward` (UNet_model_superres.py:337-379)
-    on the HIP plan.  Eval mode folds BatchNorm; train mode (under no_grad) uses batch statistics and updates the
-    running statistics like nn.BatchNorm2d; autograd through the forward is not built yet."""
+    on the HIP plan.  Eval mode folds BatchNorm; train mode uses batch statistics and updates the running statistics
+    like nn.BatchNorm2d, and with autograd enabled the call is recorded so that loss.backward() runs
+    drs_unet_backward (weight / bias / BatchNorm-affine gradients of every live parameter)."""
 
     def __init__(self, module, variant="superres", impl=None):
         if variant != "superres":
             raise NotImplementedError(f"UNet variant {variant!r} is not built yet")
         self._module = weakref.ref(module)
         self.impl = _lib.IMPL_BY_NAME[impl or DEFAULT_IMPL]
+        # training steps run the exact-fp32 MFMA kernels by default: gradients pass through ~25 BatchNorm backward
+        # cancellations and the split-bf16 rounding (1e-5 per op) grows to ~4e-3 on the deepest (LR encoder) gradients
+        self.train_impl = _lib.IMPL_BY_NAME[os.environ.get("DRS_TRAIN_IMPL", "mfma_f32")]
         self._plans = {}
         self._bn_epoch = 0  # bumped by every train-mode forward (running statistics change under the eval plans)
         self.keep_intermediates = False  # True: every block output stays readable (read_tensor), used by parity tests
@@ -65,11 +69,12 @@ class HipUNetEngine:
 
     # -- plan / weights -------------------------------------------------------------------
     def _get_plan(self, B, Bl, H, W, mag, device, train=False):
-        key = (B, Bl, H, W, mag, device.index, self.impl, self.keep_intermediates, train)
+        impl = self.train_impl if train else self.impl
+        key = (B, Bl, H, W, mag, device.index, impl, self.keep_intermediates, train)
         plan = self._plans.get(key)
         if plan is None:
             m = self._module()
-            cfg = _lib.UNetConfig(B, Bl, m.image_channels, m.out_dim, H, W, mag, self.impl, 1e-5,
+            cfg = _lib.UNetConfig(B, Bl, m.image_channels, m.out_dim, H, W, mag, impl, 1e-5,
                                   (_lib.PLAN_KEEP_ALL if self.keep_intermediates else 0) |
                                   (_lib.PLAN_TRAIN if train else 0))
             plan = _Plan(_lib.load(), cfg, device)
@@ -77,8 +82,10 @@ class HipUNetEngine:
             self._plans[key] = plan
         return plan
 
-    def set_impl(self, impl):
+    def set_impl(self, impl, train_impl=None):
         self.impl = _lib.IMPL_BY_NAME[impl]
+        if train_impl is not None:
+            self.train_impl = _lib.IMPL_BY_NAME[train_impl]
 
     def _sync_weights(self, plan):
         """Re-pack (BatchNorm fold + re-layout) when any parameter or buffer changed."""
@@ -105,13 +112,16 @@ class HipUNetEngine:
         plan.cond_key = None
 
     # -- forward ----------------------------------------------------------------------------
-    def forward(self, x, timestep, lr_img, magnification_factor, reuse_cond=False, check_weights=True):
+    def forward(self, x, timestep, lr_img, magnification_factor, reuse_cond=False, check_weights=True,
+                _in_autograd_fn=False):
         m = self._module()
         train = bool(m.training)
-        if train and torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()):
-            raise NotImplementedError(
-                "train-mode forward with autograd (backward kernels) is not part of this build; train-mode forwards "
-                "run under torch.no_grad() (batch-statistics BatchNorm, running-stat update), eval-mode everywhere")
+        if train and torch.is_grad_enabled() and not _in_autograd_fn and any(p.requires_grad for p in m.parameters()):
+            # training step: route through autograd so loss.backward() reaches drs_unet_backward
+            sd = m.state_dict(keep_vars=True)
+            plan = self._get_plan(x.shape[0], lr_img.shape[0], x.shape[2], x.shape[3], int(magnification_factor), x.device, True)
+            params = [sd[n] for n in plan.param_names if sd[n].requires_grad]
+            return _UNetTrainFn.apply(self, x, timestep, lr_img, magnification_factor, *params)
         for name, t in (("x", x), ("timestep", timestep), ("lr_img", lr_img)):
             if not isinstance(t, torch.Tensor) or not t.is_cuda:
                 raise RuntimeError(f"{name} must be a tensor on a ROCm device: the UNet forward has no CPU fallback")
@@ -155,6 +165,35 @@ class HipUNetEngine:
                     torch._foreach_add_(nbt, 1)
         self._last_plan = plan
         return out
+
+    # -- backward (training step) ---------------------------------------------------------------
+    def backward(self, plan, x, timestep, dout):
+        """d(loss)/d(parameters) for the last train-mode forward on `plan`; returns {state_dict key: gradient}."""
+        m = self._module()
+        sd = m.state_dict(keep_vars=True)
+        lib = plan.lib
+        wanted = [(i, n) for i, n in enumerate(plan.param_names) if sd[n].requires_grad]
+        total = sum(plan.param_numels[i] for i, _ in wanted)
+        flat = torch.empty(total, dtype=torch.float32, device=plan.device)  # fresh per step: .grad may alias it
+        ptrs = (C.c_void_p * len(plan.param_names))()
+        views, off = {}, 0
+        for i, n in wanted:
+            k = plan.param_numels[i]
+            views[n] = flat[off:off + k].view_as(sd[n])
+            ptrs[i] = flat.data_ptr() + 4 * off
+            off += k
+        if getattr(plan, "packed_bwd", None) is None:
+            plan.packed_bwd_bytes = lib.drs_unet_packed_bwd_bytes(plan.handle)
+            plan.packed_bwd = torch.empty(plan.packed_bwd_bytes, dtype=torch.uint8, device=plan.device)
+        dout = dout.contiguous()
+        with torch.cuda.device(plan.device):
+            stream = C.c_void_p(torch.cuda.current_stream(plan.device).cuda_stream)
+            st = lib.drs_unet_backward(plan.handle, C.c_void_p(plan.packed.data_ptr()), C.c_void_p(plan.packed_bwd.data_ptr()),
+                                       plan.packed_bwd_bytes, C.c_void_p(x.data_ptr()), C.c_void_p(timestep.data_ptr()),
+                                       C.c_void_p(dout.data_ptr()), ptrs, C.c_void_p(plan.workspace.data_ptr()),
+                                       plan.ws_bytes, stream)
+        _lib.check(st, "drs_unet_backward")
+        return views
 
     # -- per-op timing (bench.py roofline) ------------------------------------------------------
     def profile_forward(self, x, timestep, lr_img, magnification_factor, iters=5, **kw):
@@ -201,3 +240,24 @@ class HipUNetEngine:
             _lib.check(plan.lib.drs_unet_read_tensor(plan.handle, i, C.c_void_p(plan.workspace.data_ptr()),
                                                      C.c_void_p(dst.data_ptr()), stream), "drs_unet_read_tensor")
         return dst
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """Autograd node of one train-mode UNet forward: forward = drs_unet_forward on the train plan, backward =
+    drs_unet_backward.  No gradient flows to x_t / lr_img (they are data in the reference's training loop)."""
+
+    @staticmethod
+    def forward(ctx, engine, x, timestep, lr_img, mag, *params):
+        x = x.contiguous()
+        timestep = timestep.to(torch.int64).contiguous()
+        out = engine.forward(x, timestep, lr_img, mag, _in_autograd_fn=True)
+        ctx.engine, ctx.plan = engine, engine._last_plan
+        ctx.names = [n for n in ctx.plan.param_names if engine._module().state_dict(keep_vars=True)[n].requires_grad]
+        ctx.save_for_backward(x, timestep)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, timestep = ctx.saved_tensors
+        grads = ctx.engine.backward(ctx.plan, x, timestep, dout)
+        return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)

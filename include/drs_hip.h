@@ -154,6 +154,19 @@ const char* drs_unet_tensor_name(const drs_plan* plan, int i);
 int drs_unet_tensor_shape(const drs_plan* plan, int i, int* n, int* c, int* h, int* w);
 int drs_unet_read_tensor(const drs_plan* plan, int i, const void* workspace, float* dst_nchw, drs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step, backward half (reference loop body train_diffusion_superres.py:388-393: loss.backward()).
+ * Given d(loss)/d(eps_pred) (`dout`, NCHW like the output) it produces d(loss)/d(parameter) for every parameter of
+ * drs_unet_param_name(): grads[i] = device pointer of drs_unet_param_numel(i) floats, or NULL to skip (BatchNorm
+ * running statistics, which receive no gradient, must be NULL).  Gradients are OVERWRITTEN (zeroed first).
+ * Requires a DRS_PLAN_TRAIN plan with lr_batch == batch and the workspace exactly as the last drs_unet_forward
+ * (train mode) on this plan left it; `packed_bwd` is scratch for the re-packed (transposed) weights.
+ * ------------------------------------------------------------------------------------------ */
+size_t drs_unet_packed_bwd_bytes(const drs_plan* plan);
+int drs_unet_backward(drs_plan* plan, const void* packed, void* packed_bwd, size_t packed_bwd_bytes, const float* x,
+                      const int64_t* t, const float* dout, float* const* grads, void* workspace, size_t workspace_bytes,
+                      drs_stream_t stream);
+
 /* Per-op timing of the forward schedule: with profiling on, drs_unet_forward brackets every op with HIP events on
  * the stream it launches on; afterwards read (name, milliseconds, algorithmic FLOPs, algorithmic bytes) per op.
  * Used by bench.py for the roofline of the dominant kernel.  Not for use inside graph capture. */

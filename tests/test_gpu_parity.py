@@ -265,12 +265,16 @@ def test_forward_error_behaviour(dev, model):
         model(x.double().to(dev), t.to(dev), lr.to(dev), 2)
     with pytest.raises(RuntimeError, match="divisible by 8"):
         model(x[:, :, :12, :12].to(dev), t.to(dev), lr[:, :, :6, :6].to(dev), 2)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     model.train()
-    try:
-        with pytest.raises(NotImplementedError, match="train-mode"):
-            model(x.to(dev), t.to(dev), lr.to(dev), 2)
+    try:  # a training step needs one LR image per sample (DataLoader batches); the broadcast form is sampling-only
+        out = model(x.to(dev), t.to(dev), lr[:1].to(dev), 2)
+        with pytest.raises(RuntimeError, match="lr_img batch must equal"):
+            out.sum().backward()
     finally:
         model.eval()
+        model.load_state_dict(sd0)  # the train-mode forward moved the shared fixture's running statistics
+        model.zero_grad()
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -305,7 +309,7 @@ def test_train_mode_forward_golden(dev, seeded_sd, golden, impl):
     m = Residual_Attention_UNet_superres(3, 3, dev)
     m.load_state_dict(seeded_sd)
     m = m.to(dev).train()
-    m.hip_engine().set_impl(impl)
+    m.hip_engine().set_impl(impl, train_impl=impl)
     x, t, lr = golden_inputs("g5", 4, 4, 3, 32, 2, 1500)
     with torch.no_grad():
         out = m(x.to(dev), t.to(dev), lr.to(dev), 2)
@@ -325,3 +329,55 @@ def test_train_mode_forward_golden(dev, seeded_sd, golden, impl):
         got = m(x.to(dev), t.to(dev), lr.to(dev), 2)
         want = U.unet_forward({k: v.cpu() for k, v in sd.items()}, x, t, lr, 2)
     _assert_close(got, want, _tol(impl), "eval after train")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_train_step_gradients_golden(dev, seeded_sd, golden, impl):
+    """Loop body of reference train_diffusion_superres.py:384-393 (forward in train mode, MSE, backward, Adam) against
+    the reference's own autograd (G5): every parameter's gradient norm, two full gradients, the post-step deltas."""
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    m = Residual_Attention_UNet_superres(3, 3, dev)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).train()
+    m.hip_engine().set_impl(impl, train_impl=impl)
+    x, t, lr = golden_inputs("g5", 4, 4, 3, 32, 2, 1500)
+    noise = synthetic.tensor_normal("g5.noise", (4, 3, 32, 32)).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt.zero_grad()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    pred = m(x.to(dev), t.to(dev), lr.to(dev), 2)
+    loss = torch.nn.MSELoss()(pred, noise)
+    loss.backward()
+    assert abs(loss.item() - float(golden["g5_loss"])) <= 2e-3 * float(golden["g5_loss"])
+    here = os.path.dirname(os.path.abspath(__file__))
+    names = open(os.path.join(here, "golden", "g5_param_names.txt")).read().split()
+    ref_norms = golden["g5_grad_norms"]
+    scale = float(ref_norms.max())
+    # split-bf16 (1e-5 per op) is amplified by the BatchNorm-backward cancellations along the ~25-layer chain: the
+    # deepest gradients (LR encoder) are off by ~4e-3; the exact-fp32 kernels (the training default) stay below 2e-4
+    rtol = 2e-4 if impl in ("direct", "mfma_f32") else 1e-2
+    bad = []
+    params = dict(m.named_parameters())
+    for name, ref in zip(names, ref_norms):
+        g = params[name].grad
+        if ref < 0:
+            assert g is None, f"{name} is structurally unused (quirk Q3) and must get no gradient"
+            continue
+        assert g is not None, name
+        got = g.norm().item()
+        if abs(got - ref) > rtol * ref + 2e-6 * scale:
+            bad.append((name, got, float(ref)))
+    assert not bad, bad[:12]
+    _assert_close(params["output.bias"].grad, torch.from_numpy(golden["g5_grad_output_bias"]), rtol, "grad output.bias")
+    _assert_close(params["conv0.weight"].grad, torch.from_numpy(golden["g5_grad_conv0_weight"]), 5 * rtol, "grad conv0.weight")
+    opt.step()
+    ref_delta = golden["g5_delta_norms"]
+    badd = []
+    for name, ref, gref in zip(names, ref_delta, ref_norms):
+        if gref < 1e-5 * scale:
+            continue  # conv biases in front of a BatchNorm: the true gradient is 0, Adam amplifies rounding noise to +-lr
+        got = (params[name].detach() - before[name]).norm().item()
+        if abs(got - ref) > 0.02 * ref + 1e-9:  # Adam's first step is sign-like: only tiny gradients can flip
+            badd.append((name, got, float(ref)))
+    assert len(badd) <= 4, badd[:12]

@@ -1,0 +1,22 @@
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tests')
+from conftest import golden_inputs
+from diffusionremotesensing_amd import synthetic
+from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+golden = dict(np.load('tests/golden/superres_golden.npz'))
+dev = torch.device('cuda:0')
+tmpl = Residual_Attention_UNet_superres(3,3,'cpu')
+sd = synthetic.seeded_state_dict(tmpl.state_dict(), 0)
+names = open('tests/golden/g5_param_names.txt').read().split()
+for impl in ('mfma_f32', 'mfma_bf16x3'):
+    m = Residual_Attention_UNet_superres(3,3,dev); m.load_state_dict(sd); m = m.to(dev).train(); m.hip_engine().set_impl(impl)
+    x,t,lr = golden_inputs("g5",4,4,3,32,2,1500)
+    noise = synthetic.tensor_normal("g5.noise",(4,3,32,32)).to(dev)
+    pred = m(x.to(dev), t.to(dev), lr.to(dev), 2); loss = torch.nn.MSELoss()(pred, noise); loss.backward()
+    P = dict(m.named_parameters()); rows=[]
+    for n, ref in zip(names, golden['g5_grad_norms']):
+        if ref < 0: continue
+        got = P[n].grad.norm().item(); rows.append((abs(got-ref)/max(ref,1e-12), n, got, float(ref)))
+    rows.sort(reverse=True)
+    print(impl, 'loss', loss.item(), float(golden['g5_loss']))
+    for r in rows[:14]: print('  %.2e %-45s %.5e %.5e' % r)
