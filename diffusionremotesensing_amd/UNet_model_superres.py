@@ -82,6 +82,10 @@ class ResConvBlock(_ParamHolder):
     """Parameters of the residual double-conv block (reference :110-172).  Registration
     order matters: it fixes `parameters()` order and the aliased state_dict keys."""
 
+    # attribute (= state_dict key) of the x_skip convolution: `conv_upsampled_lr_img` here, `conv_SAR_img` in
+    # UNet_model_SAR_TO_NDVI.py:126, `conv_skip` in generate_new_imgs/UNet_model_generation.py:122
+    SKIP_NAME = "conv_upsampled_lr_img"
+
     def __init__(self, in_ch, out_ch, time_emb_dim, device):
         super().__init__()
         self.time_mlp = _time_mlp(time_emb_dim, out_ch, device)
@@ -92,7 +96,7 @@ class ResConvBlock(_ParamHolder):
         self.conv1 = nn.Sequential(_conv(in_ch, out_ch, 3, device, padding="same"), self.batch_norm1, self.relu)
         # dead weight in every block but the first; created on the
         # default device exactly like the reference does (:129)
-        self.conv_upsampled_lr_img = nn.Conv2d(in_ch, out_ch, 3, padding=1)
+        setattr(self, self.SKIP_NAME, nn.Conv2d(in_ch, out_ch, 3, padding=1))
         self.conv2 = nn.Sequential(_conv(out_ch, out_ch, 3, device, padding="same"), self.batch_norm2)
         self.shortcut_conv = nn.Sequential(_conv(in_ch, out_ch, 1, device, padding="same"), self.shortcut_batch_norm)
 
@@ -140,35 +144,29 @@ class RRDB(_ParamHolder):
         self.conv_out = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
 
 
-class Residual_Attention_UNet_superres(nn.Module):
-    """Same constructor, attributes, state_dict and `forward(x, timestep, lr_img,
-    magnification_factor)` contract as reference UNet_model_superres.py:266-379."""
+class _HipUNet(nn.Module):
+    """What the three UNet mirrors share: the trunk's parameter holders (identical in the three reference files),
+    the host-side pos_encoding helper, the lazily created HIP engine and a deepcopy that never copies it."""
 
-    def __init__(self, image_channels=3, out_dim=3, device=None):
-        super().__init__()
-        self.image_channels = image_channels
+    VARIANT = None
+    RES_BLOCK = ResConvBlock
+
+    def _build_trunk(self, out_channels, device):
+        """Registers conv_blocks .. output in the reference's order (UNet_model_superres.py:287-322)."""
         self.down_channels = (16, 32, 64, 128, 256)
         self.up_channels = (256, 128, 64, 32, 16)
-        self.out_dim = out_dim
-        self.time_emb_dim = 100
-        self.device = device
-        dc, uc, te = self.down_channels, self.up_channels, self.time_emb_dim
-
-        self.conv0 = nn.Conv2d(image_channels, dc[0], 3, padding=1)
-        self.LR_encoder = RRDB(in_channels=image_channels, out_channels=image_channels, num_blocks=3)
-        self.conv_upsampled_lr_img = nn.Conv2d(image_channels, dc[0], 3, padding=1)
-        self.conv_blocks = nn.ModuleList(ResConvBlock(dc[i], dc[i + 1], te, device) for i in range(len(dc) - 2))
+        dc, uc, te, Res = self.down_channels, self.up_channels, self.time_emb_dim, self.RES_BLOCK
+        self.conv_blocks = nn.ModuleList(Res(dc[i], dc[i + 1], te, device) for i in range(len(dc) - 2))
         self.downs = nn.ModuleList(_conv(dc[i + 1], dc[i + 1], 3, device, stride=2, padding=1)
                                    for i in range(len(dc) - 2))
-        self.bottle_neck = ResConvBlock(dc[-2], dc[-1], te, device)
+        self.bottle_neck = Res(dc[-2], dc[-1], te, device)
         self.gating_signals = nn.ModuleList(gating_signal(uc[i], uc[i + 1], device) for i in range(len(uc) - 2))
         self.attention_blocks = nn.ModuleList(AttentionBlock(uc[i + 1], uc[i + 1], uc[i + 1], device)
                                               for i in range(len(uc) - 2))
         self.ups = nn.ModuleList(UpConvBlock(uc[i], uc[i], te, device) for i in range(len(uc) - 2))
         self.up_convs = nn.ModuleList(_conv(int(uc[i] * 3 / 2), uc[i + 1], 3, padding=1).to(device)
                                       for i in range(len(uc) - 2))
-        self.output = nn.Conv2d(uc[-2], out_dim, 1)
-        self._hip_engine = None
+        self.output = nn.Conv2d(uc[-2], out_channels, 1)
 
     def pos_encoding(self, t, channels, device):
         """Sinusoidal embedding as a host-visible helper (reference :328-335); the forward
@@ -179,9 +177,9 @@ class Residual_Attention_UNet_superres(nn.Module):
 
     # -- HIP dispatch ---------------------------------------------------------------------
     def hip_engine(self):
-        if self._hip_engine is None:
-            self._hip_engine = _engine.HipUNetEngine(self, variant="superres")
-        return self._hip_engine
+        if self.__dict__.get("_hip_engine") is None:
+            self.__dict__["_hip_engine"] = _engine.HipUNetEngine(self, variant=self.VARIANT)
+        return self.__dict__["_hip_engine"]
 
     def __deepcopy__(self, memo):
         # engines hold device workspaces and raw pointers: never copied (EMA deep-copies the model)
@@ -192,6 +190,25 @@ class Residual_Attention_UNet_superres(nn.Module):
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k == "_hip_engine" else copy.deepcopy(v, memo)
         return new
+
+
+class Residual_Attention_UNet_superres(_HipUNet):
+    """Same constructor, attributes, state_dict and `forward(x, timestep, lr_img,
+    magnification_factor)` contract as reference UNet_model_superres.py:266-379."""
+
+    VARIANT = "superres"
+
+    def __init__(self, image_channels=3, out_dim=3, device=None):
+        super().__init__()
+        self.image_channels = image_channels
+        self.out_dim = out_dim
+        self.time_emb_dim = 100
+        self.device = device
+        self.conv0 = nn.Conv2d(image_channels, 16, 3, padding=1)
+        self.LR_encoder = RRDB(in_channels=image_channels, out_channels=image_channels, num_blocks=3)
+        self.conv_upsampled_lr_img = nn.Conv2d(image_channels, 16, 3, padding=1)
+        self._build_trunk(out_dim, device)
+        self._hip_engine = None
 
     def forward(self, x, timestep, lr_img, magnification_factor):
         return self.hip_engine().forward(x, timestep, lr_img, magnification_factor)

@@ -16,12 +16,14 @@ IMPL_BY_NAME = {"direct": IMPL_DIRECT, "mfma_f32": IMPL_MFMA_F32, "mfma_bf16x3":
 FWD_REUSE_COND = 1
 PLAN_KEEP_ALL = 1
 PLAN_TRAIN = 2
+VARIANT_SUPERRES, VARIANT_SAR_TO_NDVI, VARIANT_GENERATION = 0, 1, 2
 
 
 class UNetConfig(C.Structure):
     _fields_ = [("batch", C.c_int), ("lr_batch", C.c_int), ("image_channels", C.c_int), ("out_dim", C.c_int),
                 ("height", C.c_int), ("width", C.c_int), ("magnification", C.c_int), ("impl", C.c_int),
-                ("bn_eps", C.c_float), ("flags", C.c_int)]
+                ("bn_eps", C.c_float), ("flags", C.c_int), ("variant", C.c_int),
+                ("cond_channels", C.c_int), ("num_classes", C.c_int)]
 
 
 # name -> (restype, argtypes); kept in one table so the symbol-export test can walk it
@@ -44,12 +46,14 @@ SIGNATURES = {
     "drs_unet_workspace_bytes": (_Z, [_P]),
     "drs_unet_pack_weights": (_I, [_P, C.POINTER(_P), C.POINTER(_F), _P, _Z, _P]),
     "drs_unet_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "drs_unet_forward_labels": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _I, _P]),
     "drs_unet_num_tensors": (_I, [_P]),
     "drs_unet_tensor_name": (C.c_char_p, [_P, _I]),
     "drs_unet_tensor_shape": (_I, [_P, _I] + [C.POINTER(_I)] * 4),
     "drs_unet_read_tensor": (_I, [_P, _I, _P, _P, _P]),
     "drs_unet_packed_bwd_bytes": (_Z, [_P]),
     "drs_unet_backward": (_I, [_P, _P, _P, _Z, _P, _P, _P, C.POINTER(_P), _P, _Z, _P]),
+    "drs_unet_backward_labels": (_I, [_P, _P, _P, _Z, _P, _P, _P, _I, _P, C.POINTER(_P), _P, _Z, _P]),
     "drs_unet_profile_enable": (_I, [_P, _I]),
     "drs_unet_profile_num_ops": (_I, [_P]),
     "drs_unet_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

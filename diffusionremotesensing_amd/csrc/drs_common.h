@@ -117,7 +117,8 @@ int drs_launch_bicubic(const float* x, float* y, int N, int C, int H, int W, int
 int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
                         const float* b2, float* out, int out_stride, int B, int dim_in, int dim_out, hipStream_t s);
 int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const char* packed, const long long* table,
-                              int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in, hipStream_t s);
+                              int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in,
+                              const float* label_emb, const long long* labels, int label_batch, hipStream_t s);
 
 // train-mode BatchNorm (bn_train.hip): statistics of Z, running-stat update, normalise + the block's epilogue
 int drs_launch_bn_train(const float* z, int z_cs, int z_co, long long npix, long long pix_per_image, int C,
@@ -152,5 +153,6 @@ int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre
                        long long npix, hipStream_t s);
 int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
                             const float* temb, const float* dtemb, int stride, int B, int dim, float* dW1, float* db1,
-                            float* dW2, float* db2, hipStream_t s);
+                            float* dW2, float* db2, const float* label_emb, const long long* labels, int label_batch,
+                            float* dlabel, hipStream_t s);
 int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, hipStream_t s);

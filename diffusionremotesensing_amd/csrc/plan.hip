@@ -19,7 +19,7 @@ void DrsErr::set(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* drs_last_error(void) { return g_err; }
-extern "C" int drs_abi_version(void) { return 2; }
+extern "C" int drs_abi_version(void) { return 3; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -239,7 +239,8 @@ struct drs_plan {
   ConvLayer output;
 
   size_t packed_bytes = 0, ws_bytes = 0;
-  size_t o_inv_freq = 0, o_mlp_table = 0, o_out_w = 0, o_out_b = 0;
+  size_t o_inv_freq = 0, o_mlp_table = 0, o_out_w = 0, o_out_b = 0, o_label = 0;
+  int label_emb = -1;  // param index of label_emb.weight (generation variant)
   int temb_total = 0;
   std::vector<long long> mlp_table_host;
   std::vector<const void*> param_ptrs;  // as given to the last drs_unet_pack_weights
@@ -328,19 +329,43 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
               cfg->width, cfg->magnification);
   DRS_REQUIRE(cfg->impl >= DRS_IMPL_DIRECT && cfg->impl <= DRS_IMPL_MFMA_F16, DRS_ERR_ARG, "plan_create: impl=%d",
               cfg->impl);
+  DRS_REQUIRE(cfg->variant >= DRS_VARIANT_SUPERRES && cfg->variant <= DRS_VARIANT_GENERATION, DRS_ERR_ARG,
+              "plan_create: variant=%d", cfg->variant);
+  DRS_REQUIRE(cfg->num_classes >= 0, DRS_ERR_ARG, "plan_create: num_classes=%d", cfg->num_classes);
   drs_plan* p = new drs_plan();
   p->cfg = *cfg;
   if (p->cfg.bn_eps <= 0.f) p->cfg.bn_eps = 1e-5f;
   const int C = cfg->image_channels;
+  if (p->cfg.variant == DRS_VARIANT_SUPERRES && p->cfg.cond_channels == 0) p->cfg.cond_channels = C;
+  if (p->cfg.variant == DRS_VARIANT_GENERATION) p->cfg.cond_channels = 0;
+  const int CC = p->cfg.cond_channels;  // conditioning image channels
+  if (p->cfg.variant != DRS_VARIANT_GENERATION && (CC < 1 || CC > 4)) {
+    DrsErr::set("plan_create: cond_channels=%d", CC);
+    delete p;
+    return DRS_ERR_SHAPE;
+  }
+  if (p->cfg.variant == DRS_VARIANT_SAR_TO_NDVI && cfg->magnification != 1) {
+    DrsErr::set("plan_create: the SAR_TO_NDVI variant has no up-sampling (magnification must be 1)");
+    delete p;
+    return DRS_ERR_SHAPE;
+  }
+  const bool has_cond = p->cfg.variant != DRS_VARIANT_GENERATION;
+  const std::string enc_name = p->cfg.variant == DRS_VARIANT_SAR_TO_NDVI ? "SAR_encoder" : "LR_encoder";
+  const std::string cond_name = p->cfg.variant == DRS_VARIANT_SAR_TO_NDVI ? "conv_SAR_img" : "conv_upsampled_lr_img";
+  const std::string skip_name = p->cfg.variant == DRS_VARIANT_GENERATION ? "conv_skip" : cond_name;
 
   // ---- parameters, in a fixed canonical order (names = reference state_dict keys) ----
   p->stem0 = p->mk_planar("conv0", kDown[0], C);
-  for (int i = 0; i < 3; ++i) {
-    p->rrdb[2 * i] = p->mk_planar("LR_encoder.blocks." + std::to_string(i) + ".conv1", C, C);
-    p->rrdb[2 * i + 1] = p->mk_planar("LR_encoder.blocks." + std::to_string(i) + ".conv2", C, C);
+  if (has_cond) {
+    for (int i = 0; i < 3; ++i) {
+      p->rrdb[2 * i] = p->mk_planar(enc_name + ".blocks." + std::to_string(i) + ".conv1", CC, CC);
+      p->rrdb[2 * i + 1] = p->mk_planar(enc_name + ".blocks." + std::to_string(i) + ".conv2", CC, CC);
+    }
+    p->rrdb[6] = p->mk_planar(enc_name + ".conv_out", CC, CC);
+    p->stemc = p->mk_planar(cond_name, kDown[0], CC);
   }
-  p->rrdb[6] = p->mk_planar("LR_encoder.conv_out", C, C);
-  p->stemc = p->mk_planar("conv_upsampled_lr_img", kDown[0], C);
+  if (p->cfg.variant == DRS_VARIANT_GENERATION && cfg->num_classes > 0)
+    p->label_emb = p->P("label_emb.weight", (int64_t)cfg->num_classes * 100);
   for (int i = 0; i < 4; ++i) {
     const std::string pfx = i < 3 ? "conv_blocks." + std::to_string(i) : std::string("bottle_neck");
     const int ci = kDown[i], co = kDown[i + 1];
@@ -350,7 +375,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     rb.conv2 = p->mk_conv(pfx + ".conv2.0", co, co, 9, pfx + ".batch_norm2");
     rb.shortcut = p->mk_conv(pfx + ".shortcut_conv.0", co, ci, 1, pfx + ".shortcut_batch_norm");
     rb.has_skip = (i == 0);
-    if (rb.has_skip) rb.skip = p->mk_conv(pfx + ".conv_upsampled_lr_img", co, ci, 9);
+    if (rb.has_skip) rb.skip = p->mk_conv(pfx + "." + skip_name, co, ci, 9);
     if (i < 3) p->downs[i] = p->mk_conv("downs." + std::to_string(i), co, co, 9);
   }
   for (int i = 0; i < 3; ++i) {
@@ -386,8 +411,10 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
   }
   p->convs.push_back(&p->output);
   p->planars.push_back(&p->stem0);
-  for (int i = 0; i < 7; ++i) p->planars.push_back(&p->rrdb[i]);
-  p->planars.push_back(&p->stemc);
+  if (has_cond) {
+    for (int i = 0; i < 7; ++i) p->planars.push_back(&p->rrdb[i]);
+    p->planars.push_back(&p->stemc);
+  }
 
   // ---- packed buffer layout ----
   size_t cur = 0;
@@ -415,6 +442,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     m->o_b2 = cur; cur += align_up((size_t)m->dim * 4);
   }
   p->o_mlp_table = cur; cur += align_up(p->mlps.size() * 6 * sizeof(long long));
+  p->o_label = cur; cur += align_up((size_t)(cfg->num_classes > 0 ? cfg->num_classes : 0) * 100 * 4);
   p->o_out_w = cur; cur += align_up((size_t)cfg->out_dim * kUp[3] * 4);
   p->o_out_b = cur; cur += align_up((size_t)cfg->out_dim * 4);
   p->packed_bytes = cur;
@@ -423,10 +451,11 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
   const int B = cfg->batch, Bl = cfg->lr_batch, H = cfg->height, W = cfg->width, mag = cfg->magnification;
   const int h = H / mag, w = W / mag;
   size_t ws = 0;
-  for (int i = 0; i < 3; ++i) { p->o_lr[i] = ws; ws += align_up((size_t)Bl * C * h * w * 4); }
+  const int CCw = CC > 0 ? CC : 1;
+  for (int i = 0; i < 3; ++i) { p->o_lr[i] = ws; ws += align_up((size_t)Bl * CCw * h * w * 4); }
   p->o_temb = ws; ws += align_up((size_t)B * p->temb_total * 4);
-  p->t_lrenc = p->T("LR_encoder", ws, Bl, C, h, w, true);
-  p->t_up = p->T("upsampled_lr_img", ws, Bl, C, H, W, true);
+  p->t_lrenc = p->T(enc_name, ws, Bl, CCw, h, w, true);
+  p->t_up = p->T("upsampled_lr_img", ws, Bl, CCw, H, W, true);
   p->t_cond = p->T("cond", ws, Bl, kDown[0], H, W);
   p->t_x0 = p->T("x0", ws, B, kDown[0], H, W);
   for (int i = 0; i < 4; ++i) {
@@ -478,11 +507,11 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     p->g_out = p->T("grad.out", ws, B, cfg->out_dim, H, W);
     p->g_x0 = p->T("grad.x0", ws, B, kDown[0], H, W);
     p->t_xn = p->T("x.nhwc", ws, B, C, H, W);
-    p->t_upn = p->T("upsampled_lr_img.nhwc", ws, B, C, H, W);
-    p->g_upn = p->T("grad.upsampled_lr_img", ws, B, C, H, W);
-    for (int i = 0; i < 4; ++i) p->g_lr[i] = p->T("grad.lr." + std::to_string(i), ws, B, C, h, w);
-    for (int i = 0; i < 4; ++i) p->t_rn[i] = p->T("LR_encoder.r" + std::to_string(i) + ".nhwc", ws, B, C, h, w);
-    for (int i = 0; i < 3; ++i) p->t_an[i] = p->T("LR_encoder.a" + std::to_string(i) + ".nhwc", ws, B, C, h, w);
+    p->t_upn = p->T("upsampled_lr_img.nhwc", ws, B, CCw, H, W);
+    p->g_upn = p->T("grad.upsampled_lr_img", ws, B, CCw, H, W);
+    for (int i = 0; i < 4; ++i) p->g_lr[i] = p->T("grad.lr." + std::to_string(i), ws, B, CCw, h, w);
+    for (int i = 0; i < 4; ++i) p->t_rn[i] = p->T("LR_encoder.r" + std::to_string(i) + ".nhwc", ws, B, CCw, h, w);
+    for (int i = 0; i < 3; ++i) p->t_an[i] = p->T("LR_encoder.a" + std::to_string(i) + ".nhwc", ws, B, CCw, h, w);
     for (int i = 0; i < 4; ++i) {
       const int co = kDown[i + 1], hh = H >> i, ww = W >> i;
       p->g_R[i] = p->T("grad.R" + std::to_string(i), ws, B, co, hh, ww);
@@ -566,6 +595,9 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     plan->mlp_table_host = table;  // must outlive the async copy
     DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_mlp_table, plan->mlp_table_host.data(), table.size() * sizeof(long long),
                                  hipMemcpyHostToDevice, s));
+    if (plan->label_emb >= 0)
+      DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_label, F(plan->label_emb), (size_t)plan->cfg.num_classes * 100 * 4,
+                                   hipMemcpyDeviceToDevice, s));
     DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_w, F(plan->output.w), (size_t)plan->cfg.out_dim * kUp[3] * 4,
                                  hipMemcpyDeviceToDevice, s));
     DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_b, F(plan->output.b), (size_t)plan->cfg.out_dim * 4,
@@ -604,6 +636,12 @@ static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d, hipSt
 extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float* x, const int64_t* t,
                                 const float* lr_img, float* out, void* workspace, size_t workspace_bytes, int flags,
                                 drs_stream_t stream) {
+  return drs_unet_forward_labels(plan, packed, x, t, lr_img, nullptr, 0, out, workspace, workspace_bytes, flags, stream);
+}
+
+extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const float* x, const int64_t* t,
+                                       const float* lr_img, const int64_t* labels, int label_batch, float* out,
+                                       void* workspace, size_t workspace_bytes, int flags, drs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   DRS_REQUIRE(plan && packed && x && t && out && workspace, DRS_ERR_ARG, "forward: null pointer");
   DRS_REQUIRE(plan->packed_ok && plan->packed_ptr == packed, DRS_ERR_STATE,
@@ -611,9 +649,13 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
   DRS_REQUIRE(workspace_bytes >= plan->ws_bytes, DRS_ERR_WORKSPACE, "forward: workspace %zu < %zu", workspace_bytes,
               plan->ws_bytes);
   const bool reuse_cond = (flags & DRS_FWD_REUSE_COND) != 0;
-  DRS_REQUIRE(reuse_cond || lr_img, DRS_ERR_ARG, "forward: lr_img is null");
+  const bool has_cond = plan->cfg.variant != DRS_VARIANT_GENERATION;
+  DRS_REQUIRE(!has_cond || reuse_cond || lr_img, DRS_ERR_ARG, "forward: conditioning image is null");
+  DRS_REQUIRE(!labels || (plan->label_emb >= 0 && (label_batch == plan->cfg.batch || label_batch == 1)), DRS_ERR_ARG,
+              "forward: labels need the generation variant with num_classes > 0 and label_batch == batch or 1");
   const drs_unet_config& c = plan->cfg;
   const int B = c.batch, Bl = c.lr_batch, C = c.image_channels, H = c.height, W = c.width, mag = c.magnification;
+  const int CC = c.cond_channels;
   const int h = H / mag, w = W / mag;
   char* pk = aligned_base(packed);
   void* ws = aligned_base(workspace);
@@ -652,44 +694,49 @@ extern "C" int drs_unet_forward(drs_plan* plan, const void* packed, const float*
   const float* inv_freq = (const float*)(pk + plan->o_inv_freq);
   prof_begin(plan, "time_mlp", 0, 0, s);
   RUN(drs_launch_time_mlp_multi(t, inv_freq, pk, (const long long*)(pk + plan->o_mlp_table), (int)plan->mlps.size(), 256,
-                                temb, plan->temb_total, B, 100, s));
+                                temb, plan->temb_total, B, 100, labels ? (const float*)(pk + plan->o_label) : nullptr,
+                                (const long long*)labels, label_batch, s));
   prof_end(plan, s);
 
   // --- LR conditioning branch: RRDB -> bicubic -> conv (reference :345-353), constant per sampling chain ---
-  if (!reuse_cond) {
-    prof_begin(plan, "lr_branch", 2.0 * Bl * (7.0 * h * w * C * C * 9 + (double)H * W * C * kDown[0] * 9),
-               4.0 * Bl * (15.0 * h * w * C + (double)H * W * (2 * C + kDown[0])), s);
+  if (has_cond && !reuse_cond) {
+    prof_begin(plan, "lr_branch", 2.0 * Bl * (7.0 * h * w * CC * CC * 9 + (double)H * W * CC * kDown[0] * 9),
+               4.0 * Bl * (15.0 * h * w * CC + (double)H * W * (2 * CC + kDown[0])), s);
     float* a = (float*)((char*)ws + plan->o_lr[0]);
     float* b = (float*)((char*)ws + plan->o_lr[1]);
     float* r = (float*)((char*)ws + plan->o_lr[2]);
     const float* cur = lr_img;
-    if (train) RUN(drs_launch_nchw_to_nhwc(lr_img, TP(plan->t_rn[0]), Bl, C, h, w, C, 0, s));
+    if (train) RUN(drs_launch_nchw_to_nhwc(lr_img, TP(plan->t_rn[0]), Bl, CC, h, w, CC, 0, s));
     for (int i = 0; i < 3; ++i) {
       const PlanarConv& c1 = plan->rrdb[2 * i];
       const PlanarConv& c2 = plan->rrdb[2 * i + 1];
       RUN(drs_launch_conv3x3_planar(cur, (const float*)(pk + c1.w_off), (const float*)(pk + c1.b_off), nullptr, a, Bl,
-                                    C, C, h, w, 1, s));
+                                    CC, CC, h, w, 1, s));
       float* dst = (cur == b) ? r : b;  // ping-pong so the residual source stays intact
-      RUN(drs_launch_conv3x3_planar(a, (const float*)(pk + c2.w_off), (const float*)(pk + c2.b_off), cur, dst, Bl, C,
-                                    C, h, w, 0, s));
+      RUN(drs_launch_conv3x3_planar(a, (const float*)(pk + c2.w_off), (const float*)(pk + c2.b_off), cur, dst, Bl, CC,
+                                    CC, h, w, 0, s));
       cur = dst;
       if (train) {  // the backward pass reads a_i (ReLU output) and r_{i+1} channels-last
-        RUN(drs_launch_nchw_to_nhwc(a, TP(plan->t_an[i]), Bl, C, h, w, C, 0, s));
-        RUN(drs_launch_nchw_to_nhwc(dst, TP(plan->t_rn[i + 1]), Bl, C, h, w, C, 0, s));
+        RUN(drs_launch_nchw_to_nhwc(a, TP(plan->t_an[i]), Bl, CC, h, w, CC, 0, s));
+        RUN(drs_launch_nchw_to_nhwc(dst, TP(plan->t_rn[i + 1]), Bl, CC, h, w, CC, 0, s));
       }
     }
     const PlanarConv& co = plan->rrdb[6];
     RUN(drs_launch_conv3x3_planar(cur, (const float*)(pk + co.w_off), (const float*)(pk + co.b_off), lr_img,
-                                  TP(plan->t_lrenc), Bl, C, C, h, w, 0, s));
-    RUN(drs_launch_bicubic(TP(plan->t_lrenc), TP(plan->t_up), Bl, C, h, w, mag, s));
-    RUN(drs_launch_stem(TP(plan->t_up), (const float*)(pk + plan->stemc.w_off), (const float*)(pk + plan->stemc.b_off),
-                        nullptr, 0, TP(plan->t_cond), Bl, C, kDown[0], H, W, s));
+                                  TP(plan->t_lrenc), Bl, CC, CC, h, w, 0, s));
+    const float* upsrc = TP(plan->t_lrenc);  // SAR variant: the encoded image is used at its own resolution
+    if (mag > 1 || train) {
+      RUN(drs_launch_bicubic(TP(plan->t_lrenc), TP(plan->t_up), Bl, CC, h, w, mag, s));
+      upsrc = TP(plan->t_up);
+    }
+    RUN(drs_launch_stem(upsrc, (const float*)(pk + plan->stemc.w_off), (const float*)(pk + plan->stemc.b_off),
+                        nullptr, 0, TP(plan->t_cond), Bl, CC, kDown[0], H, W, s));
     prof_end(plan, s);
   }
   // --- x = conv0(x) + cond (reference :342,:355) ---
   prof_begin(plan, "conv0", 2.0 * B * H * W * C * kDown[0] * 9, 4.0 * B * H * W * (C + 2.0 * kDown[0]), s);
   RUN(drs_launch_stem(x, (const float*)(pk + plan->stem0.w_off), (const float*)(pk + plan->stem0.b_off),
-                      TP(plan->t_cond), Bl, TP(plan->t_x0), B, C, kDown[0], H, W, s));
+                      has_cond ? TP(plan->t_cond) : nullptr, Bl, TP(plan->t_x0), B, C, kDown[0], H, W, s));
   prof_end(plan, s);
 
   // --- encoder + bottleneck: ResConvBlock (reference :153-172), downs (:366) ---

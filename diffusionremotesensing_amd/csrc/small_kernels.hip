@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __re
                                                              const float* __restrict__ inv_freq,
                                                              const char* __restrict__ packed,
                                                              const long long* __restrict__ table,
-                                                             float* __restrict__ out, int out_stride, int dim_in) {
+                                                             float* __restrict__ out, int out_stride, int dim_in,
+                                                             const float* __restrict__ label_emb,
+                                                             const long long* __restrict__ labels, int label_batch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e = smem;
   float* h = smem + dim_in;
@@ -354,6 +356,11 @@ __global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __re
     e[half + j] = cosf(arg);
   }
   __syncthreads();
+  if (labels) {  // class-conditional generation: t += label_emb(y) (reference UNet_model_generation.py:300-301)
+    const float* le = label_emb + (size_t)labels[label_batch == 1 ? 0 : b] * dim_in;
+    for (int j = threadIdx.x; j < dim_in; j += blockDim.x) e[j] += le[j];
+    __syncthreads();
+  }
   for (int c = threadIdx.x; c < dim_out; c += blockDim.x) {
     const float* wr = W1 + (size_t)c * dim_in;
     float acc = 0.f;
@@ -371,11 +378,12 @@ __global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __re
   }
 }
 int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const char* packed, const long long* table,
-                              int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in, hipStream_t s) {
+                              int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in,
+                              const float* label_emb, const long long* labels, int label_batch, hipStream_t s) {
   if (B == 0 || nmlp == 0) return DRS_OK;
   const size_t shmem = (size_t)(dim_in + max_dim) * sizeof(float);
   hipLaunchKernelGGL(time_mlp_multi_kernel, dim3(B, nmlp), dim3(256), shmem, s, t, inv_freq, packed, table, out,
-                     out_stride, dim_in);
+                     out_stride, dim_in, label_emb, labels, label_batch);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -348,16 +348,24 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
                                                            const float* __restrict__ W2, const float* __restrict__ temb,
                                                            const float* __restrict__ dtemb, int stride, int B, int dim,
                                                            float* __restrict__ dW1, float* __restrict__ db1,
-                                                           float* __restrict__ dW2, float* __restrict__ db2) {
+                                                           float* __restrict__ dW2, float* __restrict__ db2,
+                                                           const float* __restrict__ label_emb,
+                                                           const long long* __restrict__ labels, int label_batch,
+                                                           float* __restrict__ dlabel) {
   __shared__ float e[100], pre1[256], h1[256], d2[256], dpre1[256];
   for (int b = 0; b < B; ++b) {
     const float tf = (float)t[b];
+    const long long lab = labels ? labels[label_batch == 1 ? 0 : b] : 0;
     for (int j = threadIdx.x; j < 50; j += blockDim.x) {
       const float arg = tf * inv_freq[j];
       e[j] = sinf(arg);
       e[50 + j] = cosf(arg);
     }
     __syncthreads();
+    if (labels) {  // e = posenc(t) + label_emb[y] (generation variant)
+      for (int j = threadIdx.x; j < 100; j += blockDim.x) e[j] += label_emb[lab * 100 + j];
+      __syncthreads();
+    }
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
       float a = b1[c];
       for (int k = 0; k < 100; ++k) a = fmaf(W1[(size_t)c * 100 + k], e[k], a);
@@ -381,15 +389,23 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
       db1[k] += dpre1[k];
       for (int j = 0; j < 100; ++j) dW1[(size_t)k * 100 + j] += dpre1[k] * e[j];
     }
+    if (dlabel)  // d e = W1^T dpre1 lands on the embedding row of this sample's class (MLPs run back to back on
+                 // one stream and one block: plain read-modify-write)
+      for (int j = threadIdx.x; j < 100; j += blockDim.x) {
+        float a = 0.f;
+        for (int k = 0; k < dim; ++k) a = fmaf(W1[(size_t)k * 100 + j], dpre1[k], a);
+        dlabel[lab * 100 + j] += a;
+      }
     __syncthreads();
   }
 }
 int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
                             const float* temb, const float* dtemb, int stride, int B, int dim, float* dW1, float* db1,
-                            float* dW2, float* db2, hipStream_t s) {
+                            float* dW2, float* db2, const float* label_emb, const long long* labels, int label_batch,
+                            float* dlabel, hipStream_t s) {
   DRS_REQUIRE(dim <= 256, DRS_ERR_SHAPE, "time_mlp_bwd: dim=%d", dim);
   hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, t, inv_freq, W1, b1, W2, temb, dtemb, stride, B, dim, dW1,
-                     db1, dW2, db2);
+                     db1, dW2, db2, label_emb, labels, label_batch, dlabel);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -72,7 +72,8 @@ def broadcast_module(module, src=0):
         return
     with torch.no_grad():
         tensors = [p.data for p in module.parameters()] + [b for b in module.buffers()]
-        for dtype in {t.dtype for t in tensors}:
+        # same dtype order on every rank (a set of dtypes iterates in a per-process order -> mismatched collectives)
+        for dtype in sorted({t.dtype for t in tensors}, key=str):
             group = [t for t in tensors if t.dtype == dtype]
             flat = _flat(group)
             td.broadcast(flat, src=src)

@@ -53,9 +53,13 @@ class HipUNetEngine:
     like nn.BatchNorm2d, and with autograd enabled the call is recorded so that loss.backward() runs
     drs_unet_backward (weight / bias / BatchNorm-affine gradients of every live parameter)."""
 
+    VARIANTS = {"superres": _lib.VARIANT_SUPERRES, "sar_to_ndvi": _lib.VARIANT_SAR_TO_NDVI,
+                "generation": _lib.VARIANT_GENERATION}
+
     def __init__(self, module, variant="superres", impl=None):
-        if variant != "superres":
-            raise NotImplementedError(f"UNet variant {variant!r} is not built yet")
+        if variant not in self.VARIANTS:
+            raise NotImplementedError(f"UNet variant {variant!r} is not built")
+        self.variant = variant
         self._module = weakref.ref(module)
         self.impl = _lib.IMPL_BY_NAME[impl or DEFAULT_IMPL]
         # training steps run the exact-fp32 MFMA kernels by default: gradients pass through ~25 BatchNorm backward
@@ -74,9 +78,16 @@ class HipUNetEngine:
         plan = self._plans.get(key)
         if plan is None:
             m = self._module()
-            cfg = _lib.UNetConfig(B, Bl, m.image_channels, m.out_dim, H, W, mag, impl, 1e-5,
+            if self.variant == "sar_to_ndvi":  # UNet_model_SAR_TO_NDVI.py:264-267: x has NDVI_channels, cond SAR_channels
+                cx, cout, cc, ncls = m.NDVI_channels, m.NDVI_channels, m.SAR_channels, 0
+            elif self.variant == "generation":
+                cx, cout, cc, ncls = m.image_channels, m.out_dim, 0, int(m.num_classes or 0)
+            else:
+                cx, cout, cc, ncls = m.image_channels, m.out_dim, m.image_channels, 0
+            cfg = _lib.UNetConfig(B, Bl, cx, cout, H, W, mag, impl, 1e-5,
                                   (_lib.PLAN_KEEP_ALL if self.keep_intermediates else 0) |
-                                  (_lib.PLAN_TRAIN if train else 0))
+                                  (_lib.PLAN_TRAIN if train else 0), self.VARIANTS[self.variant], cc, ncls)
+            self._channels = (cx, cout, cc)
             plan = _Plan(_lib.load(), cfg, device)
             plan.train = train
             self._plans[key] = plan
@@ -113,51 +124,74 @@ class HipUNetEngine:
 
     # -- forward ----------------------------------------------------------------------------
     def forward(self, x, timestep, lr_img, magnification_factor, reuse_cond=False, check_weights=True,
-                _in_autograd_fn=False):
+                _in_autograd_fn=False, labels=None):
+        """`lr_img` is the conditioning image (LR image / SAR image; None for the generation variant);
+        `labels` the optional class labels of the generation variant."""
         m = self._module()
         train = bool(m.training)
+        has_cond = self.variant != "generation"
+        if not has_cond:
+            lr_img, magnification_factor = None, 1
+        elif not isinstance(lr_img, torch.Tensor):
+            raise RuntimeError("the conditioning image must be a tensor on a ROCm device")
         if train and torch.is_grad_enabled() and not _in_autograd_fn and any(p.requires_grad for p in m.parameters()):
             # training step: route through autograd so loss.backward() reaches drs_unet_backward
             sd = m.state_dict(keep_vars=True)
-            plan = self._get_plan(x.shape[0], lr_img.shape[0], x.shape[2], x.shape[3], int(magnification_factor), x.device, True)
+            plan = self._get_plan(x.shape[0], lr_img.shape[0] if has_cond else x.shape[0], x.shape[2], x.shape[3],
+                                  int(magnification_factor), x.device, True)
             params = [sd[n] for n in plan.param_names if sd[n].requires_grad]
-            return _UNetTrainFn.apply(self, x, timestep, lr_img, magnification_factor, *params)
-        for name, t in (("x", x), ("timestep", timestep), ("lr_img", lr_img)):
+            return _UNetTrainFn.apply(self, x, timestep, lr_img, magnification_factor, labels, *params)
+        named = [("x", x), ("timestep", timestep)] + ([("lr_img", lr_img)] if has_cond else []) + \
+                ([("labels", labels)] if labels is not None else [])
+        for name, t in named:
             if not isinstance(t, torch.Tensor) or not t.is_cuda:
                 raise RuntimeError(f"{name} must be a tensor on a ROCm device: the UNet forward has no CPU fallback")
-        if x.dtype != torch.float32 or lr_img.dtype != torch.float32:
-            raise RuntimeError("x and lr_img must be float32 (the reference forward is fp32-only)")
-        if x.dim() != 4 or lr_img.dim() != 4:
-            raise RuntimeError("x and lr_img must be NCHW")
+        if x.dtype != torch.float32 or (has_cond and lr_img.dtype != torch.float32):
+            raise RuntimeError("x and the conditioning image must be float32 (the reference forward is fp32-only)")
+        if x.dim() != 4 or (has_cond and lr_img.dim() != 4):
+            raise RuntimeError("x and the conditioning image must be NCHW")
         B, Cx, H, W = x.shape
-        Bl = lr_img.shape[0]
+        Bl = lr_img.shape[0] if has_cond else B
         mag = int(magnification_factor)
-        if Cx != m.image_channels or lr_img.shape[1] != m.image_channels:
-            raise RuntimeError(f"expected {m.image_channels} channels, got x {Cx}, lr_img {lr_img.shape[1]}")
-        if lr_img.shape[2] * mag != H or lr_img.shape[3] * mag != W:
-            raise RuntimeError(f"lr_img {tuple(lr_img.shape)} x{mag} does not match x {tuple(x.shape)}")
+        plan = self._get_plan(B, Bl, H, W, mag, x.device, train)
+        cx, _, cc = self._channels
+        if Cx != cx or (has_cond and lr_img.shape[1] != cc):
+            raise RuntimeError(f"expected {cx} image / {cc} conditioning channels, got x {Cx}"
+                               + (f", cond {lr_img.shape[1]}" if has_cond else ""))
+        if has_cond and (lr_img.shape[2] * mag != H or lr_img.shape[3] * mag != W):
+            raise RuntimeError(f"conditioning image {tuple(lr_img.shape)} x{mag} does not match x {tuple(x.shape)}")
         if timestep.shape != (B,):
             raise RuntimeError(f"timestep must have shape ({B},), got {tuple(timestep.shape)}")
+        if labels is not None:
+            if self.variant != "generation" or not getattr(m, "num_classes", None):
+                raise RuntimeError("labels need Residual_Attention_UNet_generation built with num_classes")
+            labels = labels.to(torch.int64).contiguous()
+            if labels.shape not in ((B,), (1,)):
+                raise RuntimeError(f"labels must have shape ({B},) or (1,), got {tuple(labels.shape)}")
         x = x.contiguous()
-        lr_img = lr_img.contiguous()
+        if has_cond:
+            lr_img = lr_img.contiguous()
         timestep = timestep.to(torch.int64).contiguous()
-        plan = self._get_plan(B, Bl, H, W, mag, x.device, train)
+        out_dim = self._channels[1]
         with torch.cuda.device(x.device):
             if check_weights or plan.signature is None:
                 self._sync_weights(plan)
             flags = 0
-            if reuse_cond:
+            if reuse_cond and has_cond:
                 if plan.cond_key != (lr_img.data_ptr(), lr_img._version):
                     raise RuntimeError("reuse_cond=True but the conditioning in the workspace belongs to another lr_img")
                 flags |= _lib.FWD_REUSE_COND
-            out = torch.empty((B, m.out_dim, H, W), dtype=torch.float32, device=x.device)
+            out = torch.empty((B, out_dim, H, W), dtype=torch.float32, device=x.device)
             stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            st = plan.lib.drs_unet_forward(plan.handle, C.c_void_p(plan.packed.data_ptr()), C.c_void_p(x.data_ptr()),
-                                           C.c_void_p(timestep.data_ptr()), C.c_void_p(lr_img.data_ptr()),
-                                           C.c_void_p(out.data_ptr()), C.c_void_p(plan.workspace.data_ptr()),
-                                           plan.ws_bytes, flags, stream)
+            st = plan.lib.drs_unet_forward_labels(
+                plan.handle, C.c_void_p(plan.packed.data_ptr()), C.c_void_p(x.data_ptr()),
+                C.c_void_p(timestep.data_ptr()), C.c_void_p(lr_img.data_ptr() if has_cond else None),
+                C.c_void_p(labels.data_ptr() if labels is not None else None),
+                int(labels.shape[0]) if labels is not None else 0,
+                C.c_void_p(out.data_ptr()), C.c_void_p(plan.workspace.data_ptr()), plan.ws_bytes, flags, stream)
             _lib.check(st, "drs_unet_forward")
-            plan.cond_key = (lr_img.data_ptr(), lr_img._version)
+            if has_cond:
+                plan.cond_key = (lr_img.data_ptr(), lr_img._version)
             if train:  # the kernels updated running_mean / running_var in place; num_batches_tracked follows here
                 self._bn_epoch += 1
                 nbt = [b for k, b in m.named_buffers() if k.endswith("num_batches_tracked")]
@@ -167,7 +201,7 @@ class HipUNetEngine:
         return out
 
     # -- backward (training step) ---------------------------------------------------------------
-    def backward(self, plan, x, timestep, dout):
+    def backward(self, plan, x, timestep, dout, labels=None):
         """d(loss)/d(parameters) for the last train-mode forward on `plan`; returns {state_dict key: gradient}."""
         m = self._module()
         sd = m.state_dict(keep_vars=True)
@@ -188,10 +222,12 @@ class HipUNetEngine:
         dout = dout.contiguous()
         with torch.cuda.device(plan.device):
             stream = C.c_void_p(torch.cuda.current_stream(plan.device).cuda_stream)
-            st = lib.drs_unet_backward(plan.handle, C.c_void_p(plan.packed.data_ptr()), C.c_void_p(plan.packed_bwd.data_ptr()),
-                                       plan.packed_bwd_bytes, C.c_void_p(x.data_ptr()), C.c_void_p(timestep.data_ptr()),
-                                       C.c_void_p(dout.data_ptr()), ptrs, C.c_void_p(plan.workspace.data_ptr()),
-                                       plan.ws_bytes, stream)
+            st = lib.drs_unet_backward_labels(
+                plan.handle, C.c_void_p(plan.packed.data_ptr()), C.c_void_p(plan.packed_bwd.data_ptr()),
+                plan.packed_bwd_bytes, C.c_void_p(x.data_ptr()), C.c_void_p(timestep.data_ptr()),
+                C.c_void_p(labels.data_ptr() if labels is not None else None),
+                int(labels.shape[0]) if labels is not None else 0, C.c_void_p(dout.data_ptr()), ptrs,
+                C.c_void_p(plan.workspace.data_ptr()), plan.ws_bytes, stream)
         _lib.check(st, "drs_unet_backward")
         return views
 
@@ -243,21 +279,26 @@ class HipUNetEngine:
 
 
 class _UNetTrainFn(torch.autograd.Function):
-    """Autograd node of one train-mode UNet forward: forward = drs_unet_forward on the train plan, backward =
-    drs_unet_backward.  No gradient flows to x_t / lr_img (they are data in the reference's training loop)."""
+    """Autograd node of one train-mode UNet forward: forward = drs_unet_forward_labels on the train plan, backward =
+    drs_unet_backward_labels.  No gradient flows to x_t / the conditioning image (data in the reference's loops)."""
 
     @staticmethod
-    def forward(ctx, engine, x, timestep, lr_img, mag, *params):
+    def forward(ctx, engine, x, timestep, lr_img, mag, labels, *params):
         x = x.contiguous()
         timestep = timestep.to(torch.int64).contiguous()
-        out = engine.forward(x, timestep, lr_img, mag, _in_autograd_fn=True)
+        if labels is not None:
+            labels = labels.to(torch.int64).contiguous()
+        out = engine.forward(x, timestep, lr_img, mag, _in_autograd_fn=True, labels=labels)
         ctx.engine, ctx.plan = engine, engine._last_plan
         ctx.names = [n for n in ctx.plan.param_names if engine._module().state_dict(keep_vars=True)[n].requires_grad]
+        ctx.labels = labels
         ctx.save_for_backward(x, timestep)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, timestep = ctx.saved_tensors
-        grads = ctx.engine.backward(ctx.plan, x, timestep, dout)
-        return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+        grads = ctx.engine.backward(ctx.plan, x, timestep, dout, ctx.labels)
+        if ctx.labels is None:  # unconditional step: autograd leaves label_emb.weight.grad = None (Adam skips it)
+            grads["label_emb.weight"] = None
+        return (None,) * 6 + tuple(grads[n] for n in ctx.names)

@@ -87,6 +87,8 @@ def seeded_state_dict(template, seed=0):
                 out[key] = tensor_uniform(ckey, shape, seed, 0.6, 1.4)
             else:
                 out[key] = tensor_normal(ckey, shape, seed, std=0.1)
+        elif key == "label_emb.weight":
+            out[key] = tensor_normal(ckey, shape, seed, std=1.0)  # nn.Embedding's own N(0, 1) scale
         elif leaf == "bias":
             out[key] = tensor_normal(ckey, shape, seed, std=0.05)
         else:
@@ -96,7 +98,7 @@ def seeded_state_dict(template, seed=0):
                 fan_in = shape[0] * 9 // 4
             # gain chosen so that eval-mode activations stay O(1) through the residual/concat structure
             # (a trained network's BatchNorm statistics would do that; random ones do not)
-            gain = 0.65 if (len(shape) == 4 and not key.startswith("LR_encoder")) else 1.0
+            gain = 0.65 if (len(shape) == 4 and not key.startswith(("LR_encoder", "SAR_encoder"))) else 1.0
             out[key] = tensor_normal(ckey, shape, seed, std=gain * float(np.sqrt(2.0 / max(fan_in, 1))))
     return out
 

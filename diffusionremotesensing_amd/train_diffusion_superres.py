@@ -163,14 +163,21 @@ class Diffusion:
     def _is_rank0(self):
         return (not self.multiple_gpus) or self.device == 0 or drs_dist.rank() == 0
 
+    def _predict(self, net, x_t, t, cond):
+        """The model call of the loop bodies (:388, :474); the SAR / generation subclasses override it."""
+        return net(x_t, t, cond, self.magnification_factor)
+
+    def _split_batch(self, batch):
+        """(conditioning, clean image) of one loader item: (lr_img, hr_img) here (:379)."""
+        return batch[0].to(self.device), batch[1].to(self.device)
+
     def train_step(self, model, optimizer, loss_function, lr_img, hr_img, ema=None, ema_model=None):
         """Loop body of reference :379-396 (called `train_step` in BASELINE.json's north_star)."""
-        lr_img = lr_img.to(self.device)
-        hr_img = hr_img.to(self.device)
+        lr_img, hr_img = self._split_batch((lr_img, hr_img))
         t = self.sample_timesteps(hr_img.shape[0]).to(self.device)
         x_t, noise = self.noise_images(hr_img, t)
         optimizer.zero_grad()
-        predicted_noise = model(x_t, t, lr_img, self.magnification_factor)
+        predicted_noise = self._predict(model, x_t, t, self._train_cond(lr_img))
         train_loss = loss_function(predicted_noise, noise)
         train_loss.backward()
         if self.multiple_gpus:
@@ -179,6 +186,11 @@ class Diffusion:
         if ema is not None:
             ema.step_ema(ema_model, model)
         return train_loss
+
+    def _train_cond(self, cond):
+        """Conditioning actually passed to the model in a training / validation step (the generation subclass drops
+        the label 10% of the time, like its reference loop)."""
+        return cond
 
     def train(self, lr, epochs, check_preds_epoch, train_loader, val_loader, patience, loss, verbose):
         model = self.model
@@ -210,13 +222,12 @@ class Diffusion:
                 running_val_loss = torch.zeros((), device=self.device)
                 with torch.no_grad():
                     model.eval()
-                    for lr_img, hr_img in val_loader:
-                        lr_img = lr_img.to(self.device)
-                        hr_img = hr_img.to(self.device)
+                    for batch in val_loader:
+                        lr_img, hr_img = self._split_batch(batch)
                         t = self.sample_timesteps(hr_img.shape[0]).to(self.device)
                         x_t, noise = self.noise_images(hr_img, t)
                         net = ema_model if self.ema_smoothing else model
-                        running_val_loss += loss_function(net(x_t, t, lr_img, self.magnification_factor), noise)
+                        running_val_loss += loss_function(self._predict(net, x_t, t, self._train_cond(lr_img)), noise)
                 running_val_loss = running_val_loss.item() / max(len(val_loader), 1)
                 print(f"Epoch {epoch}: Running Val loss ({loss}){running_val_loss}")
                 if running_val_loss < best_loss:

@@ -111,7 +111,19 @@ typedef struct drs_unet_config {
   int impl;           /* DRS_IMPL_* used for the wide convolutions */
   float bn_eps;       /* 1e-5 */
   int flags;          /* DRS_PLAN_* */
+  int variant;        /* DRS_VARIANT_* : which of the reference's three near-identical UNets */
+  int cond_channels;  /* channels of the conditioning image (superres: = image_channels; SAR: 2; generation: 0) */
+  int num_classes;    /* generation: rows of label_emb (0 = no label embedding) */
 } drs_unet_config;
+/* Variants (same kernels, different wiring and state_dict key names):
+ *  SUPERRES    Residual_Attention_UNet_superres   UNet_model_superres.py:266-379   cond = lr_img, bicubic x mag
+ *  SAR_TO_NDVI Residual_Attention_UNet_SAR_TO_NDVI UNet_model_SAR_TO_NDVI.py:263-370 cond = SAR image at full size
+ *              (magnification must be 1), image_channels = out_dim = NDVI channels
+ *  GENERATION  Residual_Attention_UNet_generation generate_new_imgs/UNet_model_generation.py:226-329  no conditioning
+ *              image; optional class label added to the time encoding (t += label_emb(y), :300-301) */
+#define DRS_VARIANT_SUPERRES 0
+#define DRS_VARIANT_SAR_TO_NDVI 1
+#define DRS_VARIANT_GENERATION 2
 /* Keep every intermediate activation readable through drs_unet_read_tensor (parity tests).  Without it the
  * 32-channel output of up_convs.2 is never written: the final 1x1 `output` conv is fused into its epilogue. */
 #define DRS_PLAN_KEEP_ALL 1
@@ -145,6 +157,11 @@ int drs_unet_pack_weights(drs_plan* plan, const void* const* params, const float
 #define DRS_FWD_REUSE_COND 1
 int drs_unet_forward(drs_plan* plan, const void* packed, const float* x, const int64_t* t, const float* lr_img,
                      float* out, void* workspace, size_t workspace_bytes, int flags, drs_stream_t stream);
+/* Same, with class labels for the GENERATION variant: labels = int64[label_batch] (label_batch == batch or 1,
+ * broadcast) or NULL for the unconditional forward (reference forward(x, timestep, y=None)). */
+int drs_unet_forward_labels(drs_plan* plan, const void* packed, const float* x, const int64_t* t, const float* cond,
+                            const int64_t* labels, int label_batch, float* out, void* workspace,
+                            size_t workspace_bytes, int flags, drs_stream_t stream);
 
 /* Introspection for block-level parity tests: intermediate activations left in the workspace by the last
  * forward, converted to NCHW into `dst`.  Names follow the reference module tree
@@ -166,6 +183,11 @@ size_t drs_unet_packed_bwd_bytes(const drs_plan* plan);
 int drs_unet_backward(drs_plan* plan, const void* packed, void* packed_bwd, size_t packed_bwd_bytes, const float* x,
                       const int64_t* t, const float* dout, float* const* grads, void* workspace, size_t workspace_bytes,
                       drs_stream_t stream);
+/* Same for a forward that was given class labels (GENERATION variant): also produces d(label_emb.weight). */
+int drs_unet_backward_labels(drs_plan* plan, const void* packed, void* packed_bwd, size_t packed_bwd_bytes,
+                             const float* x, const int64_t* t, const int64_t* labels, int label_batch,
+                             const float* dout, float* const* grads, void* workspace, size_t workspace_bytes,
+                             drs_stream_t stream);
 
 /* Per-op timing of the forward schedule: with profiling on, drs_unet_forward brackets every op with HIP events on
  * the stream it launches on; afterwards read (name, milliseconds, algorithmic FLOPs, algorithmic bytes) per op.

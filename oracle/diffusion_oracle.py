@@ -72,3 +72,34 @@ def sample(model, n, lr_img, noise_steps, alpha, alpha_hat, beta, magnification_
             if i in keep_steps:
                 kept[i] = x.clone()
     return (x, kept) if keep_steps else x
+
+
+def sample_sar(model, n, sar_img, noise_steps, alpha, alpha_hat, beta, image_size, ndvi_channels=1, noise_source=None):
+    """Diffusion.sample of train_diffusion_SAR_TO_NDVI.py:204-249 on CPU: same chain, model(x, t, SAR_img)."""
+    sar = sar_img.unsqueeze(0)
+    shape = (n, ndvi_channels, image_size, image_size)
+    with torch.no_grad():
+        x = noise_source(noise_steps, shape) if noise_source else torch.randn(shape)
+        for i in reversed(range(1, noise_steps)):
+            t = (torch.ones(n) * i).long()
+            eps = model(x, t, sar)
+            z = (noise_source(i, shape) if noise_source else torch.randn_like(x)) if i > 1 else torch.zeros_like(x)
+            x = sampler_step(x, eps, z, t, alpha, alpha_hat, beta)
+    return x
+
+
+def sample_generation(model, n, target_class, cfg_scale, noise_steps, alpha, alpha_hat, beta, image_size,
+                      input_channels=3, noise_source=None):
+    """Diffusion.sample of generate_new_imgs/train_diffusion_generation.py:206-259 on CPU: conditional prediction,
+    and for cfg_scale > 0 an unconditional one combined with torch.lerp(uncond, cond, cfg_scale) (:236-239)."""
+    shape = (n, input_channels, image_size, image_size)
+    with torch.no_grad():
+        x = noise_source(noise_steps, shape) if noise_source else torch.randn(shape)
+        for i in reversed(range(1, noise_steps)):
+            t = (torch.ones(n) * i).long()
+            eps = model(x, t, target_class)
+            if cfg_scale > 0:
+                eps = torch.lerp(model(x, t, None), eps, cfg_scale)
+            z = (noise_source(i, shape) if noise_source else torch.randn_like(x)) if i > 1 else torch.zeros_like(x)
+            x = sampler_step(x, eps, z, t, alpha, alpha_hat, beta)
+    return x

@@ -55,11 +55,12 @@ def _time_mlp(sd, pfx, t):
     return F.relu(h)[(...,) + (None,) * 2]
 
 
-def res_conv_block(sd, pfx, x, t, x_skip, training=False, stats=None, taps=None):
-    """ResConvBlock.forward, :153-172."""
+def res_conv_block(sd, pfx, x, t, x_skip, training=False, stats=None, taps=None, skip_name="conv_upsampled_lr_img"):
+    """ResConvBlock.forward, :153-172 (same body in UNet_model_SAR_TO_NDVI.py:150-169 with `conv_SAR_img` and in
+    generate_new_imgs/UNet_model_generation.py:146-165 with `conv_skip`)."""
     h = F.relu(_bn(sd, pfx + ".batch_norm1", _conv(sd, pfx + ".conv1.0", x, padding=1), training, stats))
     if x_skip is not None:
-        h = h + _conv(sd, pfx + ".conv_upsampled_lr_img", x_skip, padding=1)
+        h = h + _conv(sd, pfx + "." + skip_name, x_skip, padding=1)
     h = h + _time_mlp(sd, pfx + ".time_mlp", t)
     if taps is not None:
         taps[pfx + ".h"] = h
@@ -110,31 +111,23 @@ def rrdb(sd, pfx, x):
     return out + x
 
 
-def unet_forward(sd, x, timestep, lr_img, magnification_factor, training=False, stats=None, taps=None):
-    """Residual_Attention_UNet_superres.forward, :337-379.  `taps`, when a dict, receives the named
-    intermediate activations (names match drs_unet_tensor_name)."""
-    t = pos_encoding(timestep.unsqueeze(-1).type(torch.float), TIME_EMB_DIM)
-    x = _conv(sd, "conv0", x, padding=1)
-    lr = rrdb(sd, "LR_encoder", lr_img)
-    up = F.interpolate(lr, scale_factor=magnification_factor, mode="bicubic")
-    if taps is not None:
-        taps["LR_encoder"] = lr
-        taps["upsampled_lr_img"] = up
-    x = x + _conv(sd, "conv_upsampled_lr_img", up, padding=1)
+def _trunk(sd, x, t, skip_name, training, stats, taps):
+    """Encoder, bottleneck, gated decoder and output projection: identical in the three reference models
+    (UNet_model_superres.py:356-379, UNet_model_SAR_TO_NDVI.py:347-370, UNet_model_generation.py:304-329)."""
     if taps is not None:
         taps["x0"] = x
     x_skip = x.clone()
     residual_inputs = []
     for i in range(3):
         pfx = f"conv_blocks.{i}"
-        x = res_conv_block(sd, pfx, x, t, x_skip if i == 0 else None, training, stats, taps)
+        x = res_conv_block(sd, pfx, x, t, x_skip if i == 0 else None, training, stats, taps, skip_name)
         if taps is not None:
             taps[pfx] = x
         residual_inputs.append(x)
         x = _conv(sd, f"downs.{i}", x, stride=2, padding=1)
         if taps is not None:
             taps[f"downs.{i}"] = x
-    x = res_conv_block(sd, "bottle_neck", x, t, None, training, stats, taps)
+    x = res_conv_block(sd, "bottle_neck", x, t, None, training, stats, taps, skip_name)
     if taps is not None:
         taps["bottle_neck"] = x
     for i in range(3):
@@ -152,6 +145,40 @@ def unet_forward(sd, x, timestep, lr_img, magnification_factor, training=False, 
     return _conv(sd, "output", x)
 
 
+def unet_forward(sd, x, timestep, lr_img, magnification_factor, training=False, stats=None, taps=None):
+    """Residual_Attention_UNet_superres.forward, :337-379.  `taps`, when a dict, receives the named
+    intermediate activations (names match drs_unet_tensor_name)."""
+    t = pos_encoding(timestep.unsqueeze(-1).type(torch.float), TIME_EMB_DIM)
+    x = _conv(sd, "conv0", x, padding=1)
+    lr = rrdb(sd, "LR_encoder", lr_img)
+    up = F.interpolate(lr, scale_factor=magnification_factor, mode="bicubic")
+    if taps is not None:
+        taps["LR_encoder"] = lr
+        taps["upsampled_lr_img"] = up
+    x = x + _conv(sd, "conv_upsampled_lr_img", up, padding=1)
+    return _trunk(sd, x, t, "conv_upsampled_lr_img", training, stats, taps)
+
+
+def unet_forward_sar(sd, ndvi_img, timestep, sar_img, training=False, stats=None, taps=None):
+    """Residual_Attention_UNet_SAR_TO_NDVI.forward, UNet_model_SAR_TO_NDVI.py:332-370."""
+    t = pos_encoding(timestep.unsqueeze(-1).type(torch.float), TIME_EMB_DIM)
+    x = _conv(sd, "conv0", ndvi_img, padding=1)
+    sar = rrdb(sd, "SAR_encoder", sar_img)
+    if taps is not None:
+        taps["SAR_encoder"] = sar
+    x = x + _conv(sd, "conv_SAR_img", sar, padding=1)
+    return _trunk(sd, x, t, "conv_SAR_img", training, stats, taps)
+
+
+def unet_forward_generation(sd, x, timestep, y=None, training=False, stats=None, taps=None):
+    """Residual_Attention_UNet_generation.forward, generate_new_imgs/UNet_model_generation.py:296-329."""
+    t = pos_encoding(timestep.unsqueeze(-1).type(torch.float), TIME_EMB_DIM)
+    if y is not None:
+        t = t + F.embedding(y, sd["label_emb.weight"])  # `t += self.label_emb(y)`, :300-301
+    x = _conv(sd, "conv0", x, padding=1)
+    return _trunk(sd, x, t, "conv_skip", training, stats, taps)
+
+
 class OracleUNet(torch.nn.Module):
     """Callable wrapper with the reference's `model(x, t, lr_img, mag)` contract, for driving
     `oracle.diffusion_oracle.sample` and the gloo tests."""
@@ -163,3 +190,27 @@ class OracleUNet(torch.nn.Module):
     def forward(self, x, timestep, lr_img, magnification_factor):
         with torch.no_grad():
             return unet_forward(self.sd, x, timestep, lr_img, magnification_factor, training=False)
+
+
+class OracleUNetSAR(torch.nn.Module):
+    """`model(NDVI_img, t, SAR_img)` contract of the SAR->NDVI model."""
+
+    def __init__(self, sd):
+        super().__init__()
+        self.sd = sd
+
+    def forward(self, ndvi_img, timestep, sar_img):
+        with torch.no_grad():
+            return unet_forward_sar(self.sd, ndvi_img, timestep, sar_img)
+
+
+class OracleUNetGeneration(torch.nn.Module):
+    """`model(x, t, y=None)` contract of the class-conditional generation model."""
+
+    def __init__(self, sd):
+        super().__init__()
+        self.sd = sd
+
+    def forward(self, x, timestep, y=None):
+        with torch.no_grad():
+            return unet_forward_generation(self.sd, x, timestep, y)

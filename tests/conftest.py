@@ -30,6 +30,26 @@ def seeded_sd():
     return synthetic.seeded_state_dict(m.state_dict(), 0)
 
 
+@pytest.fixture(scope="session")
+def vgolden():
+    """Golden vectors of the SAR->NDVI / generation variants (tools/make_golden_variants.py)."""
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "variants_golden.npz")))
+
+
+@pytest.fixture(scope="session")
+def seeded_sd_sar():
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.UNet_model_SAR_TO_NDVI import Residual_Attention_UNet_SAR_TO_NDVI
+    return synthetic.seeded_state_dict(Residual_Attention_UNet_SAR_TO_NDVI(2, 1, "cpu").state_dict(), 0)
+
+
+@pytest.fixture(scope="session")
+def seeded_sd_gen():
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.generate_new_imgs.UNet_model_generation import Residual_Attention_UNet_generation
+    return synthetic.seeded_state_dict(Residual_Attention_UNet_generation(3, 3, 10, "cpu").state_dict(), 0)
+
+
 def golden_inputs(tag, B, Bl, C, S, mag, T, seed=0):
     from diffusionremotesensing_amd import synthetic
     x = synthetic.tensor_normal(f"{tag}.x", (B, C, S, S), seed)
