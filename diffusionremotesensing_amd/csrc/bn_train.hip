@@ -102,7 +102,9 @@ int drs_launch_bn_train(const float* z, int z_cs, int z_co, long long npix, long
   DRS_CHECK_HIP(hipMemsetAsync(sums_scratch, 0, 2 * (size_t)C * sizeof(double), s));
   const int rows = 256 / (C >> 2);
   long long blocks = (npix + rows - 1) / rows;
-  if (blocks > 2048) blocks = 2048;
+  // every block ends with 2*C fp64 atomics on the same 2*C addresses: 2048 blocks made those the whole cost (182 us
+  // at any size); 512 blocks still cover the chip twice
+  if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, npix, C, z_cs, z_co, sums_scratch);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_scratch, npix, C, eps, momentum, mean,

@@ -5,7 +5,8 @@
 // per tap as float4s.
 #include "drs_common.h"
 
-template <int COT>
+// MASK: Cout is not a multiple of COT (2 or 3 output channels in a 4-wide tile): out-of-range columns are skipped.
+template <int COT, bool MASK = (COT == 1)>
 __global__ __launch_bounds__(256) void tapconv_direct_kernel(TapConv d) {
   const int64_t P = (int64_t)d.N * d.TH * d.TW;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void tapconv_direct_kernel(TapConv d) {
           const float* wr = wp + (int64_t)(ci + q) * d.Cout;
 #pragma unroll
           for (int j = 0; j < COT; ++j)
-            if (COT > 1 || co0 + j < d.Cout) acc[j] = fmaf(av[q], wr[j], acc[j]);
+            if (!MASK || co0 + j < d.Cout) acc[j] = fmaf(av[q], wr[j], acc[j]);
         }
       }
     } else {
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256) void tapconv_direct_kernel(TapConv d) {
         if (addp) a += addp[ci];
         const float* wr = wp + (int64_t)ci * d.Cout;
 #pragma unroll
-        for (int j = 0; j < COT; ++j) acc[j] = fmaf(a, wr[j], acc[j]);
+        for (int j = 0; j < COT; ++j)
+          if (!MASK || co0 + j < d.Cout) acc[j] = fmaf(a, wr[j], acc[j]);
       }
     }
   }
@@ -92,6 +94,9 @@ int drs_launch_tapconv_direct(const TapConv& d, hipStream_t s) {
   } else if (d.Cout % 4 == 0) {
     dim3 grid((unsigned)((P + 255) / 256), d.Cout / 4);
     hipLaunchKernelGGL(tapconv_direct_kernel<4>, grid, block, 0, s, d);
+  } else if (d.Cout > 1 && d.Cout < 4) {  // image-channel outputs (2, 3): one pass over the input instead of Cout
+    dim3 grid((unsigned)((P + 255) / 256), 1);
+    hipLaunchKernelGGL((tapconv_direct_kernel<4, true>), grid, block, 0, s, d);
   } else {
     dim3 grid((unsigned)((P + 255) / 256), d.Cout);
     hipLaunchKernelGGL(tapconv_direct_kernel<1>, grid, block, 0, s, d);

@@ -620,7 +620,9 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
                                       char* __restrict__ dst_w, float* __restrict__ dst_b, int Cout, int Cin, int taps,
-                                      int transposed, int nchunks, size_t image_bytes) {
+                                      int transposed, int nchunks, size_t image_bytes, int cout_src) {
+  // cout_src < Cout: the source has only cout_src output channels; the rest of the image is zero (a 16-channel
+  // output padded to the kernel's 32-channel tile)
   constexpr int KC = 4 * P::SLOT_CH;
   const size_t nslots = (size_t)nchunks * taps * 4 * Cout;
   for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (size_t)gridDim.x * blockDim.x) {
@@ -635,8 +637,8 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
     for (int j = 0; j < P::SLOT_CH; ++j) {
       const int ci = c * KC + q * P::SLOT_CH + j;
       float v = 0.f;
-      if (ci < Cin) {
-        const size_t src = transposed ? (((size_t)ci * Cout + co) * taps + tap) : (((size_t)co * Cin + ci) * taps + tap);
+      if (ci < Cin && co < cout_src) {
+        const size_t src = transposed ? (((size_t)ci * cout_src + co) * taps + tap) : (((size_t)co * Cin + ci) * taps + tap);
         v = w[src];
         if (gamma) v *= sc;
       }
@@ -646,7 +648,7 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
   }
   if (blockIdx.x == 0) {
     for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
-      float bb = b ? b[co] : 0.f;
+      float bb = (b && co < cout_src) ? b[co] : 0.f;
       if (gamma) {
         const float sc = gamma[co] / sqrtf(rvar[co] + eps);
         bb = (bb - rmean[co]) * sc + beta[co];
@@ -663,7 +665,8 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl) {
 
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
-                              int transposed, int impl, hipStream_t s) {
+                              int transposed, int impl, hipStream_t s, int cout_src) {
+  if (cout_src <= 0) cout_src = Cout;
   const int KC = 4 * slot_ch(impl);
   const int nchunks = drs_cdiv(Cin, KC);
   const size_t image = (size_t)nchunks * taps * 4 * Cout * 16;
@@ -673,7 +676,7 @@ int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma
   if (blocks < 1) blocks = 1;
 #define DRS_PACK(P)                                                                                                   \
   hipLaunchKernelGGL(pack_conv_mfma_kernel<P>, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps,    \
-                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image)
+                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src)
   if (impl == DRS_IMPL_MFMA_F32) DRS_PACK(PolicyF32);
   else if (impl == DRS_IMPL_MFMA_F16) DRS_PACK(PolicyF16);
   else DRS_PACK(PolicyBF16X3);

@@ -101,7 +101,7 @@ int drs_launch_pack_conv(const float* w, const float* b, const float* gamma, con
 size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl);
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
-                              int transposed, int impl, hipStream_t s);
+                              int transposed, int impl, hipStream_t s, int cout_src = 0);
 
 int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
                             hipStream_t s);
@@ -136,8 +136,12 @@ struct WgradDesc {
   const float* a_add; int a_add_cs;
   const float* a_gate;
   float* dW; int T_total; int wtap[DRS_MAX_TAPS]; int out_transposed;
+  float* partial; size_t partial_bytes;  // workspace of the MFMA path (null: direct fp32 kernel)
+  float* dbias;  // convolution form only: also accumulate sum over positions of B[., b] (the bias gradient)
 };
 int drs_launch_wgrad(const WgradDesc& d, hipStream_t s);
+bool drs_wgrad_mfma_supported(const WgradDesc& d);
+int drs_launch_wgrad_mfma(const WgradDesc& d, float* partial, size_t partial_bytes, hipStream_t s);
 int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, long long pix_per_image, int per_image,
                       int out_stride, float* out, hipStream_t s);
 int drs_launch_relu_mask(float* g, int g_cs, int g_co, const float* y, int y_cs, int y_co, int C, long long npix,

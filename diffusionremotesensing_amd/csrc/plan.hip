@@ -2,6 +2,8 @@
 // whole-UNet plan (weight packing + the launch schedule of one eval forward).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -261,7 +263,7 @@ struct drs_plan {
   // train plans: gradients of activations and channels-last copies of the 3-channel tensors (backward only)
   int g_out = -1, g_X[3], g_CAT[3], g_U[3], g_G[3], g_P[3], g_PSI[3], g_E[3], g_R[4], g_D[3], g_H[4], g_x0 = -1;
   int t_xn = -1, t_upn = -1, g_upn = -1, g_lr[4], t_rn[4], t_an[3];
-  size_t o_dtemb = 0, o_scratch = 0;
+  size_t o_dtemb = 0, o_scratch = 0, o_wgrad = 0;
 
   int P(const std::string& name, int64_t numel) {
     params.push_back({name, numel});
@@ -314,6 +316,7 @@ struct drs_plan {
   float* tp(void* ws, int i) const { return (float*)((char*)ws + tensors[i].off); }
 };
 
+static const size_t kWgradPartialBytes = 64ull << 20;
 static const int kDown[5] = {16, 32, 64, 128, 256};
 static const int kUp[5] = {256, 128, 64, 32, 16};
 
@@ -504,8 +507,9 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
   if (cfg->flags & DRS_PLAN_TRAIN) {
     p->o_dtemb = ws; ws += align_up((size_t)B * p->temb_total * 4);
     p->o_scratch = ws; ws += align_up(64 * 1024);
+    p->o_wgrad = ws; ws += align_up(kWgradPartialBytes);  // partial dW slices of the MFMA weight-gradient kernel
     p->g_out = p->T("grad.out", ws, B, cfg->out_dim, H, W);
-    p->g_x0 = p->T("grad.x0", ws, B, kDown[0], H, W);
+    p->g_x0 = p->T("grad.x0", ws, B, 32, H, W);  // 16 channels at a 32-float pixel stride (train_bwd.inc: kGx0Stride)
     p->t_xn = p->T("x.nhwc", ws, B, C, H, W);
     p->t_upn = p->T("upsampled_lr_img.nhwc", ws, B, CCw, H, W);
     p->g_upn = p->T("grad.upsampled_lr_img", ws, B, CCw, H, W);

@@ -82,6 +82,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradDesc d, int chunk) {
 int drs_launch_wgrad(const WgradDesc& d, hipStream_t s) {
   const long long P = (long long)d.N * d.TH * d.TW;
   if (P == 0) return DRS_OK;
+  if (d.partial && drs_wgrad_mfma_supported(d)) return drs_launch_wgrad_mfma(d, d.partial, d.partial_bytes, s);
+  if (d.dbias) {  // the direct kernel has no fused bias gradient
+    int rc = drs_launch_colsum(d.B, d.b_cs, d.b_co, d.Cb, (long long)d.N * d.BH * d.BW, (long long)d.BH * d.BW, 0, 0, d.dbias, s);
+    if (rc) return rc;
+  }
   const int tiles = ((d.Ca + 63) / 64) * ((d.Cb + 63) / 64);
   // enough position chunks to fill the chip (~2048 blocks in all), at least 256 positions each
   long long chunks = 2048 / ((long long)d.ntaps * tiles);
@@ -122,14 +127,60 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ t
     __syncthreads();
   }
 }
+// float4 variant (C, cs, co multiples of 4; C <= 1024): thread = (pixel row, channel quad), 4 independent loads in flight
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ t, int cs, int co, int C, long long npix,
+                                                      long long pix_per_image, int per_image, int out_stride,
+                                                      float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[256][4];
+  const int qn = C >> 2;
+  const int rows = 256 / qn;
+  const int q = threadIdx.x % qn, row = threadIdx.x / qn;
+  const long long p_begin = (long long)blockIdx.x * rows_per_block;
+  const long long p_end = min(npix, p_begin + rows_per_block);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) {
+    const float* base = t + co + q * 4;
+    long long p = p_begin + row;
+    for (; p + 3LL * rows < p_end; p += 4LL * rows) {
+      const float4 a = *reinterpret_cast<const float4*>(base + p * cs);
+      const float4 b = *reinterpret_cast<const float4*>(base + (p + rows) * cs);
+      const float4 c2 = *reinterpret_cast<const float4*>(base + (p + 2LL * rows) * cs);
+      const float4 d = *reinterpret_cast<const float4*>(base + (p + 3LL * rows) * cs);
+      s[0] += (a.x + b.x) + (c2.x + d.x); s[1] += (a.y + b.y) + (c2.y + d.y);
+      s[2] += (a.z + b.z) + (c2.z + d.z); s[3] += (a.w + b.w) + (c2.w + d.w);
+    }
+    for (; p < p_end; p += rows) {
+      const float4 a = *reinterpret_cast<const float4*>(base + p * cs);
+      s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < qn) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = 0.f;
+      for (int r = 0; r < rows; ++r) v += red[r * qn + threadIdx.x][j];
+      const long long n = per_image ? p_begin / pix_per_image : 0;
+      atomicAdd(&out[n * out_stride + threadIdx.x * 4 + j], v);
+    }
+  }
+}
 int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, long long pix_per_image, int per_image,
                       int out_stride, float* out, hipStream_t s) {
   if (npix == 0) return DRS_OK;
-  long long rpb = 1024;
+  long long rpb = 2048;
   if (per_image) {  // blocks must not straddle images
     while (pix_per_image % rpb) rpb >>= 1;
   }
   const long long blocks = (npix + rpb - 1) / rpb;
+  if (C % 4 == 0 && cs % 4 == 0 && co % 4 == 0 && C <= 1024 && 256 % (C >> 2) == 0) {
+    hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, cs, co, C, npix, pix_per_image, per_image,
+                       out_stride, out, (int)rpb);
+    DRS_CHECK_HIP(hipGetLastError());
+    return DRS_OK;
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, cs, co, C, npix, pix_per_image, per_image,
                      out_stride, out, (int)rpb);
   DRS_CHECK_HIP(hipGetLastError());
@@ -243,7 +294,7 @@ int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float*
   DRS_CHECK_HIP(hipMemsetAsync(sums_scratch, 0, 2 * (size_t)C * sizeof(double), s));
   if (C <= 256) {
     const int rows = 256 / C;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid1d(npix, rows, 2048)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid1d(npix, rows, 512)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
                        gamma, beta, relu_pre, C, npix, sums_scratch);
   } else {
     DrsErr::set("bn_bwd: C > 256 not needed by this network");
@@ -340,7 +391,8 @@ int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre
 
 // ---------------------------------------------------------------------------------------------------------------
 // Time-embedding MLP backward (reference :143-151,:161): out = relu(W2 silu(W1 e + b1) + b2), e = posenc(t) (constant).
-// One block per MLP; loops over the batch.  dtemb = gradient w.r.t. out (already summed over pixels by the caller).
+// dim/8 blocks per MLP, each owning 8 rows of every gradient; loops over the batch.  dtemb = gradient w.r.t. out
+// (already summed over pixels by the caller).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __restrict__ t,
                                                            const float* __restrict__ inv_freq,
@@ -352,51 +404,83 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
                                                            const float* __restrict__ label_emb,
                                                            const long long* __restrict__ labels, int label_batch,
                                                            float* __restrict__ dlabel) {
-  __shared__ float e[100], pre1[256], h1[256], d2[256], dpre1[256];
+  // Block `blockIdx.x` owns rows [r0, r0 + RB) of dW2 / db2 (index c) and of dW1 / db1 (index k): it re-derives the
+  // cheap per-sample vectors (e, pre1, h1, d2: dim x 100 MACs) and keeps its rows' sums over the batch in registers.
+  constexpr int RB = 8;
+  __shared__ float e[100], pre1[256], h1[256], d2[256], dpre1[RB];
+  const int r0 = blockIdx.x * RB;
+  const int tid = threadIdx.x;
+  float acc2[RB], acc1[RB], accb2 = 0.f, accb1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) acc2[r] = acc1[r] = 0.f;
   for (int b = 0; b < B; ++b) {
     const float tf = (float)t[b];
     const long long lab = labels ? labels[label_batch == 1 ? 0 : b] : 0;
-    for (int j = threadIdx.x; j < 50; j += blockDim.x) {
-      const float arg = tf * inv_freq[j];
-      e[j] = sinf(arg);
-      e[50 + j] = cosf(arg);
+    if (tid < 50) {
+      const float arg = tf * inv_freq[tid];
+      e[tid] = sinf(arg);
+      e[50 + tid] = cosf(arg);
     }
     __syncthreads();
     if (labels) {  // e = posenc(t) + label_emb[y] (generation variant)
-      for (int j = threadIdx.x; j < 100; j += blockDim.x) e[j] += label_emb[lab * 100 + j];
+      if (tid < 100) e[tid] += label_emb[lab * 100 + tid];
       __syncthreads();
     }
-    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-      float a = b1[c];
-      for (int k = 0; k < 100; ++k) a = fmaf(W1[(size_t)c * 100 + k], e[k], a);
-      pre1[c] = a;
-      h1[c] = a / (1.f + expf(-a));
-      d2[c] = temb[(size_t)b * stride + c] > 0.f ? dtemb[(size_t)b * stride + c] : 0.f;  // ReLU mask
+    if (tid < dim) {
+      float a = b1[tid];
+      for (int k = 0; k < 100; ++k) a = fmaf(W1[(size_t)tid * 100 + k], e[k], a);
+      pre1[tid] = a;
+      h1[tid] = a / (1.f + expf(-a));
+      d2[tid] = temb[(size_t)b * stride + tid] > 0.f ? dtemb[(size_t)b * stride + tid] : 0.f;  // ReLU mask
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-      db2[c] += d2[c];  // one block owns this MLP: plain read-modify-write
-      for (int k = 0; k < dim; ++k) dW2[(size_t)c * dim + k] += d2[c] * h1[k];
-    }
-    for (int k = threadIdx.x; k < dim; k += blockDim.x) {
+    {  // dpre1[k] = silu'(pre1[k]) * sum_c W2[c][k] d2[c] for this block's RB rows k: 32 lanes per row
+      const int rr = tid >> 5, l = tid & 31, k = r0 + rr;
       float dh = 0.f;
-      for (int c = 0; c < dim; ++c) dh = fmaf(W2[(size_t)c * dim + k], d2[c], dh);
-      const float sg = 1.f / (1.f + expf(-pre1[k]));
-      dpre1[k] = dh * (sg * (1.f + pre1[k] * (1.f - sg)));  // d silu
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < dim; k += blockDim.x) {
-      db1[k] += dpre1[k];
-      for (int j = 0; j < 100; ++j) dW1[(size_t)k * 100 + j] += dpre1[k] * e[j];
-    }
-    if (dlabel)  // d e = W1^T dpre1 lands on the embedding row of this sample's class (MLPs run back to back on
-                 // one stream and one block: plain read-modify-write)
-      for (int j = threadIdx.x; j < 100; j += blockDim.x) {
-        float a = 0.f;
-        for (int k = 0; k < dim; ++k) a = fmaf(W1[(size_t)k * 100 + j], dpre1[k], a);
-        dlabel[lab * 100 + j] += a;
+      if (k < dim)
+        for (int c = l; c < dim; c += 32) dh = fmaf(W2[(size_t)c * dim + k], d2[c], dh);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) dh += __shfl_xor(dh, o, 32);
+      if (l == 0) {
+        float v = 0.f;
+        if (k < dim) {
+          const float sg = 1.f / (1.f + expf(-pre1[k]));
+          v = dh * (sg * (1.f + pre1[k] * (1.f - sg)));  // d silu
+        }
+        dpre1[rr] = v;
       }
+    }
     __syncthreads();
+    if (tid < dim) {
+#pragma unroll
+      for (int r = 0; r < RB; ++r) acc2[r] = fmaf(r0 + r < dim ? d2[r0 + r] : 0.f, h1[tid], acc2[r]);
+    }
+    if (tid < 100) {
+#pragma unroll
+      for (int r = 0; r < RB; ++r) acc1[r] = fmaf(dpre1[r], e[tid], acc1[r]);
+      if (dlabel) {  // d e = W1^T dpre1: this block's RB rows of the sum, onto the embedding row of the sample's class
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          if (r0 + r < dim) a = fmaf(W1[(size_t)(r0 + r) * 100 + tid], dpre1[r], a);
+        atomicAdd(&dlabel[lab * 100 + tid], a);
+      }
+    }
+    if (tid >= 128 && tid < 128 + RB) {
+      const int r = tid - 128;
+      if (r0 + r < dim) { accb2 += d2[r0 + r]; accb1 += dpre1[r]; }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    if (r0 + r >= dim) break;
+    if (tid < dim) dW2[(size_t)(r0 + r) * dim + tid] += acc2[r];
+    if (tid < 100) dW1[(size_t)(r0 + r) * 100 + tid] += acc1[r];
+  }
+  if (tid >= 128 && tid < 128 + RB && r0 + tid - 128 < dim) {
+    db2[r0 + tid - 128] += accb2;
+    db1[r0 + tid - 128] += accb1;
   }
 }
 int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
@@ -404,7 +488,7 @@ int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const flo
                             float* dW2, float* db2, const float* label_emb, const long long* labels, int label_batch,
                             float* dlabel, hipStream_t s) {
   DRS_REQUIRE(dim <= 256, DRS_ERR_SHAPE, "time_mlp_bwd: dim=%d", dim);
-  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, t, inv_freq, W1, b1, W2, temb, dtemb, stride, B, dim, dW1,
+  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3((dim + 7) / 8), dim3(256), 0, s, t, inv_freq, W1, b1, W2, temb, dtemb, stride, B, dim, dW1,
                      db1, dW2, db2, label_emb, labels, label_batch, dlabel);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;

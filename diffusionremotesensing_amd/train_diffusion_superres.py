@@ -174,7 +174,10 @@ class Diffusion:
     def train_step(self, model, optimizer, loss_function, lr_img, hr_img, ema=None, ema_model=None):
         """Loop body of reference :379-396 (called `train_step` in BASELINE.json's north_star)."""
         lr_img, hr_img = self._split_batch((lr_img, hr_img))
-        t = self.sample_timesteps(hr_img.shape[0]).to(self.device)
+        # same CPU-generator draw as the reference (:384); pinned + non_blocking so that the copy does not make the host
+        # wait for the previous step's kernels (a pageable .to(device) is a full synchronisation point)
+        t = self.sample_timesteps(hr_img.shape[0])
+        t = (t.pin_memory() if not t.is_cuda else t).to(self.device, non_blocking=True)
         x_t, noise = self.noise_images(hr_img, t)
         optimizer.zero_grad()
         predicted_noise = self._predict(model, x_t, t, self._train_cond(lr_img))
