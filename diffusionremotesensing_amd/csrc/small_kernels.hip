@@ -357,8 +357,9 @@ __global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __re
   }
   __syncthreads();
   if (labels) {  // class-conditional generation: t += label_emb(y) (reference UNet_model_generation.py:300-301)
-    const float* le = label_emb + (size_t)labels[label_batch == 1 ? 0 : b] * dim_in;
-    for (int j = threadIdx.x; j < dim_in; j += blockDim.x) e[j] += le[j];
+    const long long lab = labels[label_batch == 1 ? 0 : b];  // < 0: this row runs unconditionally (no embedding)
+    if (lab >= 0)
+      for (int j = threadIdx.x; j < dim_in; j += blockDim.x) e[j] += label_emb[(size_t)lab * dim_in + j];
     __syncthreads();
   }
   for (int c = threadIdx.x; c < dim_out; c += blockDim.x) {
@@ -446,6 +447,79 @@ extern "C" int drs_sampler_step(float* x, const float* eps_pred, const float* no
   if (numel <= 0) return DRS_OK;
   hipLaunchKernelGGL(sampler_step_tab_kernel, dim3(ew_blocks(numel)), dim3(256), 0, (hipStream_t)stream, x, eps_pred,
                      noise, t, alpha, alpha_hat, beta, numel);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+__global__ void sampler_step_cfg_kernel(float* __restrict__ x, const float* __restrict__ ec,
+                                        const float* __restrict__ eu, float w, const float* __restrict__ noise, int t,
+                                        const float* __restrict__ alpha, const float* __restrict__ alpha_hat,
+                                        const float* __restrict__ beta, int64_t numel) {
+  const float a = alpha[t], ah = alpha_hat[t], b = beta[t];
+  // same operations, in the same order and without fused multiply-adds, as the reference expressions
+  // (train_diffusion_generation.py:239 torch.lerp, :249 the update)
+  const float c_inv = __fdiv_rn(1.f, sqrtf(a));
+  const float c_eps = __fdiv_rn(__fsub_rn(1.f, a), sqrtf(__fsub_rn(1.f, ah)));
+  const float c_sig = sqrtf(b);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const float s = eu[i], e = ec[i], d = __fsub_rn(e, s);
+    // torch.lerp(start = uncond, end = cond, w): |w| < 0.5 ? fma(w, diff, start) : end - diff * (1 - w)
+    const float eps = fabsf(w) < 0.5f ? fmaf(w, d, s) : __fsub_rn(e, __fmul_rn(d, __fsub_rn(1.f, w)));
+    float v = __fmul_rn(c_inv, __fsub_rn(x[i], __fmul_rn(c_eps, eps)));
+    if (noise) v = __fadd_rn(v, __fmul_rn(c_sig, noise[i]));
+    x[i] = v;
+  }
+}
+extern "C" int drs_sampler_step_cfg(float* x, const float* eps_cond, const float* eps_uncond, float cfg_scale,
+                                    const float* noise, int t, const float* alpha, const float* alpha_hat,
+                                    const float* beta, int noise_steps, int64_t numel, drs_stream_t stream) {
+  DRS_REQUIRE(x && eps_cond && eps_uncond && alpha && alpha_hat && beta, DRS_ERR_ARG, "sampler_step_cfg: null pointer");
+  DRS_REQUIRE(t >= 0 && t < noise_steps, DRS_ERR_ARG, "sampler_step_cfg: t=%d outside [0,%d)", t, noise_steps);
+  if (numel <= 0) return DRS_OK;
+  hipLaunchKernelGGL(sampler_step_cfg_kernel, dim3(ew_blocks(numel)), dim3(256), 0, (hipStream_t)stream, x, eps_cond,
+                     eps_uncond, cfg_scale, noise, t, alpha, alpha_hat, beta, numel);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// Gaussian-weighted tile blend (Aggregation_Sampling.py:90-116): one thread per output pixel gathers, in tile order,
+// every tile that covers it: the same sequential fp32 sums as the reference's `im_res[...] += patch * weight` loop,
+// then the division and the clamp, in one pass and without the two full-size accumulators.
+__global__ void aggregate_tiles_kernel(const float* __restrict__ tiles, const int* __restrict__ origins,
+                                       const float* __restrict__ weight, float* __restrict__ out,
+                                       int* __restrict__ uncovered, int n, int C, int S, int H, int W) {
+  const int64_t hw = (int64_t)H * W;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / W), x = (int)(p % W);
+    float cnt = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      cnt = 0.f;
+      acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const int ly = y - origins[2 * i], lx = x - origins[2 * i + 1];
+        if (ly < 0 || ly >= S || lx < 0 || lx >= S) continue;
+        const float w = weight[ly * S + lx];
+        cnt = __fadd_rn(cnt, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + j < C) acc[j] = __fadd_rn(acc[j], __fmul_rn(tiles[(((int64_t)i * C + c0 + j) * S + ly) * S + lx], w));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < C) out[(int64_t)(c0 + j) * hw + p] = fminf(fmaxf(__fdiv_rn(acc[j], cnt), 0.f), 1.f);
+    }
+    if (cnt == 0.f && uncovered) atomicAdd(uncovered, 1);
+  }
+}
+extern "C" int drs_aggregate_tiles(const float* tiles, const int32_t* origins, const float* weight, float* out,
+                                   int32_t* uncovered, int n, int C, int S, int H, int W, drs_stream_t stream) {
+  DRS_REQUIRE(tiles && origins && weight && out, DRS_ERR_ARG, "aggregate_tiles: null pointer");
+  DRS_REQUIRE(n >= 1 && C >= 1 && S >= 1 && H >= S && W >= S, DRS_ERR_SHAPE, "aggregate_tiles: n=%d C=%d S=%d H=%d W=%d", n,
+              C, S, H, W);
+  if (uncovered) DRS_CHECK_HIP(hipMemsetAsync(uncovered, 0, sizeof(int32_t), (hipStream_t)stream));
+  hipLaunchKernelGGL(aggregate_tiles_kernel, dim3(ew_blocks((int64_t)H * W)), dim3(256), 0, (hipStream_t)stream, tiles,
+                     origins, weight, out, uncovered, n, C, S, H, W);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
     }
     __syncthreads();
     if (labels) {  // e = posenc(t) + label_emb[y] (generation variant)
-      if (tid < 100) e[tid] += label_emb[lab * 100 + tid];
+      if (tid < 100 && lab >= 0) e[tid] += label_emb[lab * 100 + tid];
       __syncthreads();
     }
     if (tid < dim) {
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
     if (tid < 100) {
 #pragma unroll
       for (int r = 0; r < RB; ++r) acc1[r] = fmaf(dpre1[r], e[tid], acc1[r]);
-      if (dlabel) {  // d e = W1^T dpre1: this block's RB rows of the sum, onto the embedding row of the sample's class
+      if (dlabel && lab >= 0) {  // d e = W1^T dpre1: this block's RB rows of the sum, onto the embedding row of the sample's class
         float a = 0.f;
 #pragma unroll
         for (int r = 0; r < RB; ++r)

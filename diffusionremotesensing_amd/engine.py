@@ -168,6 +168,7 @@ class HipUNetEngine:
             labels = labels.to(torch.int64).contiguous()
             if labels.shape not in ((B,), (1,)):
                 raise RuntimeError(f"labels must have shape ({B},) or (1,), got {tuple(labels.shape)}")
+            # (values: class ids in [0, num_classes); -1 marks a row that runs unconditionally)
         x = x.contiguous()
         if has_cond:
             lr_img = lr_img.contiguous()

@@ -119,3 +119,42 @@ def sampler_step_(x, eps_pred, noise, t, alpha, alpha_hat, beta):
                                   _ptr(beta), alpha.numel(), x.numel(), _stream(x.device))
     _lib.check(st, "drs_sampler_step")
     return x
+
+
+def sampler_step_cfg_(x, eps_cond, eps_uncond, cfg_scale, noise, t, alpha, alpha_hat, beta):
+    """In-place ancestral update with eps = torch.lerp(eps_uncond, eps_cond, cfg_scale) folded in
+    (reference generate_new_imgs/train_diffusion_generation.py:236-249)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
+        raise RuntimeError("sampler_step_cfg_: x must be a contiguous fp32 ROCm tensor (no CPU fallback)")
+    eps_cond = _req(eps_cond, "eps_cond")
+    eps_uncond = _req(eps_uncond, "eps_uncond")
+    noise = _req(noise, "noise") if noise is not None else None
+    with torch.cuda.device(x.device):
+        st = lib.drs_sampler_step_cfg(_ptr(x), _ptr(eps_cond), _ptr(eps_uncond), float(cfg_scale), _ptr(noise), int(t),
+                                      _ptr(alpha), _ptr(alpha_hat), _ptr(beta), alpha.numel(), x.numel(),
+                                      _stream(x.device))
+    _lib.check(st, "drs_sampler_step_cfg")
+    return x
+
+
+def aggregate_tiles(tiles, origins, weight, height, width):
+    """Gaussian-weighted blend of (n,C,S,S) tiles placed at `origins` [(y0, x0), ...] into a (C,height,width) image,
+    normalised by the summed weights and clamped to [0,1] (reference Aggregation_Sampling.py:90-116).
+    Raises like the reference's `assert torch.all(pixel_count != 0)` when a pixel is covered by no tile."""
+    lib = _lib.load()
+    tiles = _req(tiles, "tiles")
+    weight = _req(weight, "weight")
+    n, C, S, S2 = tiles.shape
+    if S != S2 or tuple(weight.shape) != (S, S) or len(origins) != n:
+        raise RuntimeError(f"aggregate_tiles: tiles {tuple(tiles.shape)}, weight {tuple(weight.shape)}, {len(origins)} origins")
+    org = torch.tensor([[int(y), int(x)] for y, x in origins], dtype=torch.int32).to(tiles.device)
+    out = torch.empty((C, int(height), int(width)), dtype=torch.float32, device=tiles.device)
+    uncovered = torch.zeros(1, dtype=torch.int32, device=tiles.device)
+    with torch.cuda.device(tiles.device):
+        st = lib.drs_aggregate_tiles(_ptr(tiles), _ptr(org), _ptr(weight), _ptr(out), _ptr(uncovered), n, C, S,
+                                     int(height), int(width), _stream(tiles.device))
+    _lib.check(st, "drs_aggregate_tiles")
+    if int(uncovered.item()) != 0:
+        raise AssertionError("aggregation: some output pixels are covered by no tile (pixel_count == 0)")
+    return out

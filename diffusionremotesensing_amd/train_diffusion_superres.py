@@ -87,7 +87,14 @@ class Diffusion:
         instead of torch.randn — used to drive this sampler and the oracle with identical noise."""
         if self.Degradation_type.lower() not in _DEGRADATIONS:
             raise ValueError("The degradation type must be either BSRGAN or DownBlur")
-        lr_img = lr_img.to(self.device).unsqueeze(0).contiguous()
+        if lr_img.dim() == 4:
+            # extension used by the aggregation tiler: one LR image per chain, (n, C, h, w); the reference only takes a
+            # single (C, h, w) image broadcast over the n chains (:224)
+            if lr_img.shape[0] != n:
+                raise RuntimeError(f"sample: a batch of {lr_img.shape[0]} LR images for n={n} chains")
+            lr_img = lr_img.to(self.device).contiguous()
+        else:
+            lr_img = lr_img.to(self.device).unsqueeze(0).contiguous()
         frames = []
         net = model.module if hasattr(model, "module") and not hasattr(model, "hip_engine") else model
         model.eval()

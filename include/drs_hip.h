@@ -67,6 +67,23 @@ int drs_sampler_step(float* x, const float* eps_pred, const float* noise, int t,
                      const float* alpha_hat, const float* beta, int noise_steps, int64_t numel,
                      drs_stream_t stream);
 
+/* Same update with classifier-free guidance folded in: eps = lerp(eps_uncond, eps_cond, cfg_scale) with torch.lerp's
+ * formula (weight >= 0.5: end - (end - start) * (1 - weight)), then the ancestral update above.
+ * Replaces generate_new_imgs/train_diffusion_generation.py:236-249. */
+int drs_sampler_step_cfg(float* x, const float* eps_cond, const float* eps_uncond, float cfg_scale, const float* noise,
+                         int t, const float* alpha, const float* alpha_hat, const float* beta, int noise_steps,
+                         int64_t numel, drs_stream_t stream);
+
+/* Gaussian-weighted blend of n overlapping super-resolved tiles into one image, normalised and clamped to [0,1]:
+ *   out[c][y][x] = clamp( sum_i w[y-y0_i][x-x0_i] * tiles[i][c][y-y0_i][x-x0_i] / sum_i w[y-y0_i][x-x0_i], 0, 1 )
+ * over the tiles i (in index order, like the reference's sequential `+=`) whose window [y0_i, y0_i+S) x [x0_i, x0_i+S)
+ * contains (y, x).  tiles: (n,C,S,S); origins: n x 2 int32 (y0, x0) on the device; weight: (S,S); out: (C,H,W).
+ * Returns DRS_ERR_SHAPE through `uncovered` (device int, may be NULL) != 0 semantics: the count of output pixels no
+ * tile covers is written there (the reference asserts pixel_count != 0).
+ * Replaces the loop + normalisation of split_aggregation_sampling.aggregation_sampling, Aggregation_Sampling.py:90-116. */
+int drs_aggregate_tiles(const float* tiles, const int32_t* origins, const float* weight, float* out, int32_t* uncovered,
+                        int n, int C, int S, int H, int W, drs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (used by the parity tests for every convolution flavour
  * the UNet contains, at arbitrary/ragged shapes)

@@ -56,7 +56,8 @@ def sample(model, n, lr_img, noise_steps, alpha, alpha_hat, beta, magnification_
            noise_source=None, keep_steps=()):
     """Diffusion.sample (:224-255) on CPU.  `noise_source(i, shape)` supplies x_T (i = noise_steps) and z_i; without
     it the draws come from torch's CPU generator in the reference's order (x_T, then one randn_like per step)."""
-    lr = lr_img.unsqueeze(0)
+    # a 4-D lr_img is the tiler's batched form (one LR image per chain): n independent reference chains run as one batch
+    lr = lr_img if lr_img.dim() == 4 else lr_img.unsqueeze(0)
     shape = (n, input_channels, image_size, image_size)
     kept = {}
     with torch.no_grad():

@@ -74,3 +74,19 @@ def replay_noise_source(seed):
     def src(i, shape):
         return torch.randn(shape, generator=gen)
     return src
+
+
+def replay_tile_noise(seed, n_tiles, noise_steps, shape1):
+    """The draws of the reference's tile-after-tile aggregation loop (Aggregation_Sampling.py:92-93 around
+    Diffusion.sample :230,246) from torch's CPU generator: per tile x_T, then z_i for i = T-1 .. 2.
+    Returns noise_source(tile, i, shape) -> (1, C, S, S)."""
+    gen = torch.Generator().manual_seed(seed)
+    draws = {}
+    for ti in range(n_tiles):
+        draws[(ti, noise_steps)] = torch.randn(shape1, generator=gen)
+        for i in reversed(range(2, noise_steps)):
+            draws[(ti, i)] = torch.randn(shape1, generator=gen)
+
+    def src(tile, i, shape):
+        return draws[(tile, i)]
+    return src

@@ -109,7 +109,47 @@ def _case_sharded_sampling(rank, world, out_dir):
     assert torch.equal(local, full[lo:hi])
 
 
+def _tile_noise(tile, i, shape):
+    g = torch.Generator().manual_seed(7000 + 100 * tile + i)
+    return torch.randn(shape, generator=g)
+
+
+def _case_sharded_tiles(rank, world, out_dir):
+    """Aggregation tiler: the tiles of one image are sharded over the ranks and gathered once."""
+    from diffusionremotesensing_amd import dist, synthetic
+    from diffusionremotesensing_amd.Aggregation_Sampling import split_aggregation_sampling
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    sd = synthetic.seeded_state_dict(Residual_Attention_UNet_superres(3, 3, "cpu").state_dict(), 0)
+    diff = _OracleDiffusion(sd, T=3, image_size=16)
+    img = synthetic.tensor_uniform("dist.img", (1, 3, 16, 24))
+    tiler = split_aggregation_sampling(img, 8, 8, 2, diff, "cpu")
+    assert len(tiler.patches_lr) == 6  # 2 x 3 tiles -> 3 per rank
+    tiles = tiler.sample_tiles(noise_source=_tile_noise)
+    assert tiles.shape == (6, 3, 16, 16)
+    torch.save(tiles, os.path.join(out_dir, f"tiles_{rank}.pt"))
+
+
 # ---------------------------------------------------------------------------------------------------------------
+def test_sharded_tiles_match_sequential_reference_loop(tmp_path):
+    """2 ranks x 3 tiles (batched) == the reference's sequential n=1 loop over the 6 tiles (same per-tile noise)."""
+    _run("_case_sharded_tiles", tmp_path)
+    sys.path.insert(0, ROOT)
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    from oracle import aggregation_oracle as A
+    sd = synthetic.seeded_state_dict(Residual_Attention_UNet_superres(3, 3, "cpu").state_dict(), 0)
+    diff = _OracleDiffusion(sd, T=3, image_size=16)
+    img = synthetic.tensor_uniform("dist.img", (1, 3, 16, 24))
+    infos, lr_origins = A.tile_infos(16, 24, 8, 8, 2)
+    seq = torch.cat([diff.sample(1, None, img[0, :, y:y + 8, x:x + 8],
+                                 noise_source=lambda i, shape, ti=ti: _tile_noise(ti, i, shape))
+                     for ti, (y, x) in enumerate(lr_origins)])
+    a = torch.load(os.path.join(tmp_path, "tiles_0.pt"))
+    b = torch.load(os.path.join(tmp_path, "tiles_1.pt"))
+    assert torch.equal(a, b)
+    assert torch.allclose(a, seq, rtol=0, atol=1e-5)
+
+
 def test_shards_and_gather(tmp_path):
     _run("_case_shards_and_gather", tmp_path)
 

@@ -238,3 +238,112 @@ def test_variant_train_loops(dev, seeded_sd_sar, seeded_sd_gen, tmp_path):
                 verbose=False)
         s = torch.load(d.snapshot_path)
         assert len(s["MODEL_STATE"]) == nkeys
+
+
+# ---------------------------------------------------------------------------------------------
+# aggregation sampling tiler and the fused CFG update
+# ---------------------------------------------------------------------------------------------
+def test_aggregate_tiles_kernel(dev):
+    """drs_aggregate_tiles against the oracle's sequential += / divide / clamp on tiles with values around [0, 1]:
+    same operation order, results within 1 ulp (2.4e-7 on [0, 1])."""
+    from diffusionremotesensing_amd import hip_ops, synthetic
+    from oracle import aggregation_oracle as A
+    for (h, w, ps, st, m, C) in ((48, 56, 32, 16, 2, 3), (20, 20, 8, 8, 1, 1), (24, 40, 16, 12, 2, 5)):
+        infos, _ = A.tile_infos(h, w, ps, st, m)
+        S = ps * m
+        tiles = synthetic.tensor_uniform(f"agg.{h}.{w}", (len(infos), C, S, S), 0, -0.5, 1.5)
+        wt = A.gaussian_weight(S, S)
+        want = A.aggregate(tiles, infos, wt, h * m, w * m)[0]
+        got = hip_ops.aggregate_tiles(tiles.to(dev), [(i[0], i[2]) for i in infos], wt.to(dev), h * m, w * m).cpu()
+        assert (got - want).abs().max().item() <= 2.4e-7, (h, w, (got - want).abs().max())
+    with pytest.raises(AssertionError):  # a hole between tiles: the reference asserts pixel_count != 0
+        hip_ops.aggregate_tiles(tiles[:1].to(dev), [(0, 0)], wt.to(dev), 2 * S, 2 * S)
+    with pytest.raises(RuntimeError):
+        hip_ops.aggregate_tiles(tiles, [(0, 0)] * len(infos), wt, 8, 8)  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("impl", ["mfma_f32", "mfma_bf16x3"])
+def test_aggregation_sampling_golden(dev, seeded_sd, vgolden, impl):
+    """split_aggregation_sampling (all tiles as one batched chain) against the imported reference's sequential
+    tile loop (G10) with its noise replayed per tile."""
+    from conftest import replay_tile_noise
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.Aggregation_Sampling import split_aggregation_sampling
+    from diffusionremotesensing_amd.train_diffusion_superres import Diffusion
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    from oracle import aggregation_oracle as A
+    m = Residual_Attention_UNet_superres(3, 3, dev)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    m.hip_engine().set_impl(impl)
+    T = 8
+    d = Diffusion("cosine", m, "/nonexistent/snapshot.pt", noise_steps=T, device=dev, magnification_factor=2,
+                  image_size=64, Degradation_type="DownBlur")
+    img = synthetic.tensor_uniform("g10.img", (1, 3, 48, 56)).to(dev)
+    tiler = split_aggregation_sampling(img, 32, 16, 2, d, dev)
+    assert np_equal(tiler.patches_sr_infos, vgolden["g10_infos"])
+    assert torch.equal(tiler.weight[0, 0].cpu(), torch.from_numpy(vgolden["g10_weight"]))
+    assert tiler.weight.shape == (1, 3, 64, 64)
+    src = replay_tile_noise(1010, len(tiler.patches_lr), T, (1, 3, 64, 64))
+    out = tiler.aggregation_sampling(noise_source=src).cpu()
+    ref = torch.from_numpy(vgolden["g10_result"])
+    assert out.shape == ref.shape
+    # random weights drive most pixels into the clamp; the un-saturated ones carry the numerical comparison
+    mid = (ref > 0) & (ref < 1)
+    assert mid.float().mean() > 0.03
+    tol = 1e-4 if impl == "mfma_f32" else 5e-3
+    assert (out - ref).abs().max().item() <= tol, (out - ref).abs().max().item()
+    # tile level (un-clamped): the batched chain equals the oracle's per-tile chains
+    from oracle import diffusion_oracle as D
+    from oracle import unet_oracle as U
+    a, ah, b = D.schedule("cosine", T)
+    _, lr_origins = A.tile_infos(48, 56, 32, 16, 2)
+    tiles = tiler.sample_tiles(noise_source=src).cpu()
+    y0, x0 = lr_origins[3]
+    want = D.sample(U.OracleUNet(seeded_sd), 1, img[0, :, y0:y0 + 32, x0:x0 + 32].cpu(), T, a, ah, b, 2, 64,
+                    noise_source=lambda i, shape: src(3, i, shape))
+    _assert_close(tiles[3:4], want, 1e-4 if impl == "mfma_f32" else 5e-3, "tile 3")
+
+
+def np_equal(infos, arr):
+    import numpy as np
+    return np.array_equal(np.array(infos, dtype=np.int32), arr)
+
+
+def test_sampler_step_cfg_matches_torch(dev):
+    """drs_sampler_step_cfg == torch.lerp + the reference update expression (train_diffusion_generation.py:239,249)."""
+    from diffusionremotesensing_amd import hip_ops, synthetic
+    from oracle import diffusion_oracle as D
+    a, ah, b = D.schedule("cosine", 50)
+    x = synthetic.tensor_normal("cfg.x", (2, 3, 16, 16))
+    ec = synthetic.tensor_normal("cfg.ec", (2, 3, 16, 16))
+    eu = synthetic.tensor_normal("cfg.eu", (2, 3, 16, 16))
+    z = synthetic.tensor_normal("cfg.z", (2, 3, 16, 16))
+    for w in (3.0, 0.3, 1.0, 7.5):
+        for i, noise in ((17, z), (1, None)):
+            t = (torch.ones(2) * i).long()
+            want = D.sampler_step(x, torch.lerp(eu, ec, w), noise if noise is not None else torch.zeros_like(x), t, a, ah, b)
+            got = hip_ops.sampler_step_cfg_(x.clone().to(dev), ec.to(dev), eu.to(dev), w,
+                                            noise.to(dev) if noise is not None else None, i, a.to(dev), ah.to(dev), b.to(dev))
+            assert torch.allclose(got.cpu(), want, rtol=1e-6, atol=1e-6), (w, i, (got.cpu() - want).abs().max())
+
+
+def test_generation_label_broadcast_and_mixed_rows(dev, seeded_sd_gen):
+    """A (1,) label is broadcast over the batch (reference imgs_generator passes one class for n images); label -1
+    rows run unconditionally inside a conditional batch (what the batched CFG sampler relies on)."""
+    from diffusionremotesensing_amd import synthetic
+    from oracle import unet_oracle as U
+    m = _gen_model(dev, seeded_sd_gen).eval()
+    m.hip_engine().set_impl("mfma_f32")
+    x = synthetic.tensor_normal("lb.x", (3, 3, 32, 32))
+    t = torch.tensor([3, 500, 1200])
+    with torch.no_grad():
+        want = U.unet_forward_generation(seeded_sd_gen, x, t, torch.tensor([4, 4, 4]))
+        got = m(x.to(dev), t.to(dev), torch.tensor([4]).to(dev))
+        _assert_close(got, want, TOL_F32, "label broadcast")
+        wc = U.unet_forward_generation(seeded_sd_gen, x, t, torch.tensor([4, 1, 9]))
+        wu = U.unet_forward_generation(seeded_sd_gen, x, t, None)
+        got = m(x.to(dev), t.to(dev), torch.tensor([4, -1, 9]).to(dev))
+        _assert_close(got[0:1], wc[0:1], TOL_F32, "row 0 conditional")
+        _assert_close(got[1:2], wu[1:2], TOL_F32, "row 1 unconditional")
+        _assert_close(got[2:3], wc[2:3], TOL_F32, "row 2 conditional")

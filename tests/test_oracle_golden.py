@@ -119,3 +119,27 @@ def test_generation_variant(vgolden, seeded_sd_gen):
                                  noise_source=replay_noise_source(seed))
         ref = torch.from_numpy(vgolden[f"g9s_{tag}_x"])
         assert torch.allclose(xs, ref, rtol=0, atol=1e-5 * ref.abs().max().item()), tag
+
+
+def test_aggregation_sampling(vgolden, seeded_sd):
+    """Tile split, Gaussian weights and blend of Aggregation_Sampling.py against what the imported reference class
+    produced around the reference Diffusion.sample (G10), noise replayed in the reference's tile-major order."""
+    from conftest import replay_tile_noise
+    from diffusionremotesensing_amd import synthetic
+    from oracle import aggregation_oracle as A
+    infos, lr_origins = A.tile_infos(48, 56, 32, 16, 2)
+    assert np.array_equal(np.array(infos, dtype=np.int32), vgolden["g10_infos"])
+    w = A.gaussian_weight(64, 64)
+    assert torch.equal(w, torch.from_numpy(vgolden["g10_weight"]))
+    img = synthetic.tensor_uniform("g10.img", (1, 3, 48, 56))
+    T = 8
+    a, ah, b = D.schedule("cosine", T)
+    src = replay_tile_noise(1010, len(infos), T, (1, 3, 64, 64))
+    model = U.OracleUNet(seeded_sd)
+    tiles = []
+    for ti, (y0, x0) in enumerate(lr_origins):
+        lr = img[0, :, y0:y0 + 32, x0:x0 + 32]
+        tiles.append(D.sample(model, 1, lr, T, a, ah, b, 2, 64, noise_source=lambda i, shape, ti=ti: src(ti, i, shape)))
+    out = A.aggregate(torch.cat(tiles), infos, w, 96, 112)
+    ref = torch.from_numpy(vgolden["g10_result"])
+    assert torch.allclose(out, ref, rtol=0, atol=1e-5)
