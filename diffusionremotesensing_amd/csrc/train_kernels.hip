@@ -536,3 +536,41 @@ int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int 
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-tensor Adam (torch.optim.Adam defaults), one launch for all parameters: grid = (chunks of the largest tensor,
+// tensors); blocks beyond a tensor's length exit.  Same operation order as torch's single-tensor implementation.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_multi_kernel(const drs_adam_tensor* __restrict__ table, double lr, double b1d,
+                                                         double b2d, float eps) {
+  const drs_adam_tensor t = table[blockIdx.y];
+  if (!t.g) return;  // no gradient this step: torch skips the parameter (state untouched)
+  // torch forms 1 - beta in Python doubles and rounds the result to fp32 inside the kernels
+  const float beta2 = (float)b2d, w1 = (float)(1.0 - b1d), w2 = (float)(1.0 - b2d);
+  const long long lo = (long long)blockIdx.x * 4096;
+  if (lo >= t.n) return;
+  const long long hi = min(t.n, lo + 4096);
+  // bias corrections in double like torch's Python-side scalars (step_size = lr / bc1, bias_correction2_sqrt)
+  const double bc1 = 1.0 - pow(b1d, (double)t.step), bc2 = 1.0 - pow(b2d, (double)t.step);
+  const float lr_over_bc1 = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float g = t.g[i];
+    float m = t.m[i], v = t.v[i];
+    m = w1 < 0.5f ? fmaf(w1, __fsub_rn(g, m), m) : __fsub_rn(g, __fmul_rn(__fsub_rn(g, m), __fsub_rn(1.f, w1)));  // lerp_
+    v = __fadd_rn(__fmul_rn(v, beta2), __fmul_rn(__fmul_rn(w2, g), g));                                          // mul_, addcmul_
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
+    t.m[i] = m;
+    t.v[i] = v;
+    t.p[i] = __fadd_rn(t.p[i], __fmul_rn(-lr_over_bc1, __fdiv_rn(m, denom)));                                    // addcdiv_
+  }
+}
+extern "C" int drs_adam_multi(const drs_adam_tensor* table, int ntensors, int64_t max_numel, double lr, double beta1,
+                              double beta2, double eps, drs_stream_t stream) {
+  DRS_REQUIRE(table && ntensors >= 0, DRS_ERR_ARG, "adam_multi: bad arguments");
+  if (ntensors == 0 || max_numel <= 0) return DRS_OK;
+  const unsigned gx = (unsigned)((max_numel + 4095) / 4096);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, ntensors), dim3(256), 0, (hipStream_t)stream, table, lr, beta1, beta2,
+                     (float)eps);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}

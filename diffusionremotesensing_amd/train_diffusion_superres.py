@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import dist as drs_dist
 from . import hip_ops
+from .optim import FusedAdam
 from .UNet_model_superres import EMA, Residual_Attention_UNet_superres
 
 _DEGRADATIONS = ("downblur", "bsrgan", "downblurnoise")
@@ -204,7 +205,7 @@ class Diffusion:
 
     def train(self, lr, epochs, check_preds_epoch, train_loader, val_loader, patience, loss, verbose):
         model = self.model
-        optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+        optimizer = FusedAdam(model.parameters(), lr=lr)  # torch.optim.Adam's math, one launch (optim.py)
         ema = ema_model = None
         if self.ema_smoothing:
             ema = EMA(beta=0.995)

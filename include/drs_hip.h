@@ -74,6 +74,23 @@ int drs_sampler_step_cfg(float* x, const float* eps_cond, const float* eps_uncon
                          int t, const float* alpha, const float* alpha_hat, const float* beta, int noise_steps,
                          int64_t numel, drs_stream_t stream);
 
+/* One Adam step over many tensors in ONE launch (torch.optim.Adam defaults: no weight decay, no amsgrad):
+ *   m = lerp(m, g, 1-beta1); v = v*beta2 + (1-beta2)*g*g; p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)
+ * `table` (device): ntensors x drs_adam_tensor {p, g, m, v, n, step}; entries with g == NULL are skipped (parameters
+ * that got no gradient, like torch).  `step` is that tensor's 1-based step count after the increment (torch keeps one
+ * per parameter: a parameter that skipped steps has its own bias correction).
+ * Replaces `optimizer.step()` of torch.optim.Adam in the training loop body, train_diffusion_superres.py:337,393. */
+typedef struct drs_adam_tensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  int64_t step;
+} drs_adam_tensor;
+int drs_adam_multi(const drs_adam_tensor* table, int ntensors, int64_t max_numel, double lr, double beta1, double beta2,
+                   double eps, drs_stream_t stream);
+
 /* Gaussian-weighted blend of n overlapping super-resolved tiles into one image, normalised and clamped to [0,1]:
  *   out[c][y][x] = clamp( sum_i w[y-y0_i][x-x0_i] * tiles[i][c][y-y0_i][x-x0_i] / sum_i w[y-y0_i][x-x0_i], 0, 1 )
  * over the tiles i (in index order, like the reference's sequential `+=`) whose window [y0_i, y0_i+S) x [x0_i, x0_i+S)

@@ -416,3 +416,39 @@ def test_diffusion_train_loop_end_to_end(dev, seeded_sd, tmp_path):
     assert d2.epochs_run == s["EPOCHS_RUN"]
     out = d2.sample(1, m2, ds[0][0], input_channels=3)
     assert out.shape == (1, 3, 32, 32) and torch.isfinite(out).all()
+
+
+def test_fused_adam_matches_torch_adam(dev):
+    """FusedAdam (drs_adam_multi) against torch.optim.Adam (the reference's optimizer, train_diffusion_superres.py:337)
+    over 6 steps on ragged tensors, including a parameter that never gets a gradient and one that skips a step."""
+    from diffusionremotesensing_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(32, 16, 3, 3), (5,), (1,), (257, 100), (3, 3, 3, 3), (70001,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=3e-4)
+    mine = FusedAdam(my_p, lr=3e-4)
+    for step in range(6):
+        for i, (a, b) in enumerate(zip(ref_p, my_p)):
+            if i == 2 or (i == 4 and step == 3):
+                a.grad = None
+                b.grad = None
+                continue
+            g = torch.randn(a.shape) * (10.0 ** (step - 3))
+            a.grad = g.clone()
+            b.grad = g.clone().to(dev)
+        ref.step()
+        mine.step()
+    for a, b in zip(ref_p, my_p):
+        assert torch.allclose(b.detach().cpu(), a.detach(), rtol=2e-6, atol=1e-7), (a.shape, (b.cpu() - a).abs().max())
+    sa, sb = ref.state_dict()["state"], mine.state_dict()["state"]
+    assert set(sa) == set(sb)  # parameter 2 never stepped: no state, like torch
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sb[k]["step"])
+        for name in ("exp_avg", "exp_avg_sq"):  # 1-2 ulp of the largest term (gradients span 6 decades here)
+            a, b = sa[k][name], sb[k][name].cpu()
+            assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item(), (k, name)
+    with pytest.raises(RuntimeError):
+        p = torch.nn.Parameter(torch.zeros(3))
+        p.grad = torch.zeros(3)
+        FusedAdam([p]).step()  # CPU parameter: no fallback
