@@ -197,21 +197,27 @@ __device__ __forceinline__ void fuse_epilogue(const TapConv& d, f32x4 (&acc)[RPW
   }
 }
 
-template <int MODE, int RPW>
+template <int MODE, int RPW, int NWG>
 struct ModeTraits {
   // window slots per thread: generic stride 1 <= 384 px, stride 2 <= 576 px, conv3x3 18x18, convT 9x17
-  static constexpr int A_ITERS = MODE == MODE_CONVT ? 3 : (RPW == 4 ? 6 : 9);
+  static constexpr int A_ITERS = (MODE == MODE_CONV3X3 || MODE == MODE_CONV3X3_FUSE)
+                                     ? ((4 * RPW + 2) * 18 + 64 * NWG - 1) / (64 * NWG)
+                                     : (MODE == MODE_CONVT ? 3 : (RPW == 4 ? 6 : 9)) / NWG;
   static constexpr int NACC = MODE == MODE_CONVT ? 4 : 1;
 };
 
-template <class P, int BN, int RPW, int MODE, bool HAS2>
-__global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeom g) {
+// NWG = 2: 512 threads, two groups of 4 waves share ONE staged input window and each compute their own BN output
+// channels (BNB = 64 per block): half the activation loads / conversions / LDS writes per MFMA for layers with
+// Cout % 64 == 0, at one block per CU (117 KB of LDS).
+template <class P, int BN, int RPW, int MODE, bool HAS2, int NWG>
+__global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KC = 4 * P::SLOT_CH;
   constexpr int TH = 4 * RPW, TW = 16, NT = BN / 16;
-  constexpr int A_ITERS = ModeTraits<MODE, RPW>::A_ITERS;
-  constexpr int NACC = ModeTraits<MODE, RPW>::NACC;
-  constexpr int W_ITERS = (DRS_MAX_TAPS * 4 * BN + 255) / 256;
+  constexpr int NTHR = 256 * NWG, BNB = BN * NWG, PPI = 64 * NWG;  // threads, block channels, window pixels per pass
+  constexpr int A_ITERS = ModeTraits<MODE, RPW, NWG>::A_ITERS;
+  constexpr int NACC = ModeTraits<MODE, RPW, NWG>::NACC;
+  constexpr int W_ITERS = (DRS_MAX_TAPS * 4 * BNB + NTHR - 1) / NTHR;
   constexpr int V4 = P::SLOT_CH / 4;  // float4 loads per activation slot
   char* sA = smem;
   char* sW = smem + (size_t)P::IMAGES * g.a_image;
@@ -219,7 +225,9 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   int* sTapOff = reinterpret_cast<int*>(smem + (size_t)P::IMAGES * (g.a_image + g.w_image));  // window slot offset
   int* sTapW = sTapOff + 16;                                                                   // weight tap index
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) & 3;  // row-wave inside its group
+  const int ng = tid >> 8;          // channel group of this wave (0 when NWG == 1)
   const int lr = lane & 15, kg = lane >> 4;
   if (tid < DRS_MAX_TAPS) {
     int dyv = 0, dxv = 0, wt = 0;
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   // of consecutive patches at a time: neighbouring halos and the layer's weights are served by that L2.  The loop
   // below is software-pipelined ACROSS items: the loads of the next item's first chunk are in flight while the
   // current item is multiplied and written out, so HBM reads, MFMA and HBM writes overlap instead of alternating.
-  const int ngroups = d.Cout / BN;
+  const int ngroups = d.Cout / BNB;
   const int nitems = d.N * g.tiles_y * g.tiles_x * ngroups;
   const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
   const int per = (nitems + 7) >> 3;  // items per XCD range
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   if (S == 0) return;
   auto item_of = [&](int ordinal, int& n_, int& ty0_, int& tx0_, int& n0_) {
     int it = lo_item + ordinal * nb8 + j8;
-    n0_ = (it % ngroups) * BN;
+    n0_ = (it % ngroups) * BNB;
     it /= ngroups;
     tx0_ = (it % g.tiles_x) * TW;
     it /= g.tiles_x;
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
     n_ = it / g.tiles_y;
   };
   const int npix = g.IH * g.IW;
-  const int wslots = d.ntaps * 4 * BN;
+  const int wslots = d.ntaps * 4 * BNB;
 
   f32x4 acc[NACC][RPW][NT];
 
@@ -270,15 +278,15 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   const int ap0 = (tid >> 4) * 4 + ((ai & 7) >> 1);
   // window coordinates of slot pixel p: py = p / IW through a 16-bit reciprocal (exact for p < 1024, IW <= 64)
   auto win_yx = [&](int it, int& py, int& px) {
-    const int p = min(ap0 + it * 64, npix - 1);
+    const int p = min(ap0 + it * PPI, npix - 1);
     py = (p * g.iw_magic) >> 16;
     px = p - py * g.IW;
   };
   int w_goff[W_ITERS];  // byte offset of the slot inside one chunk of one global weight image, channel group 0
 #pragma unroll
   for (int it = 0; it < W_ITERS; ++it) {
-    const int s = min(tid + it * 256, wslots - 1);
-    const int nn = s % BN, q = (s / BN) & 3, tap = s / (BN * 4);
+    const int s = min(tid + it * NTHR, wslots - 1);
+    const int nn = s % BNB, q = (s / BNB) & 3, tap = s / (BNB * 4);
     w_goff[it] = ((sTapW[tap] * 4 + q) * d.Cout + nn) * 16;
   }
   const bool has_add = d.in_add != nullptr;
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
         int py, px;
         win_yx(it, py, px);
         const int iy = iy0 + py, ix = ix0 + px;
-        const bool ok = (ap0 + it * 64) < npix && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+        const bool ok = (ap0 + it * PPI) < npix && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
         const int iyc = min(max(iy, 0), d.H - 1), ixc = min(max(ix, 0), d.W - 1);
         a_base[it] = (iyc * d.W + ixc) * d.in_cs + d.in_co;
         a_ok |= (ok ? 1u : 0u) << it;
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
         int py, px;
         win_yx(it, py, px);
         const int iy = lty0 + py, ix = ltx0 + px;
-        const bool ok = (ap0 + it * 64) < npix && py < TH && px < TW && iy < d.H2 && ix < d.W2;
+        const bool ok = (ap0 + it * PPI) < npix && py < TH && px < TW && iy < d.H2 && ix < d.W2;
         const int iyc = min(iy, d.H2 - 1), ixc = min(ix, d.W2 - 1);
         a_base[it] = (iyc * d.W2 + ixc) * d.in2_cs + d.in2_co;
         a_ok |= (ok ? 1u : 0u) << it;
@@ -346,9 +354,9 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) areg[it][v] = *reinterpret_cast<const float4*>(in_n + a_base[it] + ch);
       }
-      {  // 1 tap: 4 * BN weight slots, all in the first staging pass
-        const int s2 = min(tid, 4 * BN - 1);
-        const size_t off = ((size_t)held_cc * 4 * d.Cout + (size_t)(s2 / BN) * d.Cout + ln0 + (s2 % BN)) * 16;
+      {  // 1 tap: 4 * BNB weight slots, all in the first staging pass
+        const int s2 = min(tid, 4 * BNB - 1);
+        const size_t off = ((size_t)held_cc * 4 * d.Cout + (size_t)(s2 / BNB) * d.Cout + ln0 + (s2 % BNB)) * 16;
 #pragma unroll
         for (int im = 0; im < P::IMAGES; ++im)
           wreg[0][im] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage + off);
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
   auto store_chunk = [&](int c) {  // registers -> LDS (operand conversion happens here)
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-      const int p = ap0 + it * 64;
+      const int p = ap0 + it * PPI;
       const bool pix_ok = (a_ok >> it) & 1u;
       float x[P::SLOT_CH];
 #pragma unroll
@@ -374,17 +382,19 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
     }
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it)
-      if (tid + it * 256 < (held_second ? 4 * BN : wslots)) {
+      if (tid + it * NTHR < (held_second ? 4 * BNB : wslots)) {
 #pragma unroll
         for (int im = 0; im < P::IMAGES; ++im)
-          *reinterpret_cast<u32x4*>(sW + (size_t)im * g.w_image + (size_t)(tid + it * 256) * 16) = wreg[it][im];
+          *reinterpret_cast<u32x4*>(sW + (size_t)im * g.w_image + (size_t)(tid + it * NTHR) * 16) = wreg[it][im];
       }
   };
   const int kg_off = kg * g.a_plane + (kg >> 1) * 128;  // fragment reads: this lane's k-group plane
   auto a_frag = [&](int wrow, int wcol) {               // window pixel (wrow, wcol) of this lane's k-group
     return P::load(sA, g.a_image, (size_t)kg_off + (size_t)(wrow * g.IW + wcol) * 16);
   };
-  auto w_frag = [&](int tap, int t) { return P::load(sW, g.w_image, ((size_t)(tap * 4 + kg) * BN + t * 16 + lr) * 16); };
+  auto w_frag = [&](int tap, int t) {
+    return P::load(sW, g.w_image, ((size_t)(tap * 4 + kg) * BNB + (ng * NT + t) * 16 + lr) * 16);
+  };
 
   if (!(g.debug & 4)) load_step(0);
   int n = 0, ty0 = 0, tx0 = 0, n0 = 0;
@@ -481,12 +491,12 @@ __global__ __launch_bounds__(256, 2) void tapconv_mfma_kernel(TapConv d, MfmaGeo
     if (c == nck - 1 && !(g.debug & 8)) {  // item complete
       if constexpr (MODE == MODE_CONVT) {
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) tile_epilogue<RPW, NT, false>(d, acc[ph], n, n0, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
+        for (int ph = 0; ph < 4; ++ph) tile_epilogue<RPW, NT, false>(d, acc[ph], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
       } else {
         if constexpr (MODE == MODE_CONV3X3_FUSE)
-          fuse_epilogue<RPW, NT>(d, acc[0], n, n0, ty0, tx0, wave, lr, kg);
+          fuse_epilogue<RPW, NT>(d, acc[0], n, n0 + ng * BN, ty0, tx0, wave, lr, kg);
         else
-          tile_epilogue<RPW, NT, false>(d, acc[0], n, n0, ty0, tx0, wave, lr, kg, d.out_oy, d.out_ox);
+          tile_epilogue<RPW, NT, false>(d, acc[0], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, d.out_oy, d.out_ox);
       }
     }
   }
@@ -505,11 +515,17 @@ static bool is_std3x3(const TapConv& d) {
   return true;
 }
 
+static int nwg_of(const TapConv& d, int mode) {
+  static const int env = getenv("DRS_NWG") ? atoi(getenv("DRS_NWG")) : 2;
+  return (env == 2 && mode == MODE_CONV3X3 && d.Cout % 64 == 0) ? 2 : 1;
+}
+
 static bool geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, int* rpw, int* mode, size_t* lds) {
   *mode = d.mode == DRS_TAPMODE_CONVT ? MODE_CONVT : (is_std3x3(d) ? MODE_CONV3X3 : MODE_GENERIC);
   if (*mode == MODE_CONV3X3 && d.fuse_out) *mode = MODE_CONV3X3_FUSE;
   *bn = 32;  // BN = 64 would need > 256 VGPRs with the prefetch registers live across the epilogue
   *rpw = (*mode == MODE_CONVT || d.in_stride != 1) ? 2 : 4;
+  // (measured: 32 x 16 patches with 8 rows per wave spill 60-125 VGPRs at 512 threads and run 5 % slower)
   const int TH = 4 * *rpw, TW = 16;
   if (*mode == MODE_CONVT) {
     g->dy_min = 0; g->dx_min = 0; g->IH = TH + 1; g->IW = TW + 1;
@@ -523,15 +539,18 @@ static bool geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, int* rpw, int
     g->IH = (TH - 1) * d.in_stride + (dy1 - dy0) + 1;
     g->IW = (TW - 1) * d.in_stride + (dx1 - dx0) + 1;
   }
-  const int a_iters = *mode == MODE_CONVT ? 3 : (*rpw == 4 ? 6 : 9);
-  if (g->IH * g->IW > a_iters * 64) return false;
+  const int nwg = nwg_of(d, *mode);
+  const int a_iters = (*mode == MODE_CONV3X3 || *mode == MODE_CONV3X3_FUSE)
+                          ? ((4 * *rpw + 2) * 18 + 64 * nwg - 1) / (64 * nwg)
+                          : (*mode == MODE_CONVT ? 3 : (*rpw == 4 ? 6 : 9)) / nwg;
+  if (g->IH * g->IW > a_iters * 64 * nwg) return false;
   g->tiles_x = drs_cdiv(d.TW, TW);
   g->tiles_y = drs_cdiv(d.TH, TH);
   const int KC = 4 * slot_ch(impl);
   g->nchunks = drs_cdiv(d.Cin, KC);
   g->a_plane = (g->IH * g->IW * 16 + 255) / 256 * 256;
   g->a_image = 4 * g->a_plane + 128;
-  g->w_image = d.ntaps * 4 * *bn * 16;
+  g->w_image = d.ntaps * 4 * *bn * nwg * 16;
   g->w_gimage = g->nchunks * d.wtaps_total * 4 * d.Cout * 16;
   g->nchunks2 = d.in2 ? drs_cdiv(d.Cin2, KC) : 0;
   g->iw_magic = (65536 + g->IW - 1) / g->IW;
@@ -564,9 +583,9 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
   return geom(d, impl, &g, &bn, &rpw, &mode, &lds);
 }
 
-template <class P, int BN, int RPW, int MODE, bool HAS2 = false>
+template <class P, int BN, int RPW, int MODE, bool HAS2 = false, int NWG = 1>
 static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t s) {
-  auto kern = tapconv_mfma_kernel<P, BN, RPW, MODE, HAS2>;
+  auto kern = tapconv_mfma_kernel<P, BN, RPW, MODE, HAS2, NWG>;
   static bool attr_done = false;  // per instantiation
   static int num_cu = 0;
   if (!attr_done) {
@@ -578,13 +597,14 @@ static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t
     attr_done = true;
   }
   // persistent grid: 2 blocks per CU (what the LDS footprint admits), a multiple of the 8 XCDs, never more than items
-  const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / BN);
-  static const int per_cu = getenv("DRS_BLOCKS_PER_CU") ? atoi(getenv("DRS_BLOCKS_PER_CU")) : 2;
+  const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / (BN * NWG));
+  static const int per_cu_env = getenv("DRS_BLOCKS_PER_CU") ? atoi(getenv("DRS_BLOCKS_PER_CU")) : 2;
+  const int per_cu = NWG == 2 ? 1 : per_cu_env;
   long long blocks = (long long)num_cu * per_cu;
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
   dim3 grid((unsigned)blocks);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d, g);
+  hipLaunchKernelGGL(kern, grid, dim3(256 * NWG), lds, s, d, g);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -592,6 +612,10 @@ static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t
 template <class P>
 static int launch_p(const TapConv& d, const MfmaGeom& g, int bn, int rpw, int mode, size_t lds, hipStream_t s) {
   if (mode == MODE_CONVT) return launch_t<P, 32, 2, MODE_CONVT>(d, g, lds, s);
+  if (bn == 32 && mode == MODE_CONV3X3 && nwg_of(d, mode) == 2) {
+    if (d.in2) return launch_t<P, 32, 4, MODE_CONV3X3, true, 2>(d, g, lds, s);
+    return launch_t<P, 32, 4, MODE_CONV3X3, false, 2>(d, g, lds, s);
+  }
   if (bn == 32 && mode == MODE_CONV3X3 && d.in2) return launch_t<P, 32, 4, MODE_CONV3X3, true>(d, g, lds, s);
   if (bn == 32 && mode == MODE_CONV3X3) return launch_t<P, 32, 4, MODE_CONV3X3>(d, g, lds, s);
   if (bn == 32 && mode == MODE_CONV3X3_FUSE) return launch_t<P, 32, 4, MODE_CONV3X3_FUSE>(d, g, lds, s);
