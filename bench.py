@@ -156,12 +156,18 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if args.impl == "mfma_bf16x3" and os.path.exists(tpath):  # PMC passes cannot run inside this process
+            # the dominant family = every CONV3X3 instantiation (with / without the fused shortcut input, one or two
+            # channel groups per block): launch-weighted mean of their measured HBM bytes per launch
+            tot_b = tot_n = 0.0
             for kname, e in json.load(open(tpath))["kernels"].items():
-                if "PolicyBF16X3, 32, 4, 1" in kname:
-                    traffic = round(e["hbm_bytes_per_launch"])
+                if "PolicyBF16X3, 32, 4, 1," in kname and "hbm_bytes_per_launch" in e:
+                    tot_b += e["hbm_bytes_per_launch"] * e["launches_per_forward"]
+                    tot_n += e["launches_per_forward"]
+            if tot_n:
+                traffic = round(tot_b / tot_n)
         mfma_per_product = 3 if args.impl == "mfma_bf16x3" else 1
         roofline = {"bound": "mfma",
-                    "kernel": ("tapconv_mfma_kernel<%s, 32, 4, CONV3X3>" % args.impl) if args.impl != "direct"
+                    "kernel": ("tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *> (3x3 stride-1 family)" % args.impl) if args.impl != "direct"
                     else "tapconv_direct_kernel",
                     "launches_per_forward": len(dom),
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),

@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
   int* sTapW = sTapOff + 16;                                                                   // weight tap index
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = (tid >> 6) & 3;  // row-wave inside its group
-  const int ng = tid >> 8;          // channel group of this wave (0 when NWG == 1)
+  const int wave = NWG == 1 ? (tid >> 6) : ((tid >> 6) & 3);  // row-wave inside its group
+  const int ng = NWG == 1 ? 0 : (tid >> 8);                   // channel group of this wave
   const int lr = lane & 15, kg = lane >> 4;
   if (tid < DRS_MAX_TAPS) {
     int dyv = 0, dxv = 0, wt = 0;
