@@ -56,6 +56,121 @@ def cpu_baseline(sd, x, t, lr):
                       f"torch {torch.__version__} CPU ops, {platform.processor() or platform.machine()}"}
 
 
+def other_workload(args):
+    """The non-headline BASELINE.json configs on the same contract (one JSON line, barrier + synchronize around exactly
+    K timed steps, max over ranks): `train` = configs[2] (per-rank batch 16 of 256x256, train-mode forward + backward +
+    flat RCCL all-reduce + FusedAdam), `sar` = configs[3] (SAR->NDVI sampling step, B=32 128x128), `generation` =
+    configs[4] (class-conditional sampling step with CFG scale 3, B=64 64x64, 10 classes)."""
+    from diffusionremotesensing_amd import _lib, dist, hip_ops, synthetic
+    _lib.load()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device: there is no CPU path to measure")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+        dist.init_process_group("nccl")
+    rank = dist.rank()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    wl = args.workload
+    if wl == "train":
+        from diffusionremotesensing_amd.optim import FusedAdam
+        from diffusionremotesensing_amd.train_diffusion_superres import Diffusion
+        from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+        m = Residual_Attention_UNet_superres(3, 3, dev)
+        m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 0))
+        m = m.to(dev).train()
+        d = Diffusion("cosine", m, "/nonexistent/snapshot.pt", noise_steps=1500, device=dev, magnification_factor=2,
+                      image_size=256, Degradation_type="DownBlur", multiple_gpus=world > 1)
+        hr = synthetic.tensor_uniform("train.hr", (16, 3, 256, 256), seed=rank).to(dev)
+        lr = synthetic.tensor_uniform("train.lr", (16, 3, 128, 128), seed=rank).to(dev)
+        opt = FusedAdam(m.parameters(), lr=1e-4)
+        loss_fn = torch.nn.MSELoss()
+        step = lambda: d.train_step(m, opt, loss_fn, lr, hr)  # noqa: E731
+        unit, batch, gflop = "train_steps/s (16 images per rank)", 16, 3 * 454.39
+        desc = "BASELINE configs[2] per-rank shape: superres 256x256 train step, batch 16 per GPU, MSE, Adam, train_impl=mfma_f32"
+        dtype = "f32 (v_mfma_f32_16x16x4_f32)"
+    elif wl == "sar":
+        from diffusionremotesensing_amd.train_diffusion_SAR_TO_NDVI import Diffusion
+        from diffusionremotesensing_amd.UNet_model_SAR_TO_NDVI import Residual_Attention_UNet_SAR_TO_NDVI
+        m = Residual_Attention_UNet_SAR_TO_NDVI(2, 1, dev)
+        m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 0))
+        m = m.to(dev).eval()
+        m.hip_engine().set_impl(args.impl)
+        d = Diffusion("cosine", m, "/nonexistent/snapshot.pt", noise_steps=1000, device=dev, image_size=128)
+        x = synthetic.tensor_normal("sar.x", (32, 1, 128, 128), seed=rank).to(dev)
+        sar = synthetic.tensor_uniform("sar.sar", (32, 2, 128, 128), seed=rank).to(dev)
+        t = torch.empty(32, dtype=torch.int64, device=dev)
+        state = {"i": 999, "first": True}
+
+        def step():
+            i = max(state["i"], 2)
+            eps = m.hip_engine().forward(x, t.fill_(i), sar, 1, reuse_cond=not state["first"], check_weights=state["first"])
+            hip_ops.sampler_step_(x, eps, torch.randn_like(x), i, d.alpha, d.alpha_hat, d.beta)
+            state["i"] -= 1
+            state["first"] = False
+        unit, batch, gflop = "batch32_steps/s", 32, 32 * 7.088
+        desc = "BASELINE configs[3]: SAR->NDVI UNet 128x128, 1-ch out / 2-ch SAR, batch 32 per GPU, sampling step"
+        dtype = DTYPE[args.impl]
+    else:
+        from diffusionremotesensing_amd.generate_new_imgs.train_diffusion_generation import Diffusion
+        from diffusionremotesensing_amd.generate_new_imgs.UNet_model_generation import Residual_Attention_UNet_generation
+        m = Residual_Attention_UNet_generation(3, 3, 10, dev)
+        m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 0))
+        m = m.to(dev).eval()
+        m.hip_engine().set_impl(args.impl)
+        d = Diffusion("cosine", m, "/nonexistent/snapshot.pt", noise_steps=1000, device=dev, image_size=64)
+        x = synthetic.tensor_normal("gen.x", (64, 3, 64, 64), seed=rank).to(dev)
+        labels2 = torch.cat([synthetic.tensor_randint("gen.y", (64,), 0, 10, seed=rank),
+                             torch.full((64,), -1, dtype=torch.int64)]).to(dev)
+        t2 = torch.empty(128, dtype=torch.int64, device=dev)
+        state = {"i": 999, "first": True}
+
+        def step():
+            i = max(state["i"], 2)
+            eps2 = m.hip_engine().forward(x.repeat(2, 1, 1, 1), t2.fill_(i), None, 1, labels=labels2,
+                                          check_weights=state["first"])
+            hip_ops.sampler_step_cfg_(x, eps2[:64], eps2[64:], 3.0, torch.randn_like(x), i, d.alpha, d.alpha_hat, d.beta)
+            state["i"] -= 1
+            state["first"] = False
+        unit, batch, gflop = "batch64_cfg_steps/s", 64, 2 * 64 * 1.771
+        desc = ("BASELINE configs[4]: class-conditional generation UNet 64x64, 10 classes, batch 64 per GPU, one CFG "
+                "sampling step = conditional + unconditional forward (one 128-row batch) + guided update")
+        dtype = DTYPE[args.impl]
+
+    def sync():
+        if dist.is_initialized():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    ctx = torch.enable_grad() if wl == "train" else torch.no_grad()
+    with ctx:
+        for _ in range(max(args.warmup, 1)):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist.is_initialized():
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = el.item()
+    value = world * args.steps / elapsed
+    if rank == 0:
+        print(json.dumps({"metric": f"{wl}_steps_per_s", "value": round(value, 4), "unit": unit, "n_gpus": world,
+                          "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+                          "data": "synthetic", "config": {"workload": desc, "batch_per_gpu": batch, "impl": args.impl},
+                          "images_per_s": round(value * batch, 2),
+                          "tflops_algorithmic": round(value * gflop / 1e3, 3)}), flush=True)
+    if dist.is_initialized():
+        torch.distributed.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,7 +178,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--impl", default=os.environ.get("DRS_IMPL", "mfma_bf16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="superres", choices=["superres", "train", "sar", "generation"],
+                    help="superres = the headline (BASELINE configs[1]); the others are the remaining configs")
     args = ap.parse_args()
+    if args.workload != "superres":
+        return other_workload(args)
 
     from diffusionremotesensing_amd import _lib, dist, hip_ops, synthetic
     from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
