@@ -517,7 +517,7 @@ static bool is_std3x3(const TapConv& d) {
 
 static int nwg_of(const TapConv& d, int mode) {
   static const int env = getenv("DRS_NWG") ? atoi(getenv("DRS_NWG")) : 2;
-  return (env == 2 && mode == MODE_CONV3X3 && d.Cout % 64 == 0) ? 2 : 1;
+  return (env == 2 && mode == MODE_CONV3X3 && d.Cout % 64 == 0 && !d.shared_cu) ? 2 : 1;
 }
 
 static bool geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, int* rpw, int* mode, size_t* lds) {
@@ -599,7 +599,7 @@ static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t
   // persistent grid: 2 blocks per CU (what the LDS footprint admits), a multiple of the 8 XCDs, never more than items
   const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / (BN * NWG));
   static const int per_cu_env = getenv("DRS_BLOCKS_PER_CU") ? atoi(getenv("DRS_BLOCKS_PER_CU")) : 2;
-  const int per_cu = NWG == 2 ? 1 : per_cu_env;
+  const int per_cu = NWG == 2 ? 1 : (d.shared_cu ? (d.shared_cu == 2 ? 2 : 1) : per_cu_env);
   long long blocks = (long long)num_cu * per_cu;
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;

@@ -60,6 +60,10 @@ struct TapConv {
   const float* fuse_b;
   float* fuse_out;
   int fuse_dim;
+  // launch hint: this op runs next to another one on a second stream: one block per CU (80 KB of LDS each, so a block of
+  // either kernel fits on every CU at the same time) and no 512-thread variant; 2 = two blocks per CU for the small-LDS
+  // 1x1 flavours (37 KB each next to the partner's 80 KB)
+  int shared_cu;
 };
 
 struct DrsErr {

@@ -264,6 +264,9 @@ struct drs_plan {
   int g_out = -1, g_X[3], g_CAT[3], g_U[3], g_G[3], g_P[3], g_PSI[3], g_E[3], g_R[4], g_D[3], g_H[4], g_x0 = -1;
   int t_xn = -1, t_upn = -1, g_upn = -1, g_lr[4], t_rn[4], t_an[3];
   size_t o_dtemb = 0, o_scratch = 0, o_wgrad = 0;
+  // second stream of the eval forward: the attention branch of a decoder stage runs next to the up-sampling branch
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   int P(const std::string& name, int64_t numel) {
     params.push_back({name, numel});
@@ -539,7 +542,16 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
   return DRS_OK;
 }
 
-extern "C" void drs_unet_plan_destroy(drs_plan* plan) { delete plan; }
+extern "C" void drs_unet_plan_destroy(drs_plan* plan) {
+  if (!plan) return;
+  if (plan->side) {
+    (void)hipStreamSynchronize(plan->side);
+    (void)hipEventDestroy(plan->ev_fork);
+    (void)hipEventDestroy(plan->ev_join);
+    (void)hipStreamDestroy(plan->side);
+  }
+  delete plan;
+}
 extern "C" int drs_unet_num_params(const drs_plan* plan) { return plan ? (int)plan->params.size() : 0; }
 extern "C" const char* drs_unet_param_name(const drs_plan* plan, int i) {
   return (plan && i >= 0 && i < (int)plan->params.size()) ? plan->params[i].name.c_str() : nullptr;
@@ -693,14 +705,31 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   }
 #define RUN(expr) do { if ((rc = (expr))) return rc; } while (0)
 
+  // --- second stream (eval plans): see the decoder section ---
+  static const bool concurrent_env = !(getenv("DRS_CONCURRENT") && atoi(getenv("DRS_CONCURRENT")) == 0);
+  const bool concurrent = concurrent_env && !train && !plan->profiling && c.impl != DRS_IMPL_DIRECT;
+  if (concurrent && !plan->side) {
+    DRS_CHECK_HIP(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
+    DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+    DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
+  }
+
   // --- time embeddings for the 7 blocks (reference :338-339 + every time_mlp) ---
   float* temb = (float*)((char*)ws + plan->o_temb);
   const float* inv_freq = (const float*)(pk + plan->o_inv_freq);
+  // (eval: on the side stream, next to the conditioning branch / conv0; the first consumer is block 0's conv1)
+  hipStream_t st_mlp = s;
+  if (concurrent) {
+    st_mlp = plan->side;
+    DRS_CHECK_HIP(hipEventRecord(plan->ev_fork, s));  // t / labels were produced on the caller's stream
+    DRS_CHECK_HIP(hipStreamWaitEvent(st_mlp, plan->ev_fork, 0));
+  }
   prof_begin(plan, "time_mlp", 0, 0, s);
   RUN(drs_launch_time_mlp_multi(t, inv_freq, pk, (const long long*)(pk + plan->o_mlp_table), (int)plan->mlps.size(), 256,
                                 temb, plan->temb_total, B, 100, labels ? (const float*)(pk + plan->o_label) : nullptr,
-                                (const long long*)labels, label_batch, s));
+                                (const long long*)labels, label_batch, st_mlp));
   prof_end(plan, s);
+  if (concurrent) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, st_mlp));
 
   // --- LR conditioning branch: RRDB -> bicubic -> conv (reference :345-353), constant per sampling chain ---
   if (has_cond && !reuse_cond) {
@@ -742,6 +771,8 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   RUN(drs_launch_stem(x, (const float*)(pk + plan->stem0.w_off), (const float*)(pk + plan->stem0.b_off),
                       has_cond ? TP(plan->t_cond) : nullptr, Bl, TP(plan->t_x0), B, C, kDown[0], H, W, s));
   prof_end(plan, s);
+
+  if (concurrent) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));  // time embeddings are ready
 
   // --- encoder + bottleneck: ResConvBlock (reference :153-172), downs (:366) ---
   const float* xin = TP(plan->t_x0);
@@ -788,6 +819,11 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   }
 
   // --- decoder (reference :372-377) ---
+  // Eval plans run the attention branch of a stage (gating, w_g, w_x, psi, result: HBM-bound 1x1 / 2x2 kernels) on a
+  // second stream NEXT TO the up-sampling branch (3x3 conv + ConvTranspose: MFMA / LDS-bound): both only read the stage
+  // input and the skip tensor and write disjoint channel slices of cat.i.  Every kernel of the pair is launched with
+  // one block per CU, so a block of each fits on every CU at once (2 x 80 KB of LDS) and the two use complementary
+  // resources.  Train plans and profiled runs keep the serial order.
   const float* xcur = TP(plan->t_R[3]);
   bool fused_output = false;
   for (int i = 0; i < 3; ++i) {
@@ -796,53 +832,68 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     const int lh = H >> (3 - i), lw = W >> (3 - i);
     const float* xres = TP(plan->t_R[2 - i]);  // residual_inputs[-(i+1)]: (B, Ch, 2lh, 2lw)
     float* cat = TP(plan->t_CAT[i]);
+    hipStream_t sa = s;  // stream of the attention branch
+    if (concurrent) {
+      sa = plan->side;
+      DRS_CHECK_HIP(hipEventRecord(plan->ev_fork, s));
+      DRS_CHECK_HIP(hipStreamWaitEvent(sa, plan->ev_fork, 0));
+    }
+    auto att_conv = [&](const ConvLayer& L, TapConv d) -> int {  // attention-branch op (eval: BN folded)
+      if (!concurrent) return conv_bn(L, d);
+      d.shared_cu = 1;
+      return plan_conv(plan, L, d, sa);
+    };
+    auto att_plain = [&](const ConvLayer& L, TapConv d) -> int {
+      if (concurrent) d.shared_cu = 1;
+      return plan_conv(plan, L, d, sa);
+    };
     {  // gating = relu(BN(conv1x1(x)))   (:222-225)
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.gate), PB(st.gate), TP(plan->t_G[i]), Ch, Ch, 0, 1, 1, 1,
                             0);
       d.relu_pre = 1;
-      RUN(conv_bn(st.gate, d));
+      RUN(att_conv(st.gate, d));
     }
-    // (fusing w_g into the stride-2 w_x kernel was measured slower: its 16x32 window staging is 4x too large for g)
-    const bool fuse_wg = false;
-    if (!fuse_wg) {  // g1 = w_g(g)   (:101)
-      TapConv d = conv_desc(TP(plan->t_G[i]), B, lh, lw, Ch, Ch, 0, PW(st.wg), PB(st.wg), TP(plan->t_Q[i]), Ch, Ch, 0, 1,
-                            1, 1, 0);
-      RUN(plan_conv(plan, st.wg, d, s));
-    }
-    {  // relu(g1 + w_x(x))   (:102-103)
-      TapConv d = conv_desc(xres, B, 2 * lh, 2 * lw, Ch, Ch, 0, PW(st.wx), PB(st.wx), TP(plan->t_P[i]), Ch, Ch, 0, 2, 2,
-                            2, 0);
-      if (fuse_wg) {
-        d.in2 = TP(plan->t_G[i]); d.in2_cs = Ch; d.in2_co = 0; d.Cin2 = Ch; d.H2 = lh; d.W2 = lw;
-        d.w2 = PW(st.wg); d.bias2 = PB(st.wg);
-      } else {
-        d.res = TP(plan->t_Q[i]); d.res_cs = Ch; d.res_co = 0;
+    // (fusing w_g into the stride-2 w_x kernel was measured slower: its 16x32 window staging is 4x too large for g;
+    //  running w_x early on the side stream, next to the encoder, slowed the encoder kernels more than it saved)
+    {
+      {  // g1 = w_g(g)   (:101)
+        TapConv d = conv_desc(TP(plan->t_G[i]), B, lh, lw, Ch, Ch, 0, PW(st.wg), PB(st.wg), TP(plan->t_Q[i]), Ch, Ch, 0, 1,
+                              1, 1, 0);
+        RUN(att_plain(st.wg, d));
       }
-      d.relu_post = 1;
-      RUN(plan_conv(plan, st.wx, d, s));
+      {  // relu(g1 + w_x(x))   (:102-103)
+        TapConv d = conv_desc(xres, B, 2 * lh, 2 * lw, Ch, Ch, 0, PW(st.wx), PB(st.wx), TP(plan->t_P[i]), Ch, Ch, 0, 2, 2,
+                              2, 0);
+        d.res = TP(plan->t_Q[i]); d.res_cs = Ch; d.res_co = 0;
+        d.relu_post = 1;
+        RUN(att_plain(st.wx, d));
+      }
     }
     {  // psi = sigmoid(conv1x1 -> 1 channel)   (:104)
       TapConv d = conv_desc(TP(plan->t_P[i]), B, lh, lw, Ch, Ch, 0, PW(st.psi), PB(st.psi), TP(plan->t_PSI[i]), 1, 1, 0,
                             1, 1, 1, 0);
       d.sigmoid = 1;
-      RUN(plan_conv(plan, st.psi, d, s));
+      RUN(att_plain(st.psi, d));
     }
     {  // attention = BN(conv1x1(nearest2x(psi) * x))  == nearest2x(psi) * (W' x) + b'   (:105-107), into cat[:, Cc:]
       TapConv d = conv_desc(xres, B, 2 * lh, 2 * lw, Ch, Ch, 0, PW(st.result), PB(st.result), cat, Ch, Cc + Ch, Cc, 1, 1,
                             1, 0);
       d.gate = TP(plan->t_PSI[i]);
-      RUN(conv_bn(st.result, d));
+      RUN(att_conv(st.result, d));
+      if (concurrent) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, sa));
     }
     {  // UpConvBlock: relu(BN(conv(x + relu(time_mlp(t)))))   (:199-205)
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.conv), PB(st.conv), TP(plan->t_U[i]), Cc, Cc, 0, 3, 3, 1,
                             1);
       d.relu_pre = 1;
       d.in_add = temb + st.mlp.temb_off; d.in_add_cs = plan->temb_total;
+      d.shared_cu = concurrent ? 1 : 0;
       RUN(conv_bn(st.conv, d));
     }
     if (st.transform.mfma) {  // transform: ConvTranspose2d, into cat[:, :Cc]   (:206, :376), 4 phases in one launch
       TapConv d = convT_fused_desc(TP(plan->t_U[i]), B, lh, lw, Cc, Cc, 0, PW(st.transform), PB(st.transform), cat, Cc,
                                    Cc + Ch, 0);
+      d.shared_cu = concurrent ? 1 : 0;
       RUN(plan_conv(plan, st.transform, d, s));
     } else
     for (int py = 0; py < 2; ++py)
@@ -851,6 +902,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                                      Cc + Ch, 0, py, px);
         RUN(plan_conv(plan, st.transform, d, s));
       }
+    if (concurrent) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));  // both halves of cat.i are complete
     {  // up_conv over the concatenation (:377), no norm / activation
       TapConv d = conv_desc(cat, B, 2 * lh, 2 * lw, Cc + Ch, Cc + Ch, 0, PW(st.upconv), PB(st.upconv), TP(plan->t_X[i]),
                             Ch, Ch, 0, 3, 3, 1, 1);
