@@ -71,6 +71,30 @@ class HipUNetEngine:
         self._inv_freq = inv_freq_table(module.time_emb_dim)
         self._inv_freq_c = (C.c_float * self._inv_freq.numel())(*self._inv_freq.tolist())
 
+    # -- state_dict key -> live tensor, without building a state_dict per call ----------------------------------
+    def _tensors(self, names):
+        """{key: parameter / buffer} for the plan's keys.  `module.state_dict()` walks all 60 sub-modules and 299 keys
+        (~0.4 ms, several times per training step); the (owning module, attribute) pair of every key is resolved once
+        and the tensors are fetched with getattr (they are looked up, not cached: `.to()` / `load_state_dict` may
+        replace or rewrite them)."""
+        cache = self.__dict__.setdefault("_key_owner", {})
+        m = self._module()
+        out = {}
+        for n in names:
+            ent = cache.get(n)
+            if ent is None:
+                path, _, leaf = n.rpartition(".")
+                owner = m.get_submodule(path) if path else m
+                ent = cache[n] = (owner, leaf)
+            owner, leaf = ent
+            t = owner._parameters.get(leaf)
+            if t is None:
+                t = owner._buffers.get(leaf)
+            if t is None:
+                raise RuntimeError(f"state_dict key {n} is missing from the module")
+            out[n] = t
+        return out
+
     # -- plan / weights -------------------------------------------------------------------
     def _get_plan(self, B, Bl, H, W, mag, device, train=False):
         impl = self.train_impl if train else self.impl
@@ -100,8 +124,7 @@ class HipUNetEngine:
 
     def _sync_weights(self, plan):
         """Re-pack (BatchNorm fold + re-layout) when any parameter or buffer changed."""
-        m = self._module()
-        sd = m.state_dict(keep_vars=True)
+        sd = self._tensors(plan.param_names)
         tensors = []
         for name, numel in zip(plan.param_names, plan.param_numels):
             t = sd[name]
@@ -136,9 +159,9 @@ class HipUNetEngine:
             raise RuntimeError("the conditioning image must be a tensor on a ROCm device")
         if train and torch.is_grad_enabled() and not _in_autograd_fn and any(p.requires_grad for p in m.parameters()):
             # training step: route through autograd so loss.backward() reaches drs_unet_backward
-            sd = m.state_dict(keep_vars=True)
             plan = self._get_plan(x.shape[0], lr_img.shape[0] if has_cond else x.shape[0], x.shape[2], x.shape[3],
                                   int(magnification_factor), x.device, True)
+            sd = self._tensors(plan.param_names)
             params = [sd[n] for n in plan.param_names if sd[n].requires_grad]
             return _UNetTrainFn.apply(self, x, timestep, lr_img, magnification_factor, labels, *params)
         named = [("x", x), ("timestep", timestep)] + ([("lr_img", lr_img)] if has_cond else []) + \
@@ -204,8 +227,7 @@ class HipUNetEngine:
     # -- backward (training step) ---------------------------------------------------------------
     def backward(self, plan, x, timestep, dout, labels=None):
         """d(loss)/d(parameters) for the last train-mode forward on `plan`; returns {state_dict key: gradient}."""
-        m = self._module()
-        sd = m.state_dict(keep_vars=True)
+        sd = self._tensors(plan.param_names)
         lib = plan.lib
         wanted = [(i, n) for i, n in enumerate(plan.param_names) if sd[n].requires_grad]
         total = sum(plan.param_numels[i] for i, _ in wanted)
@@ -291,7 +313,8 @@ class _UNetTrainFn(torch.autograd.Function):
             labels = labels.to(torch.int64).contiguous()
         out = engine.forward(x, timestep, lr_img, mag, _in_autograd_fn=True, labels=labels)
         ctx.engine, ctx.plan = engine, engine._last_plan
-        ctx.names = [n for n in ctx.plan.param_names if engine._module().state_dict(keep_vars=True)[n].requires_grad]
+        sd = engine._tensors(ctx.plan.param_names)
+        ctx.names = [n for n in ctx.plan.param_names if sd[n].requires_grad]
         ctx.labels = labels
         ctx.save_for_backward(x, timestep)
         return out
