@@ -644,7 +644,7 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
                                       char* __restrict__ dst_w, float* __restrict__ dst_b, int Cout, int Cin, int taps,
-                                      int transposed, int nchunks, size_t image_bytes, int cout_src) {
+                                      int transposed, int nchunks, size_t image_bytes, int cout_src, int flip_taps) {
   // cout_src < Cout: the source has only cout_src output channels; the rest of the image is zero (a 16-channel
   // output padded to the kernel's 32-channel tile)
   constexpr int KC = 4 * P::SLOT_CH;
@@ -653,6 +653,7 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
     const int co = (int)(s % Cout);
     const int q = (int)((s / Cout) & 3);
     const int tap = (int)((s / ((size_t)Cout * 4)) % taps);
+    const int tap_src = flip_taps ? taps - 1 - tap : tap;  // data gradients convolve with the spatially flipped kernel
     const int c = (int)(s / ((size_t)Cout * 4 * taps));
     float sc = 1.f;
     if (gamma) sc = gamma[co] / sqrtf(rvar[co] + eps);
@@ -662,7 +663,8 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
       const int ci = c * KC + q * P::SLOT_CH + j;
       float v = 0.f;
       if (ci < Cin && co < cout_src) {
-        const size_t src = transposed ? (((size_t)ci * cout_src + co) * taps + tap) : (((size_t)co * Cin + ci) * taps + tap);
+        const size_t src = transposed ? (((size_t)ci * cout_src + co) * taps + tap_src)
+                                      : (((size_t)co * Cin + ci) * taps + tap_src);
         v = w[src];
         if (gamma) v *= sc;
       }
@@ -689,7 +691,7 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl) {
 
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
-                              int transposed, int impl, hipStream_t s, int cout_src) {
+                              int transposed, int impl, hipStream_t s, int cout_src, int flip_taps) {
   if (cout_src <= 0) cout_src = Cout;
   const int KC = 4 * slot_ch(impl);
   const int nchunks = drs_cdiv(Cin, KC);
@@ -700,7 +702,7 @@ int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma
   if (blocks < 1) blocks = 1;
 #define DRS_PACK(P)                                                                                                   \
   hipLaunchKernelGGL(pack_conv_mfma_kernel<P>, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps,    \
-                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src)
+                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps)
   if (impl == DRS_IMPL_MFMA_F32) DRS_PACK(PolicyF32);
   else if (impl == DRS_IMPL_MFMA_F16) DRS_PACK(PolicyF16);
   else DRS_PACK(PolicyBF16X3);

@@ -105,7 +105,7 @@ int drs_launch_pack_conv(const float* w, const float* b, const float* gamma, con
 size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl);
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
-                              int transposed, int impl, hipStream_t s, int cout_src = 0);
+                              int transposed, int impl, hipStream_t s, int cout_src = 0, int flip_taps = 0);
 
 int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
                             hipStream_t s);
