@@ -302,12 +302,26 @@ def launch(args):
     spec = str(args.dataset_path or "")
     if not spec.startswith("synthetic"):
         raise NotImplementedError("image-folder datasets (reference utils.get_data_superres*) are outside the hot "
-                                  "path; use --dataset_path synthetic[:N]")
+                                  "path; use --dataset_path synthetic[:N] or synthetic_u8[:N]")
     length = int(spec.split(":")[1]) if ":" in spec else 4 * args.batch_size
     ch = args.inp_out_channels
     train_dataset = SyntheticSuperresDataset(length, ch, args.image_size, args.magnification_factor, seed=1)
     val_dataset = SyntheticSuperresDataset(max(length // 4, 1), ch, args.image_size, args.magnification_factor, seed=2)
-    if args.multiple_gpus:
+    if spec.startswith("synthetic_u8"):
+        # the reference's DownBlur feed (utils.get_data_superres: bicubic down-sampling + Gaussian blur per item with
+        # Pillow on the host) from a uint8 HR cache on the device, bit-exact (degradation.py); rank r owns every
+        # world-th image like DistributedSampler
+        from .degradation import DeviceSuperresFeed
+        if args.Degradation_type.lower() != "downblur":
+            raise NotImplementedError("the on-device feed implements Degradation_type=DownBlur")
+        radius = args.Blur_radius if args.Blur_radius == "random" else float(args.Blur_radius)
+        r, wsz = (drs_dist.rank(), drs_dist.world_size()) if args.multiple_gpus else (0, 1)
+
+        def feed(ds):
+            u8 = (ds.hr[r::wsz] * 255).round().clamp(0, 255).to(torch.uint8).to(device)
+            return DeviceSuperresFeed(u8, args.magnification_factor, radius, args.batch_size, shuffle=True)
+        train_loader, val_loader = feed(train_dataset), feed(val_dataset)
+    elif args.multiple_gpus:
         train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=False,
                                   sampler=DistributedSampler(train_dataset))
         val_loader = DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,

@@ -101,6 +101,15 @@ int drs_adam_multi(const drs_adam_tensor* table, int ntensors, int64_t max_numel
 int drs_aggregate_tiles(const float* tiles, const int32_t* origins, const float* weight, float* out, int32_t* uncovered,
                         int n, int C, int S, int H, int W, drs_stream_t stream);
 
+/* "DownBlur" degradation of the super-resolution data feed on the device, bit-exact with the Pillow calls of the
+ * reference's dataset item: x = ToTensor(GaussianBlur(radius)(resize(y, (out_w, out_h), BICUBIC))), y = ToTensor(hr).
+ *   hr: (N,C,H,W) uint8;  x_lr: (N,C,out_h,out_w) float32 in [0,1];  y_hr: (N,C,H,W) float32 or NULL;
+ *   blur_radius: Pillow's GaussianBlur radius (0 = no blur);  scratch: drs_downblur_scratch_bytes(...) bytes.
+ * Replaces get_data_superres.__getitem__, utils.py:140-158 (Gauss_noise=False). */
+size_t drs_downblur_scratch_bytes(int N, int C, int H, int W, int out_h, int out_w);
+int drs_downblur_u8(const uint8_t* hr, int N, int C, int H, int W, int out_h, int out_w, float blur_radius, float* x_lr,
+                    float* y_hr, void* scratch, size_t scratch_bytes, drs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (used by the parity tests for every convolution flavour
  * the UNet contains, at arbitrary/ragged shapes)

@@ -143,3 +143,26 @@ def test_aggregation_sampling(vgolden, seeded_sd):
     out = A.aggregate(torch.cat(tiles), infos, w, 96, 112)
     ref = torch.from_numpy(vgolden["g10_result"])
     assert torch.allclose(out, ref, rtol=0, atol=1e-5)
+
+
+def test_degradation_oracle_matches_pillow_fixtures():
+    """The numpy restatement of Pillow's 8-bit bicubic resize + GaussianBlur against outputs of Pillow itself on the
+    reference's call sequence (tools/make_golden_degradation.py): bit-exact."""
+    import os
+    from oracle import degradation_oracle as G
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "degradation_golden.npz")))
+    tags = sorted(k[:-3] for k in g if k.endswith("_hr"))
+    assert len(tags) == 7
+    for tag in tags:
+        hr, ref = g[tag + "_hr"], g[tag + "_lr"]
+        h, w, m, r = g[tag + "_params"]
+        planes = hr[None] if hr.ndim == 2 else np.moveaxis(hr, -1, 0)       # (C, H, W)
+        want = ref[None] if ref.ndim == 2 else np.moveaxis(ref, -1, 0)
+        out_h, out_w = int(w) // int(m), int(h) // int(m)                    # the reference's transposed size quirk
+        assert want.shape[1:] == (out_h, out_w), tag
+        x, y = G.downblur(planes, out_h, out_w, float(r))
+        assert np.array_equal((x * 255).round().astype(np.uint8), want), tag
+        assert np.array_equal(x, want.astype(np.float32) / np.float32(255)), tag
+        assert np.array_equal(y, planes.astype(np.float32) / np.float32(255))
+    # Gaussian radius -> box radius: values of BoxBlur.c's float formula
+    assert abs(float(G.gaussian_box_radius(0.5)) - 0.0) < 0.3 and float(G.gaussian_box_radius(1.5)) > 0.9
