@@ -628,13 +628,13 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
 static void prof_begin(drs_plan* plan, const std::string& name, double flops, double bytes, hipStream_t s) {
   if (!plan->profiling) return;
   drs_plan::OpRec r{name, flops, bytes, nullptr, nullptr};
-  hipEventCreate(&r.e0);
-  hipEventCreate(&r.e1);
-  hipEventRecord(r.e0, s);
+  (void)hipEventCreate(&r.e0);
+  (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, s);
   plan->ops.push_back(r);
 }
 static void prof_end(drs_plan* plan, hipStream_t s) {
-  if (plan->profiling) hipEventRecord(plan->ops.back().e1, s);
+  if (plan->profiling) (void)hipEventRecord(plan->ops.back().e1, s);
 }
 static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d, hipStream_t s) {
   std::string name = plan->params[L.w].name;
@@ -700,7 +700,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   };
   int rc;
   if (plan->profiling) {
-    for (auto& r : plan->ops) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : plan->ops) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     plan->ops.clear();
   }
 #define RUN(expr) do { if ((rc = (expr))) return rc; } while (0)
