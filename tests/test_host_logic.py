@@ -193,3 +193,14 @@ def test_variant_cli_flags_and_no_cpu_fallback():
         ms["sar"](torch.zeros(1, 1, 32, 32), torch.ones(1, dtype=torch.int64), torch.zeros(1, 2, 32, 32))
     with pytest.raises(RuntimeError):
         ms["gen"](torch.zeros(1, 3, 32, 32), torch.ones(1, dtype=torch.int64), torch.tensor([1]))
+
+
+def test_video_maker_without_cv2(tmp_path):
+    """generate_video=True must not fail for lack of cv2: frames are saved as a tensor instead."""
+    from diffusionremotesensing_amd.video import video_maker
+    frames = [torch.rand(2, 3, 8, 8) for _ in range(3)]
+    path = str(tmp_path / "v.mp4")
+    video_maker(frames, path, 10)
+    saved = torch.load(path + ".frames.pt") if os.path.exists(path + ".frames.pt") else None
+    assert saved is None or (saved.shape == (3, 8, 8, 3) and saved.dtype == torch.uint8)
+    assert saved is not None or os.path.exists(path)
