@@ -72,11 +72,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("DRS_LIB", LIB_PATH)  # A/B experiments with alternative builds of the same ABI
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
+            f"{path} not found: the HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (needs hipcc, cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
