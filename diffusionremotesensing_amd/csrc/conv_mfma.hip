@@ -524,7 +524,11 @@ static bool geom(const TapConv& d, int impl, MfmaGeom* g, int* bn, int* rpw, int
   *mode = d.mode == DRS_TAPMODE_CONVT ? MODE_CONVT : (is_std3x3(d) ? MODE_CONV3X3 : MODE_GENERIC);
   if (*mode == MODE_CONV3X3 && d.fuse_out) *mode = MODE_CONV3X3_FUSE;
   *bn = 32;  // BN = 64 would need > 256 VGPRs with the prefetch registers live across the epilogue
-  *rpw = (*mode == MODE_CONVT || d.in_stride != 1) ? 2 : 4;
+  // images of at most 8 rows (the 64x64 generation model's bottleneck): 8-row patches waste half as many MFMAs as
+  // 16-row ones; the 3x3 schedule only exists for 16 rows, so those layers take the generic tap list
+  const bool small = d.in && d.TH <= 8 && d.in_stride == 1;
+  if (small && *mode == MODE_CONV3X3 && !d.in2) *mode = MODE_GENERIC;
+  *rpw = (*mode == MODE_CONVT || d.in_stride != 1 || (small && *mode == MODE_GENERIC)) ? 2 : 4;
   // (measured: 32 x 16 patches with 8 rows per wave spill 60-125 VGPRs at 512 threads and run 5 % slower)
   const int TH = 4 * *rpw, TW = 16;
   if (*mode == MODE_CONVT) {
