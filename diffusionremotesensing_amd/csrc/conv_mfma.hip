@@ -26,176 +26,10 @@
 // The footprint is sized for 2 blocks per CU.
 #include <stdlib.h>
 
+#include "conv_epilogue.h"
 #include "mfma_policy.h"
 
 enum { MODE_GENERIC = 0, MODE_CONV3X3 = 1, MODE_CONVT = 2, MODE_CONV3X3_FUSE = 3 };
-
-// ---- epilogue of RPW rows x NT channel tiles held in MFMA layout ---------------------------------------------------
-// Lane (lr, kg) holds channels t*16 + kg*4 .. +3 of pixel lr for every n-tile t.  Pairs of n-tiles are exchanged
-// between lanes lr and lr^8 (one DPP row rotate) so that each store instruction covers 8 pixels x 32 channels =
-// full 128-byte lines: pass h=0 writes pixels 0..7 of the row, pass h=1 pixels 8..15; lanes lr < 8 carry the even
-// n-tile of the pair, lanes lr >= 8 the odd one.  Residual / gate loads use the same mapping and are issued per
-// row group before the arithmetic (addresses clamped, stores predicated).
-template <int RPW, int NT, bool FUSE>
-__device__ __forceinline__ void tile_epilogue(const TapConv& d, f32x4 (&acc)[RPW][NT], int n, int n0, int ty0, int tx0,
-                                              int wave, int lr, int kg, int out_oy, int out_ox) {
-  constexpr int NP = NT / 2;
-  constexpr int RG = RPW > 2 ? 2 : RPW;  // rows whose loads are in flight together (bounded register footprint)
-  const bool lo = lr < 8;
-  const int pl = lr & 7;
-  const int csel = (lo ? 0 : 16) + kg * 4;
-  float4 bias4[NP], post4[NP];
-#pragma unroll
-  for (int pr = 0; pr < NP; ++pr) {
-    const int co = n0 + pr * 32 + csel;
-    bias4[pr] = d.bias ? *reinterpret_cast<const float4*>(d.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d.bias2) {
-      const float4 b2 = *reinterpret_cast<const float4*>(d.bias2 + co);
-      bias4[pr].x += b2.x; bias4[pr].y += b2.y; bias4[pr].z += b2.z; bias4[pr].w += b2.w;
-    }
-    post4[pr] = d.post_add ? *reinterpret_cast<const float4*>(d.post_add + (size_t)n * d.post_cs + co)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float4 fw[4][NP];
-  if constexpr (FUSE) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int pr = 0; pr < NP; ++pr)
-        fw[j][pr] = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)min(j, d.fuse_dim - 1) * d.Cout + n0 + pr * 32 + csel);
-  }
-#pragma unroll
-  for (int rg = 0; rg < RPW; rg += RG) {
-    bool valid[RG][2];
-    unsigned opix[RG][2];
-    int oyx[RG][2][2];
-    float gv[RG][2];
-    float4 res4[RG][2][NP];
-#pragma unroll
-    for (int rr = 0; rr < RG; ++rr)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ty = ty0 + wave * RPW + rg + rr, tx = tx0 + pl + 8 * h;
-        valid[rr][h] = ty < d.TH && tx < d.TW;
-        const int oy = min(ty, d.TH - 1) * d.out_scale + out_oy, ox = min(tx, d.TW - 1) * d.out_scale + out_ox;
-        oyx[rr][h][0] = oy; oyx[rr][h][1] = ox;
-        opix[rr][h] = ((unsigned)n * d.OH + oy) * d.OW + ox;
-        if (d.gate) gv[rr][h] = d.gate[((size_t)n * (d.OH >> 1) + (oy >> 1)) * (d.OW >> 1) + (ox >> 1)];
-        if (d.res) {
-          const size_t rp = d.res_bstride_zero ? (size_t)((unsigned)oy * d.OW + ox) : (size_t)opix[rr][h];
-#pragma unroll
-          for (int pr = 0; pr < NP; ++pr)
-            res4[rr][h][pr] = *reinterpret_cast<const float4*>(d.res + rp * d.res_cs + d.res_co + n0 + pr * 32 + csel);
-        }
-      }
-#pragma unroll
-    for (int rr = 0; rr < RG; ++rr) {
-      const int r = rg + rr;
-      f32x4 val[2][NP];
-#pragma unroll
-      for (int pr = 0; pr < NP; ++pr) {
-        f32x4 mine, theirs;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float send = lo ? acc[r][2 * pr + 1][j] : acc[r][2 * pr][j];
-          theirs[j] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xf, 0xf, false));
-          mine[j] = lo ? acc[r][2 * pr][j] : acc[r][2 * pr + 1][j];
-        }
-        val[0][pr] = lo ? mine : theirs;   // pass 0: pixel pl     (lo: own even tile,      hi: partner's odd tile)
-        val[1][pr] = lo ? theirs : mine;   // pass 1: pixel pl + 8 (lo: partner's even tile, hi: own odd tile)
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float fz[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pr = 0; pr < NP; ++pr) {
-          f32x4 v = val[h][pr];
-          if (d.gate) v *= gv[rr][h];
-          v[0] += bias4[pr].x; v[1] += bias4[pr].y; v[2] += bias4[pr].z; v[3] += bias4[pr].w;
-          if (d.relu_pre) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-          }
-          v[0] += post4[pr].x; v[1] += post4[pr].y; v[2] += post4[pr].z; v[3] += post4[pr].w;
-          if (d.res) {
-            v[0] += res4[rr][h][pr].x; v[1] += res4[rr][h][pr].y; v[2] += res4[rr][h][pr].z; v[3] += res4[rr][h][pr].w;
-          }
-          if (d.relu_post) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-          }
-          if (d.out && valid[rr][h])
-            *reinterpret_cast<float4*>(d.out + (size_t)opix[rr][h] * d.out_cs + d.out_co + n0 + pr * 32 + csel) =
-                make_float4(v[0], v[1], v[2], v[3]);
-          if constexpr (FUSE) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              fz[j] += v[0] * fw[j][pr].x + v[1] * fw[j][pr].y + v[2] * fw[j][pr].z + v[3] * fw[j][pr].w;
-          }
-        }
-        if constexpr (FUSE) {  // y[j] = sum over the pixel's 32 channels = 8 lanes: lr^8 (tile of the pair) x 4 k-groups
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            fz[j] += __shfl_xor(fz[j], 8);
-            fz[j] += __shfl_xor(fz[j], 16);
-            fz[j] += __shfl_xor(fz[j], 32);
-          }
-          if (valid[rr][h] && lo && kg == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < d.fuse_dim)
-                d.fuse_out[(((size_t)n * d.fuse_dim + j) * d.OH + oyx[rr][h][0]) * d.OW + oyx[rr][h][1]] = fz[j] + d.fuse_b[j];
-          }
-        }
-      }
-    }
-  }
-}
-
-// ---- fused 1x1 projection epilogue (the UNet's `output` conv riding on up_convs.2) ------------------------------
-// Works in MFMA layout: lane (lr, kg) holds channels t*16 + kg*4 .. +3 of pixel lr.  y[j] = fuse_b[j] + sum over the 32
-// channels of (acc + bias) * fuse_w[j][co]: 8 in-lane products, then 2 cross-lane steps over the 4 k-group lanes.
-// The 32-channel tensor itself is written only if d.out is set (parity taps); production runs never store it.
-template <int RPW, int NT>
-__device__ __forceinline__ void fuse_epilogue(const TapConv& d, f32x4 (&acc)[RPW][NT], int n, int n0, int ty0, int tx0,
-                                              int wave, int lr, int kg) {
-  float4 bias4[NT], fw[4][NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int co = n0 + t * 16 + kg * 4;
-    bias4[t] = d.bias ? *reinterpret_cast<const float4*>(d.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      fw[j][t] = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)min(j, d.fuse_dim - 1) * d.Cout + co);
-  }
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int ty = ty0 + wave * RPW + r, tx = tx0 + lr;
-    const bool valid = ty < d.TH && tx < d.TW;
-    const int oy = min(ty, d.TH - 1) * d.out_scale + d.out_oy, ox = min(tx, d.TW - 1) * d.out_scale + d.out_ox;
-    float fz[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x4 v = acc[r][t];
-      v[0] += bias4[t].x; v[1] += bias4[t].y; v[2] += bias4[t].z; v[3] += bias4[t].w;
-      if (d.out && valid)
-        *reinterpret_cast<float4*>(d.out + (((size_t)n * d.OH + oy) * d.OW + ox) * d.out_cs + d.out_co + n0 + t * 16 + kg * 4) =
-            make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fz[j] += v[0] * fw[j][t].x + v[1] * fw[j][t].y + v[2] * fw[j][t].z + v[3] * fw[j][t].w;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      fz[j] += __shfl_xor(fz[j], 16);
-      fz[j] += __shfl_xor(fz[j], 32);
-    }
-    if (valid && kg == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < d.fuse_dim) d.fuse_out[(((size_t)n * d.fuse_dim + j) * d.OH + oy) * d.OW + ox] = fz[j] + d.fuse_b[j];
-    }
-  }
-}
 
 template <int MODE, int RPW, int NWG>
 struct ModeTraits {
@@ -635,6 +469,8 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((size_t)d.N * d.TH * d.TW == 0) return DRS_OK;
   MfmaGeom g; int bn, rpw, mode; size_t lds;
   geom(d, impl, &g, &bn, &rpw, &mode, &lds);
+  if (mode == MODE_CONV3X3 && nwg_of(d, mode) == 2 && drs_tapconv_ws_supported(d, impl))
+    return drs_launch_tapconv_ws(d, g, impl, s);
   if (impl == DRS_IMPL_MFMA_F32) return launch_p<PolicyF32>(d, g, bn, rpw, mode, lds, s);
   if (impl == DRS_IMPL_MFMA_F16) return launch_p<PolicyF16>(d, g, bn, rpw, mode, lds, s);
   return launch_p<PolicyBF16X3>(d, g, bn, rpw, mode, lds, s);
