@@ -5,22 +5,27 @@
 // "issue the loads of the next chunk" (the wave sits in the vector-memory queue for a memory round trip), "convert +
 // store to LDS" and "multiply", all 8 waves of a CU in lock step: the memory system idles while the matrix cores run
 // and vice versa (phase timeline).  Here a block is 12 waves on one CU:
-//   * 8 consumer waves (4 row-waves x 2 channel groups, 2 per SIMD) only read fragments from LDS and issue MFMAs;
-//   * 4 producer waves (1 per SIMD) only move data: the chunk's WEIGHTS arrive by LDS-DMA (global_load_lds_dwordx4:
-//     the packed weight image is already in operand format, so no registers and no conversion), the input WINDOW is
-//     loaded to registers two steps ahead, converted to the operand format and stored one step ahead into the other
-//     of two window buffers.
-// LDS budget (bf16x3): 2 window buffers x 42 KB + ONE weight buffer of 72 KB = 157 KB.  The weight buffer is a ring
-// of the 3 kernel columns: the consumers copy a column's 6 fragments to registers before they multiply with it, so
-// its LDS slot is free again two thirds of a step before the next chunk needs it - the producers refill it then.
-// Step k (one 32-channel chunk of one patch), three block-wide barriers Y1..Y3, all 12 waves:
-//   Y1(k): consumers have read column 0 of k and finished step k-1 | window k stored, column 1 of k landed
-//          C: MFMA column 0, read column 1          P: store window k+1, DMA column 0 of k+1
-//   Y2(k): consumers have read column 1                            | column 2 of k landed
-//          C: MFMA column 1, read column 2          P: DMA column 1 of k+1, load window k+2 to registers
-//   Y3(k): consumers have read column 2                            | column 0 of k+1 landed
-//          C: MFMA column 2, epilogue, read column 0 of k+1        P: DMA column 2 of k+1
-// Barriers are raw s_barrier + explicit counted s_waitcnt: a __syncthreads() would drain the DMAs in flight.
+//   * 8 consumer waves (4 row-waves x 2 channel groups, 2 per SIMD) read fragments from LDS and issue MFMAs;
+//   * 4 mover waves (1 per SIMD) only issue LDS-DMA (global_load_lds_dwordx4, no registers): the chunk's WEIGHTS (the
+//     packed image is already in operand format) and the RAW fp32 input window of the next step, in full 128-byte
+//     lines, into a staging area.
+// Operand conversion of the window (fp32 -> bf16 hi/lo planes, zero padding of the halo) is one short pass of all 12
+// waves between two steps (LDS -> LDS, 3-4 quads per thread).
+// LDS (bf16x3): raw window staging 41 KB + window operand planes 42.5 KB + ONE weight buffer of 72 KB = 155.5 KB.
+// The weight buffer is a ring of the 3 kernel columns: the consumers copy a column's 6 fragments to registers before
+// they multiply with it, so its LDS slot is free again long before the next chunk needs it.
+// Step k (one K-chunk of one 16x16 patch x 64 channels), two block-wide barriers + one LDS counter, all 12 waves:
+//   Y0(k): consumers finished step k-1                   | raw window k and weight column 0 of k have landed
+//          all: convert the window;  C: read column 0    | M: DMA column 2 of k
+//   Y1(k): operand planes complete                       | columns 1 and 2 of k have landed
+//          C: MFMA column 0, read column 1, bump the     | M: DMA column 0 of k+1 and the raw window k+1 (the long,
+//             counter, MFMA columns 1 and 2, epilogue    |    memory-bound burst), then wait for the counter ("all 8
+//                                                        |    consumers have read column 1") and DMA column 1 of k+1
+// The movers sit in the vector-memory issue queue for most of a step; no barrier falls inside that burst, so the
+// consumers never wait for it.
+// Barriers are raw s_barrier + explicit counted s_waitcnt: a __syncthreads() would drain the DMAs in flight.  The
+// consumers never wait on the vector-memory counter inside the loop, so the epilogue's stores drain in the background
+// (all of its loads are issued before its first store).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -35,7 +40,7 @@ __device__ __forceinline__ void ws_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform, 0..31)
+// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform)
 __device__ __forceinline__ void ws_wait_vm(int n) {
 #define DRS_WS_CASE(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
   switch (n) {
@@ -50,7 +55,7 @@ __device__ __forceinline__ void ws_wait_vm(int n) {
 }
 
 #ifdef DRS_WS_TIMELINE
-__device__ unsigned long long drs_ws_tl[32];
+__device__ unsigned long long drs_ws_tl[48];
 #define WS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl[i] += t_ - tl_last; tl_last = t_; } while (0)
 #else
 #define WS_STAMP(i) do { } while (0)
@@ -59,25 +64,42 @@ __device__ unsigned long long drs_ws_tl[32];
 typedef __attribute__((address_space(1))) void* ws_gptr;
 typedef __attribute__((address_space(3))) void* ws_lptr;
 
+template <class P>
+struct WsGeom {
+  static constexpr int KC = 4 * P::SLOT_CH;
+  static constexpr int IW = 18, NPIX = 18 * 18;
+  static constexpr int QPP = KC / 4;                        // 16-byte fp32 quads per pixel and chunk
+  static constexpr int NQUAD = NPIX * QPP;                  // quads of one raw window
+  static constexpr int NPIECE = (NQUAD + 63) / 64;          // 1 KB DMA pieces of one raw window
+  static constexpr int STAGE = NPIECE * 1024;               // bytes of the raw staging area
+  static constexpr int APS = (NPIX * 16 + 255) / 256 * 256 + 64;  // k-group plane stride: 64 B skew = conflict-free quad writes
+  static constexpr int A_IMAGE = 4 * APS;
+  static constexpr int BNB = 64;
+  static constexpr int W_IMAGE = 9 * 4 * BNB * 16;
+  static constexpr int LDS = STAGE + P::IMAGES * (A_IMAGE + W_IMAGE) + 16;  // + the consumers' column-1 counter
+};
+
 template <class P, bool HAS2>
 __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KC = 4 * P::SLOT_CH;
-  constexpr int RPW = 4, NT = 2, BN = 32, BNB = 64, TH = 16, TW = 16;
-  constexpr int A_ITERS = 6;               // window slots per producer thread: 18 x 18 px x 4 k-groups / 256
-  constexpr int V4 = P::SLOT_CH / 4;       // float4 loads per window slot
-  constexpr int NLOAD = A_ITERS * V4;      // vector loads of one window per producer thread
-  constexpr int WPI = P::IMAGES * 12 / 4;  // 1 KB DMA pieces per producer wave and kernel column
-  // the geometry is fixed (18 x 18 window, 64 channels per block): compile-time LDS offsets fold into the ds_read /
-  // ds_write immediates instead of living in one address register per fragment
-  constexpr int IW = 18, NPIX = 18 * 18;
-  constexpr int A_PLANE = (NPIX * 16 + 255) / 256 * 256, A_IMAGE = 4 * A_PLANE + 128, W_IMAGE = 9 * 4 * BNB * 16;
-  constexpr int a_buf = P::IMAGES * A_IMAGE;  // bytes of one window buffer
-  char* sA = smem;                          // [buffer(2)][image][kgroup(4)][window pixel] slots
-  char* sW = smem + 2 * (size_t)a_buf;      // [image][kx(3)][ky(3)][kgroup(4)][BNB] slots
+  using G = WsGeom<P>;
+  constexpr int KC = G::KC, IW = G::IW, QPP = G::QPP, NQUAD = G::NQUAD, NPIECE = G::NPIECE;
+  constexpr int APS = G::APS, A_IMAGE = G::A_IMAGE, W_IMAGE = G::W_IMAGE, BNB = G::BNB;
+  constexpr int RPW = 4, NT = 2, BN = 32, TH = 16, TW = 16;
+  constexpr int WPI = P::IMAGES * 12 / 4;        // weight pieces per mover wave and kernel column
+  constexpr int W2PI = (P::IMAGES * 4 + 3) / 4;  // ... of the second input's single tap
+  constexpr int NPW = (NPIECE + 3) / 4;          // raw window pieces per mover wave (at most)
+  constexpr int CV_ITERS = (NQUAD + 767) / 768;  // conversion quads per thread
+  char* sStage = smem;                           // [window pixel][quad] raw fp32
+  char* sA = smem + G::STAGE;                    // [image][kgroup(4)][window pixel] operand slots
+  char* sW = sA + P::IMAGES * A_IMAGE;           // [image][kx(3)][ky(3)][kgroup(4)][BNB] operand slots
+  typedef __attribute__((address_space(3))) unsigned* ws_flag_ptr;
+  ws_flag_ptr sFlag = (ws_flag_ptr)(sW + P::IMAGES * W_IMAGE);  // consumer waves that have read column 1 so far
+  ws_flag_ptr sFlag2 = sFlag + 1;                                // ... column 2
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 consumers, 8..11 producers
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 consumers, 8..11 movers
+  const bool mover = wid >= 8;
   const int lr = lane & 15, kg = lane >> 4;
 
   // persistent blocks, XCD-aware item order (see tapconv_mfma_kernel)
@@ -101,183 +123,75 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
     n_ = it / g.tiles_y;
   };
 
-  if (wid >= 8) {
-    // =============================== producers ===============================
-    const int pt = tid - 512, pw = wid - 8;
-    constexpr int npix = NPIX;
-    const int ai = pt & 15;
-    const int aq = ((ai & 1) << 1) | (ai >> 3);  // k-group of all of this thread's slots (conflict-free ds_write order)
-    const int ap0 = (pt >> 4) * 4 + ((ai & 7) >> 1);
-    const int a_qoff = aq * A_PLANE + (aq >> 1) * 128;
-    const bool has_add = d.in_add != nullptr;
-    const char* wg = reinterpret_cast<const char*>(d.w);
-    const size_t w_chunk = (size_t)d.wtaps_total * 4 * d.Cout * 16;
-
-    float4 areg[A_ITERS][V4];
-    float4 addreg[V4];
-    unsigned a_ok = 0;
-    bool held_second = false;
-    int vm_issued = 0;  // vector-memory operations this wave has issued so far (program order)
-
-    auto load_window = [&](int k) {
-      const int c = k % nck;
-      int ln, lty0, ltx0, ln0;
-      item_of(k / nck, ln, lty0, ltx0, ln0);
-      held_second = HAS2 && c >= g.nchunks;
-      const int cc = held_second ? c - g.nchunks : c;
-      int a_base[A_ITERS];
-      a_ok = 0;
-      const float* in_n;
-      if (!held_second) {
-        in_n = d.in + (size_t)ln * d.H * d.W * d.in_cs;
+  // ---- mover state -----------------------------------------------------------------------------------------------
+  const int pw = wid - 8;
+  const char* wg = reinterpret_cast<const char*>(d.w);
+  const size_t w_chunk = (size_t)9 * 4 * d.Cout * 16;
+  int vm_issued = 0;               // vector-memory operations this wave has issued so far (program order)
+  int end_col[3] = {0, 0, 0};      // issue count right after the DMA group that fills weight ring slot j
+  int end_win = 0;                 // ... after the raw window group
+  auto issue_col = [&](int col, int c_, int n0_) {
+    const bool second = HAS2 && c_ >= g.nchunks;
+    if (!second) {
 #pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) {
-          const int p = min(ap0 + it * 64, npix - 1);
-          const int py = p / IW, px = p - py * IW;
-          const int iy = lty0 - 1 + py, ix = ltx0 - 1 + px;
-          const bool ok = (ap0 + it * 64) < npix && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-          const int iyc = min(max(iy, 0), d.H - 1), ixc = min(max(ix, 0), d.W - 1);
-          a_base[it] = (iyc * d.W + ixc) * d.in_cs + d.in_co + cc * KC + aq * P::SLOT_CH;
-          a_ok |= (ok ? 1u : 0u) << it;
-        }
-      } else {
-        in_n = d.in2 + (size_t)ln * d.H2 * d.W2 * d.in2_cs;
-#pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) {
-          const int p = min(ap0 + it * 64, npix - 1);
-          const int py = p / IW, px = p - py * IW;
-          const int iy = lty0 + py, ix = ltx0 + px;
-          const bool ok = (ap0 + it * 64) < npix && py < TH && px < TW && iy < d.H2 && ix < d.W2;
-          const int iyc = min(iy, d.H2 - 1), ixc = min(ix, d.W2 - 1);
-          a_base[it] = (iyc * d.W2 + ixc) * d.in2_cs + d.in2_co + cc * KC + aq * P::SLOT_CH;
-          a_ok |= (ok ? 1u : 0u) << it;
-        }
+      for (int i = 0; i < WPI; ++i) {
+        const int idx = pw * WPI + i;  // (image, ky, k-group) piece of this wave
+        const int im = idx / 12, ky = (idx % 12) >> 2, kq = idx & 3;
+        const char* src = wg + (size_t)im * g.w_gimage + (size_t)c_ * w_chunk +
+                          ((size_t)((ky * 3 + col) * 4 + kq) * d.Cout + n0_ + lane) * 16;
+        char* dst = sW + (size_t)im * W_IMAGE + (size_t)((col * 3 + ky) * 4 + kq) * BNB * 16;
+        __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
       }
+      vm_issued += WPI;
+    } else if (col == 0) {  // second input: one tap, stored where (kx 0, ky 0) lives
+      const int cc = c_ - g.nchunks;
 #pragma unroll
-      for (int v = 0; v < V4; ++v) {
-#pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) areg[it][v] = *reinterpret_cast<const float4*>(in_n + a_base[it] + 4 * v);
-      }
-      vm_issued += NLOAD;
-      if (has_add && !held_second) {
-#pragma unroll
-        for (int v = 0; v < V4; ++v)
-          addreg[v] = *reinterpret_cast<const float4*>(d.in_add + (size_t)ln * d.in_add_cs + cc * KC + aq * P::SLOT_CH + 4 * v);
-        vm_issued += V4;
-      }
-    };
-    auto store_window = [&](int buf) {
-      char* dst = sA + (size_t)buf * a_buf;
-#pragma unroll
-      for (int it = 0; it < A_ITERS; ++it) {
-        const int p = ap0 + it * 64;
-        const bool ok = (a_ok >> it) & 1u;
-        float x[P::SLOT_CH];
-#pragma unroll
-        for (int v = 0; v < V4; ++v) {
-          float4 a = areg[it][v];
-          if (has_add && !held_second) {
-            a.x += addreg[v].x; a.y += addreg[v].y; a.z += addreg[v].z; a.w += addreg[v].w;
-          }
-          x[4 * v] = ok ? a.x : 0.f; x[4 * v + 1] = ok ? a.y : 0.f; x[4 * v + 2] = ok ? a.z : 0.f; x[4 * v + 3] = ok ? a.w : 0.f;
-        }
-        if (p < npix) P::cvt_store(dst + a_qoff, A_IMAGE, (size_t)p * 16, x);
-      }
-    };
-    // DMA kernel column `col` of step k's weights into ring slot `col`; returns the issue count after the group
-    int w_c = 0, w_n0 = 0;  // chunk and first output channel of the step whose weights are being fetched
-    auto set_w = [&](int k) {
-      int ln, lty0, ltx0;
-      w_c = k % nck;
-      item_of(k / nck, ln, lty0, ltx0, w_n0);
-    };
-    auto issue_w = [&](int col) {
-      const int c = w_c, ln0 = w_n0;
-      const bool second = HAS2 && c >= g.nchunks;
-      if (!second) {
-#pragma unroll
-        for (int i = 0; i < WPI; ++i) {
-          const int idx = pw * WPI + i;  // (image, ky, k-group) piece of this wave
-          const int im = idx / 12, ky = (idx % 12) >> 2, kq = idx & 3;
-          const char* src = wg + (size_t)im * g.w_gimage + (size_t)c * w_chunk +
-                            ((size_t)((ky * 3 + col) * 4 + kq) * d.Cout + ln0 + lane) * 16;
-          char* dst = sW + (size_t)im * W_IMAGE + (size_t)((col * 3 + ky) * 4 + kq) * BNB * 16;
-          __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
-        }
-        vm_issued += WPI;
-      } else if (col == 0) {  // second input: one tap = IMAGES x 4 pieces, stored where (kx 0, ky 0) lives
-        const int cc = c - g.nchunks;
-#pragma unroll
-        for (int i = 0; i < (P::IMAGES * 4 + 3) / 4; ++i) {
-          const int idx = pw * ((P::IMAGES * 4 + 3) / 4) + i;
-          const int im = idx >> 2, kq = idx & 3;
+      for (int i = 0; i < W2PI; ++i) {
+        const int idx = pw * W2PI + i;
+        const int im = idx >> 2, kq = idx & 3;
+        if (im < P::IMAGES) {
           const char* src = reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage +
-                            ((size_t)(cc * 4 + kq) * d.Cout + ln0 + lane) * 16;
+                            ((size_t)(cc * 4 + kq) * d.Cout + n0_ + lane) * 16;
           char* dst = sW + (size_t)im * W_IMAGE + (size_t)kq * BNB * 16;
           __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
+          vm_issued += 1;
         }
-        vm_issued += (P::IMAGES * 4 + 3) / 4;
       }
-      return vm_issued;
-    };
-
-    int end_col[3];  // issue count right after the DMA group that fills ring slot j
-#ifdef DRS_WS_TIMELINE
-    unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_amdgcn_s_memtime();
-#endif
-    set_w(0);
-    end_col[0] = issue_w(0);
-    end_col[1] = issue_w(1);
-    end_col[2] = issue_w(2);
-    load_window(0);
-    store_window(0);
-    if (S > 1) load_window(1);
-    ws_wait_vm(vm_issued - end_col[2]);  // all three columns of step 0 landed
-    ws_wait_lds();
-    ws_barrier();  // P0
-    WS_STAMP(0);
-    for (int k = 0; k < S; ++k) {
-      const bool more = k + 1 < S;
-      ws_wait_vm(vm_issued - end_col[1]);  // column 1 of k landed
-      ws_wait_lds();                       // window k stored
-      WS_STAMP(1);
-      ws_barrier();                        // Y1
-      WS_STAMP(2);
-      if (more) {
-        store_window((k + 1) & 1);
-        set_w(k + 1);
-        end_col[0] = issue_w(0);
+    }
+    end_col[col] = vm_issued;
+  };
+  // raw fp32 window of a step -> staging, 128-byte lines; pieces [i0, i1) of this wave's share
+  auto issue_win = [&](int c_, int n_, int ty_, int tx_, int i0, int i1) {
+    const bool second = HAS2 && c_ >= g.nchunks;
+    const int cc = second ? c_ - g.nchunks : c_;
+    int lane_o = lane;  // opaque: the per-piece address arithmetic is recomputed here, not hoisted (and spilled)
+    asm volatile("" : "+v"(lane_o));
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int j = pw + 4 * i;  // piece (wave-uniform)
+      if (i >= i0 && i < i1 && j < NPIECE) {
+        const int e = min(j * 64 + lane_o, NQUAD - 1);
+        const int p = e / QPP, quad = e % QPP, py = p / IW, px = p % IW;
+        const float* src;
+        if (!second) {
+          const int iy = min(max(ty_ - 1 + py, 0), d.H - 1), ix = min(max(tx_ - 1 + px, 0), d.W - 1);
+          src = d.in + ((size_t)n_ * d.H * d.W + (size_t)(iy * d.W + ix)) * d.in_cs + d.in_co + cc * KC + quad * 4;
+        } else {
+          const int iy = min(ty_ + py, d.H2 - 1), ix = min(tx_ + px, d.W2 - 1);
+          src = d.in2 + ((size_t)n_ * d.H2 * d.W2 + (size_t)(iy * d.W2 + ix)) * d.in2_cs + d.in2_co + cc * KC + quad * 4;
+        }
+        __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)(sStage + j * 1024), 16, 0, 0);
+        vm_issued += 1;
       }
-      WS_STAMP(3);
-      ws_wait_vm(vm_issued - end_col[2]);  // column 2 of k landed
-      WS_STAMP(1);
-      ws_barrier();                        // Y2
-      WS_STAMP(4);
-      if (more) end_col[1] = issue_w(1);
-      if (k + 2 < S) load_window(k + 2);
-      WS_STAMP(5);
-      ws_wait_vm(vm_issued - end_col[0]);  // column 0 of k+1 landed
-      WS_STAMP(1);
-      ws_barrier();                        // Y3
-      WS_STAMP(6);
-      if (more) end_col[2] = issue_w(2);
-      WS_STAMP(7);
     }
-    ws_wait_vm(0);
-#ifdef DRS_WS_TIMELINE
-    if (blockIdx.x == 0 && wid == 8 && lane == 0) {
-      for (int i = 0; i < 8; ++i) drs_ws_tl[16 + i] = tl[i];
-      drs_ws_tl[24] = S;
-    }
-#endif
-    return;
-  }
+    end_win = vm_issued;
+  };
 
-  // =============================== consumers ===============================
-  const int rw = wid & 3;   // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
-  const int ng = wid >> 2;  // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
-  const int kg_off = kg * A_PLANE + (kg >> 1) * 128 + (rw * RPW * IW + lr) * 16;  // this lane's window origin
-  const char* wbase = sW + ((size_t)kg * BNB + ng * NT * 16 + lr) * 16;                   // this lane's weight origin
+  // ---- consumer state --------------------------------------------------------------------------------------------
+  const int rw = wid & 3;         // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
+  const int ng = (wid >> 2) & 1;  // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
+  const char* win = sA + kg * APS + (rw * RPW * IW + lr) * 16;           // this lane's window origin
+  const char* wbase = sW + ((size_t)kg * BNB + ng * NT * 16 + lr) * 16;  // this lane's weight origin
   f32x4 acc[RPW][NT];
   typename P::Frag wf[3][NT];
   auto read_wf = [&](int col) {
@@ -287,7 +201,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
       for (int t = 0; t < NT; ++t)
         wf[ky][t] = P::load(wbase, W_IMAGE, (size_t)(((col * 3 + ky) * 4 * BNB) + t * 16) * 16);
   };
-  auto mma_col = [&](const char* win, int col) {
+  auto mma_col = [&](int col) {
 #pragma unroll
     for (int wr = 0; wr < RPW + 2; ++wr) {
       const typename P::Frag af = P::load(win, A_IMAGE, (size_t)(wr * IW + col) * 16);
@@ -301,66 +215,171 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
       }
     }
   };
-  ws_barrier();  // P0
+  // ---- window conversion: raw staging -> operand planes, all 768 threads -------------------------------------------
+  int cv_src[CV_ITERS], cv_dst[CV_ITERS], cv_yx[CV_ITERS];  // chunk-independent per-thread quad descriptors
+#pragma unroll
+  for (int it = 0; it < CV_ITERS; ++it) {
+    const int e = min(tid + it * 768, NQUAD - 1);
+    const int p = e / QPP, quad = e % QPP;
+    cv_src[it] = e * 16;
+    cv_dst[it] = P::IMAGES == 2 ? (quad >> 1) * APS + p * 16 + (quad & 1) * 8 : quad * APS + p * 16;
+    cv_yx[it] = ((p / IW) << 8) | (p % IW);
+  }
+  auto convert = [&](bool second, int ty_, int tx_) {
+    // patches whose window lies inside the image need no zero padding (wave-uniform test)
+    const bool interior = second ? (ty_ + TH <= d.H2 && tx_ + TW <= d.W2)
+                                 : (ty_ >= 1 && ty_ + TH + 1 <= d.H && tx_ >= 1 && tx_ + TW + 1 <= d.W);
+    f32x4 v[CV_ITERS];
+#pragma unroll
+    for (int it = 0; it < CV_ITERS; ++it) v[it] = *reinterpret_cast<const f32x4*>(sStage + cv_src[it]);  // all reads in flight
+    if (!interior) {
+#pragma unroll
+      for (int it = 0; it < CV_ITERS; ++it) {
+        const int py = cv_yx[it] >> 8, px = cv_yx[it] & 255;
+        bool ok;
+        if (!second) {
+          const int iy = ty_ - 1 + py, ix = tx_ - 1 + px;
+          ok = iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+        } else {
+          ok = py < TH && px < TW && ty_ + py < d.H2 && tx_ + px < d.W2;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[it][j] = ok ? v[it][j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < CV_ITERS; ++it) {
+      if (it < CV_ITERS - 1 || tid + it * 768 < NQUAD) {
+        if constexpr (P::IMAGES == 2) {
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          bf16x4 h, l;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            h[j] = (__bf16)v[it][j];
+            l[j] = (__bf16)(v[it][j] - (float)h[j]);
+          }
+          *reinterpret_cast<bf16x4*>(sA + cv_dst[it]) = h;
+          *reinterpret_cast<bf16x4*>(sA + cv_dst[it] + A_IMAGE) = l;
+        } else {
+          *reinterpret_cast<f32x4*>(sA + cv_dst[it]) = v[it];
+        }
+      }
+    }
+  };
+
 #ifdef DRS_WS_TIMELINE
   unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_amdgcn_s_memtime();
 #endif
-  read_wf(0);
-  int n = 0, ty0 = 0, tx0 = 0, n0 = 0;
-  for (int k = 0; k < S; ++k) {
-    const int c = k % nck;
-    if (c == 0) {
-      item_of(k / nck, n, ty0, tx0, n0);
-#pragma unroll
-      for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 2) __hip_atomic_store(sFlag + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  ws_wait_lds();
+  ws_barrier();
+  int c = -1, ord = -1, n = 0, ty0 = 0, tx0 = 0, n0 = 0;  // current step: chunk, item ordinal, item coordinates
+  if (mover) {
+    // ===================== movers =====================
+    {
+      int n_, ty_, tx_, n0_;
+      item_of(0, n_, ty_, tx_, n0_);
+      issue_win(0, n_, ty_, tx_, 0, NPW);
+      issue_col(0, 0, n0_);
+      issue_col(1, 0, n0_);
+      issue_col(2, 0, n0_);
     }
-    const char* win = sA + (size_t)(k & 1) * a_buf + kg_off;
-    WS_STAMP(0);
-    ws_wait_lds();
-    ws_barrier();  // Y1
-    WS_STAMP(1);
-    if (HAS2 && c >= g.nchunks) {  // second input: one tap, window origin; columns 1 and 2 are empty
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        const typename P::Frag af = P::load(win, A_IMAGE, (size_t)(r * IW) * 16);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[0][t], af, acc[r][t]);
-      }
+    for (int k = 0; k < S; ++k) {
+      if (++c == nck) c = 0;
+      if (c == 0) item_of(++ord, n, ty0, tx0, n0);
+      const bool second = HAS2 && c >= g.nchunks;
+      WS_STAMP(0);
+      ws_wait_vm(k ? vm_issued - max(end_win, end_col[0]) : 0);  // raw window k and column 0 of k have landed
+      WS_STAMP(1);
+      ws_barrier();  // Y0
+      WS_STAMP(2);
+      convert(second, ty0, tx0);
       ws_wait_lds();
-      ws_barrier();  // Y2
-      ws_barrier();  // Y3
-    } else {
-      mma_col(win, 0);
-      read_wf(1);
+      ws_wait_vm(vm_issued - max(end_col[1], end_col[2]));  // columns 1 and 2 of k
+      WS_STAMP(3);
+      ws_barrier();  // Y1
+      WS_STAMP(4);
+      if (k + 1 < S) {
+        int c1 = c + 1, n1 = n, ty1 = ty0, tx1 = tx0, n01 = n0;
+        if (c1 == nck) {
+          c1 = 0;
+          item_of(ord + 1, n1, ty1, tx1, n01);
+        }
+        issue_col(0, c1, n01);
+        issue_win(c1, n1, ty1, tx1, 0, NPW);
+        WS_STAMP(5);
+        const unsigned target = 8u * (unsigned)(k + 1);
+        while (__hip_atomic_load(sFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(4);  // every consumer wave has read column 1 of k
+        WS_STAMP(6);
+        issue_col(1, c1, n01);
+        while (__hip_atomic_load(sFlag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(4);
+        issue_col(2, c1, n01);
+      }
+      WS_STAMP(7);
+    }
+  } else {
+    // ===================== consumers =====================
+    for (int k = 0; k < S; ++k) {
+      if (++c == nck) c = 0;
+      if (c == 0) {
+        item_of(++ord, n, ty0, tx0, n0);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const bool second = HAS2 && c >= g.nchunks;
+      WS_STAMP(0);
+      ws_wait_lds();
+      ws_barrier();  // Y0
+      WS_STAMP(1);
+      convert(second, ty0, tx0);
+      read_wf(0);
       WS_STAMP(2);
       ws_wait_lds();
-      ws_barrier();  // Y2
+      ws_barrier();  // Y1
       WS_STAMP(3);
-      mma_col(win, 1);
-      read_wf(2);
-      WS_STAMP(4);
-      ws_wait_lds();
-      ws_barrier();  // Y3
-      WS_STAMP(5);
-      mma_col(win, 2);
+      if (second) {  // second input: one tap, window origin; columns 1 and 2 are empty
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const typename P::Frag af = P::load(win, A_IMAGE, (size_t)(r * IW) * 16);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[0][t], af, acc[r][t]);
+        }
+        ws_wait_lds();
+        if (lane == 0) {
+          __hip_atomic_fetch_add(sFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(sFlag2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        mma_col(0);
+        read_wf(1);
+        WS_STAMP(4);
+        ws_wait_lds();
+        if (lane == 0) __hip_atomic_fetch_add(sFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // column 1 is in registers: its ring slot may be refilled
+        WS_STAMP(5);
+        mma_col(1);
+        read_wf(2);
+        ws_wait_lds();
+        if (lane == 0) __hip_atomic_fetch_add(sFlag2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        mma_col(2);
+      }
       WS_STAMP(6);
+      if (c == nck - 1) {
+        // opaque copies of the lane coordinates: everything the epilogue derives from them is computed here, not hoisted
+        // out of the step loop (where it would be spilled and reloaded with vmcnt(0) waits between the stores)
+        int lr_e = lr, kg_e = kg;
+        asm volatile("" : "+v"(lr_e), "+v"(kg_e));
+        tile_epilogue<RPW, NT, false, RPW>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
+      }
+      WS_STAMP(7);
     }
-    if (c == nck - 1) {
-      // opaque copies of the lane coordinates: everything the epilogue derives from them is computed here, not hoisted
-      // out of the step loop (where it would be spilled and reloaded with vmcnt(0) waits between the stores)
-      int lr_e = lr, kg_e = kg;
-      asm volatile("" : "+v"(lr_e), "+v"(kg_e));
-      tile_epilogue<RPW, NT, false, RPW>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
-    }
-    if (k + 1 < S) read_wf(0);
-    WS_STAMP(7);
   }
+  if (mover) ws_wait_vm(0);
 #ifdef DRS_WS_TIMELINE
-  if (blockIdx.x == 0 && wid == 0 && lane == 0) {
-    for (int i = 0; i < 8; ++i) drs_ws_tl[i] = tl[i];
-    drs_ws_tl[8] = S;
+  if (blockIdx.x == 0 && (wid == 0 || wid == 4 || wid == 8) && lane == 0) {
+    for (int i = 0; i < 8; ++i) drs_ws_tl[(wid == 0 ? 0 : (wid == 4 ? 32 : 16)) + i] = tl[i];
+    drs_ws_tl[wid == 0 ? 8 : (wid == 4 ? 40 : 24)] = S;
   }
 #endif
 }
@@ -373,7 +392,7 @@ bool ws_std3x3(const TapConv& d) {
 }
 
 template <class P, bool HAS2>
-int ws_launch(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t s) {
+int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
   auto kern = tapconv_ws_kernel<P, HAS2>;
   static bool attr_done = false;
   static int num_cu = 0;
@@ -385,21 +404,25 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t s) {
     DRS_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_done = true;
   }
+  static_assert(WsGeom<P>::LDS <= 160 * 1024, "LDS budget");
   const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / 64);
   long long blocks = num_cu;  // one 12-wave block per CU
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), lds, s, d, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), WsGeom<P>::LDS, s, d, g);
   DRS_CHECK_HIP(hipGetLastError());
 #ifdef DRS_WS_TIMELINE
   {
-    unsigned long long h[32];
+    unsigned long long h[48];
     DRS_CHECK_HIP(hipStreamSynchronize(s));
     DRS_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(drs_ws_tl), sizeof(h)));
     const double sc = h[8] ? 1.0 / (double)h[8] : 0.0;
-    fprintf(stderr, "ws Cin=%d Cout=%d TH=%d S=%llu | C: preY1 %.0f Y1 %.0f col0 %.0f Y2 %.0f col1 %.0f Y3 %.0f col2 %.0f epi+rd %.0f | P: wait %.0f Y1 %.0f st+dma0 %.0f Y2 %.0f dma1+ld %.0f Y3 %.0f dma2 %.0f\n",
-            d.Cin, d.Cout, d.TH, h[8], h[0] * sc, h[1] * sc, h[2] * sc, h[3] * sc, h[4] * sc, h[5] * sc, h[6] * sc, h[7] * sc,
+    fprintf(stderr, "ws Cin=%d Cout=%d TH=%d in2=%d S=%llu | C: epi>Y0 %.0f cvt+rd0 %.0f >Y1 %.0f col0+rd1 %.0f flag %.0f col1,2 %.0f epi %.0f | "
+            "M: vmwait %.0f Y0 %.0f cvt+dma2 %.0f Y1 %.0f dma0+win %.0f poll %.0f dma1 %.0f\n",
+            d.Cin, d.Cout, d.TH, d.in2 ? d.Cin2 : 0, h[8], (h[0] + h[1]) * sc, h[2] * sc, h[3] * sc, h[4] * sc, h[5] * sc, h[6] * sc, h[7] * sc,
             h[17] * sc, h[18] * sc, h[19] * sc, h[20] * sc, h[21] * sc, h[22] * sc, h[23] * sc);
+    fprintf(stderr, "   wave4 C: epi>Y0 %.0f cvt+rd0 %.0f >Y1 %.0f col0+rd1 %.0f flag %.0f col1,2 %.0f epi %.0f\n", (h[32] + h[33]) * sc,
+            h[34] * sc, h[35] * sc, h[36] * sc, h[37] * sc, h[38] * sc, h[39] * sc);
   }
 #endif
   return DRS_OK;
@@ -407,24 +430,22 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t s) {
 
 }  // namespace
 
-// Eligibility of the wave-specialised kernel; `g` must come from the CONV3X3 / NWG = 2 geometry of conv_mfma.hip.
+// Eligibility of the wave-specialised kernel (the caller has established the CONV3X3 / 512-thread geometry).
 bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
   static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 0;
   if (!env) return false;
   if (impl != DRS_IMPL_MFMA_BF16X3 && impl != DRS_IMPL_MFMA_F32) return false;
   const int KC = impl == DRS_IMPL_MFMA_F32 ? 16 : 32;
-  if (!d.in || !ws_std3x3(d) || d.fuse_out || d.shared_cu || d.gate) return false;
+  if (!d.in || !ws_std3x3(d) || d.fuse_out || d.shared_cu || d.gate || d.in_add) return false;
   if (d.Cout % 64 != 0 || d.Cin % KC != 0 || d.TH <= 8) return false;
-  if (d.in2 && (d.Cin2 % KC != 0)) return false;
+  if ((d.in_cs & 3) || (d.in_co & 3)) return false;
+  if (d.in2 && (d.Cin2 % KC != 0 || (d.in2_cs & 3) || (d.in2_co & 3))) return false;
   return true;
 }
 
 int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStream_t s) {
-  const size_t lds = (size_t)(impl == DRS_IMPL_MFMA_F32 ? 1 : 2) * (2 * (size_t)g.a_image + g.w_image);
-  DRS_REQUIRE(lds <= 160 * 1024, DRS_ERR_SHAPE, "tapconv_ws: %zu bytes of LDS", lds);
-  DRS_REQUIRE(g.IH == 18 && g.IW == 18 && g.w_image == 9 * 4 * 64 * 16 && g.a_plane == 5376 && g.a_image == 4 * 5376 + 128,
-              DRS_ERR_SHAPE, "tapconv_ws: geometry");
+  DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_ws: geometry");
   if (impl == DRS_IMPL_MFMA_F32)
-    return d.in2 ? ws_launch<PolicyF32, true>(d, g, lds, s) : ws_launch<PolicyF32, false>(d, g, lds, s);
-  return d.in2 ? ws_launch<PolicyBF16X3, true>(d, g, lds, s) : ws_launch<PolicyBF16X3, false>(d, g, lds, s);
+    return d.in2 ? ws_launch<PolicyF32, true>(d, g, s) : ws_launch<PolicyF32, false>(d, g, s);
+  return d.in2 ? ws_launch<PolicyBF16X3, true>(d, g, s) : ws_launch<PolicyBF16X3, false>(d, g, s);
 }
