@@ -1,6 +1,6 @@
 // Wave-specialised 3x3 stride-1 tap-convolution for the wide layers (Cout % 64 == 0, Cin % KC == 0).
 //
-// Same GEMM view, LDS slot layout, MFMA schedule and epilogue as tapconv_mfma_kernel<.., CONV3X3, .., NWG = 2>
+// Same GEMM view, operand slots, MFMA schedule and epilogue as tapconv_mfma_kernel<.., CONV3X3, .., NWG = 2>
 // (conv_mfma.hip); what changes is WHO moves the operands and WHEN.  In that kernel every wave alternates between
 // "issue the loads of the next chunk" (the wave sits in the vector-memory queue for a memory round trip), "convert +
 // store to LDS" and "multiply", all 8 waves of a CU in lock step: the memory system idles while the matrix cores run
@@ -9,23 +9,26 @@
 //   * 4 mover waves (1 per SIMD) only issue LDS-DMA (global_load_lds_dwordx4, no registers): the chunk's WEIGHTS (the
 //     packed image is already in operand format) and the RAW fp32 input window of the next step, in full 128-byte
 //     lines, into a staging area.
-// Operand conversion of the window (fp32 -> bf16 hi/lo planes, zero padding of the halo) is one short pass of all 12
-// waves between two steps (LDS -> LDS, 3-4 quads per thread).
+// Operand conversion of the window (fp32 -> bf16 hi/lo planes, zero padding of the halo) is one short LDS -> LDS pass
+// of the consumer waves between two steps (5-6 quads per thread, each element converted once).
 // LDS (bf16x3): raw window staging 41 KB + window operand planes 42.5 KB + ONE weight buffer of 72 KB = 155.5 KB.
 // The weight buffer is a ring of the 3 kernel columns: the consumers copy a column's 6 fragments to registers before
 // they multiply with it, so its LDS slot is free again long before the next chunk needs it.
-// Step k (one K-chunk of one 16x16 patch x 64 channels), two block-wide barriers + one LDS counter, all 12 waves:
+// Step k (one K-chunk of one 16x16 patch x 64 channels): two block-wide barriers + three LDS counters:
 //   Y0(k): consumers finished step k-1                   | raw window k and weight column 0 of k have landed
-//          all: convert the window;  C: read column 0    | M: DMA column 2 of k
-//   Y1(k): operand planes complete                       | columns 1 and 2 of k have landed
-//          C: MFMA column 0, read column 1, bump the     | M: DMA column 0 of k+1 and the raw window k+1 (the long,
-//             counter, MFMA columns 1 and 2, epilogue    |    memory-bound burst), then wait for the counter ("all 8
-//                                                        |    consumers have read column 1") and DMA column 1 of k+1
-// The movers sit in the vector-memory issue queue for most of a step; no barrier falls inside that burst, so the
-// consumers never wait for it.
+//          C: convert the window, read column 0          | M: nothing (the staging area is being read)
+//   Y1(k): operand planes complete                       | column 1 of k has landed
+//          C: MFMA column 0, read column 1, bump F1,     | M: bump L2 once column 2 of k has landed, then DMA column 0
+//             MFMA column 1, wait L2, read column 2,     |    of k+1 and the raw window k+1 (the long, memory-bound
+//             bump F2, MFMA column 2, epilogue           |    burst), wait F1 -> DMA column 1, wait F2 -> DMA column 2
+//   F1 / F2 count consumer waves that hold column 1 / 2 in registers (ring slot free), L2 counts mover waves whose part
+//   of column 2 has landed.  The movers sit in the vector-memory issue queue for most of a step; no barrier falls inside
+//   that burst, so the consumers never wait for it.
 // Barriers are raw s_barrier + explicit counted s_waitcnt: a __syncthreads() would drain the DMAs in flight.  The
 // consumers never wait on the vector-memory counter inside the loop, so the epilogue's stores drain in the background
 // (all of its loads are issued before its first store).
+// Measured (DRS_WS_TIMELINE build, up_convs.1, ticks per step): conversion 2050, MFMA phase 8180 for 432 MFMAs per
+// SIMD (16 cycles each = 6912: the matrix pipe is the bound inside that phase), epilogue share 690, barrier waits 800.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -76,7 +79,7 @@ struct WsGeom {
   static constexpr int A_IMAGE = 4 * APS;
   static constexpr int BNB = 64;
   static constexpr int W_IMAGE = 9 * 4 * BNB * 16;
-  static constexpr int LDS = STAGE + P::IMAGES * (A_IMAGE + W_IMAGE) + 16;  // + the consumers' column-1 counter
+  static constexpr int LDS = STAGE + P::IMAGES * (A_IMAGE + W_IMAGE) + 16;  // + the three counters
 };
 
 template <class P, bool HAS2>
@@ -89,13 +92,14 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   constexpr int WPI = P::IMAGES * 12 / 4;        // weight pieces per mover wave and kernel column
   constexpr int W2PI = (P::IMAGES * 4 + 3) / 4;  // ... of the second input's single tap
   constexpr int NPW = (NPIECE + 3) / 4;          // raw window pieces per mover wave (at most)
-  constexpr int CV_ITERS = (NQUAD + 767) / 768;  // conversion quads per thread
+  constexpr int CV_ITERS = (NQUAD + 511) / 512;  // conversion quads per consumer thread
   char* sStage = smem;                           // [window pixel][quad] raw fp32
   char* sA = smem + G::STAGE;                    // [image][kgroup(4)][window pixel] operand slots
   char* sW = sA + P::IMAGES * A_IMAGE;           // [image][kx(3)][ky(3)][kgroup(4)][BNB] operand slots
   typedef __attribute__((address_space(3))) unsigned* ws_flag_ptr;
   ws_flag_ptr sFlag = (ws_flag_ptr)(sW + P::IMAGES * W_IMAGE);  // consumer waves that have read column 1 so far
   ws_flag_ptr sFlag2 = sFlag + 1;                                // ... column 2
+  ws_flag_ptr sLand2 = sFlag + 2;                                // mover waves whose part of column 2 has landed
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 consumers, 8..11 movers
@@ -215,11 +219,12 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
       }
     }
   };
-  // ---- window conversion: raw staging -> operand planes, all 768 threads -------------------------------------------
+  // ---- window conversion: raw staging -> operand planes, the 512 consumer threads (the movers, youngest waves of their
+  //      SIMDs, would finish last and stretch the phase) -------------------------------------------
   int cv_src[CV_ITERS], cv_dst[CV_ITERS], cv_yx[CV_ITERS];  // chunk-independent per-thread quad descriptors
 #pragma unroll
   for (int it = 0; it < CV_ITERS; ++it) {
-    const int e = min(tid + it * 768, NQUAD - 1);
+    const int e = min(tid + it * 512, NQUAD - 1);
     const int p = e / QPP, quad = e % QPP;
     cv_src[it] = e * 16;
     cv_dst[it] = P::IMAGES == 2 ? (quad >> 1) * APS + p * 16 + (quad & 1) * 8 : quad * APS + p * 16;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
     }
 #pragma unroll
     for (int it = 0; it < CV_ITERS; ++it) {
-      if (it < CV_ITERS - 1 || tid + it * 768 < NQUAD) {
+      if (it < CV_ITERS - 1 || tid + it * 512 < NQUAD) {
         if constexpr (P::IMAGES == 2) {
           typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
           bf16x4 h, l;
@@ -269,8 +274,9 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
 
 #ifdef DRS_WS_TIMELINE
   unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long tl_begin = tl_last;
 #endif
-  if (tid < 2) __hip_atomic_store(sFlag + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (tid < 3) __hip_atomic_store(sFlag + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   ws_wait_lds();
   ws_barrier();
   int c = -1, ord = -1, n = 0, ty0 = 0, tx0 = 0, n0 = 0;  // current step: chunk, item ordinal, item coordinates
@@ -293,12 +299,13 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
       WS_STAMP(1);
       ws_barrier();  // Y0
       WS_STAMP(2);
-      convert(second, ty0, tx0);
-      ws_wait_lds();
-      ws_wait_vm(vm_issued - max(end_col[1], end_col[2]));  // columns 1 and 2 of k
+      ws_wait_vm(vm_issued - end_col[1]);  // column 1 of k
       WS_STAMP(3);
       ws_barrier();  // Y1
       WS_STAMP(4);
+      // column 2 of k was issued last in the previous burst and is read late in the step: certified by a counter
+      ws_wait_vm(vm_issued - end_col[2]);
+      if (lane == 0) __hip_atomic_fetch_add(sLand2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (k + 1 < S) {
         int c1 = c + 1, n1 = n, ty1 = ty0, tx1 = tx0, n01 = n0;
         if (c1 == nck) {
@@ -359,6 +366,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
         if (lane == 0) __hip_atomic_fetch_add(sFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // column 1 is in registers: its ring slot may be refilled
         WS_STAMP(5);
         mma_col(1);
+        while (__hip_atomic_load(sLand2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)(k + 1)) __builtin_amdgcn_s_sleep(2);
         read_wf(2);
         ws_wait_lds();
         if (lane == 0) __hip_atomic_fetch_add(sFlag2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -380,6 +388,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   if (blockIdx.x == 0 && (wid == 0 || wid == 4 || wid == 8) && lane == 0) {
     for (int i = 0; i < 8; ++i) drs_ws_tl[(wid == 0 ? 0 : (wid == 4 ? 32 : 16)) + i] = tl[i];
     drs_ws_tl[wid == 0 ? 8 : (wid == 4 ? 40 : 24)] = S;
+    if (wid == 0) drs_ws_tl[9] = __builtin_amdgcn_s_memtime() - tl_begin;
   }
 #endif
 }
@@ -414,9 +423,19 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 #ifdef DRS_WS_TIMELINE
   {
     unsigned long long h[48];
+    hipEvent_t e0, e1;
+    float ms = 0.f;
+    DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
+    DRS_CHECK_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), WsGeom<P>::LDS, s, d, g);  // timed repeat (same result)
+    DRS_CHECK_HIP(hipEventRecord(e1, s));
     DRS_CHECK_HIP(hipStreamSynchronize(s));
+    DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     DRS_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(drs_ws_tl), sizeof(h)));
     const double sc = h[8] ? 1.0 / (double)h[8] : 0.0;
+    fprintf(stderr, "ws kernel %.1f us, block 0 wave 0 alive %llu ticks (%.2f GHz if it spans the launch), %lld blocks\n", ms * 1e3, h[9],
+            h[9] / (ms * 1e6), blocks);
     fprintf(stderr, "ws Cin=%d Cout=%d TH=%d in2=%d S=%llu | C: epi>Y0 %.0f cvt+rd0 %.0f >Y1 %.0f col0+rd1 %.0f flag %.0f col1,2 %.0f epi %.0f | "
             "M: vmwait %.0f Y0 %.0f cvt+dma2 %.0f Y1 %.0f dma0+win %.0f poll %.0f dma1 %.0f\n",
             d.Cin, d.Cout, d.TH, d.in2 ? d.Cin2 : 0, h[8], (h[0] + h[1]) * sc, h[2] * sc, h[3] * sc, h[4] * sc, h[5] * sc, h[6] * sc, h[7] * sc,
@@ -432,7 +451,7 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 
 // Eligibility of the wave-specialised kernel (the caller has established the CONV3X3 / 512-thread geometry).
 bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
-  static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 0;
+  static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 1;
   if (!env) return false;
   if (impl != DRS_IMPL_MFMA_BF16X3 && impl != DRS_IMPL_MFMA_F32) return false;
   const int KC = impl == DRS_IMPL_MFMA_F32 ? 16 : 32;
