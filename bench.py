@@ -255,7 +255,7 @@ def main():
         with torch.no_grad():
             x.copy_(x_cpu)
             ops = engine.profile_forward(x, t.fill_(750), lr, MAG, iters=5)
-        # dominant kernel = the 3x3 stride-1 implicit-GEMM instantiation (tapconv_mfma_kernel<policy, 32, 4, CONV3X3>):
+        # dominant kernel = the 3x3 stride-1 implicit-GEMM family (tapconv_ws_kernel / tapconv_mfma_kernel<.., CONV3X3>):
         # every conv1 / conv2 / skip conv of the residual blocks, ups.*.conv and up_convs.0/1 (up_convs.2 is the
         # fused-projection instantiation and is listed separately).  achieved = algorithmic FLOPs of those launches
         # (2*MACs) / their HIP-event durations, i.e. FLOPs per launch / average launch duration.
@@ -275,18 +275,20 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if args.impl == "mfma_bf16x3" and os.path.exists(tpath):  # PMC passes cannot run inside this process
-            # the dominant family = every CONV3X3 instantiation (with / without the fused shortcut input, one or two
-            # channel groups per block): launch-weighted mean of their measured HBM bytes per launch
+            # the dominant family = every 3x3 stride-1 instantiation (wave-specialised kernel for the wide layers, the
+            # CONV3X3 schedule of tapconv_mfma_kernel for the rest): launch-weighted mean of their measured HBM bytes
             tot_b = tot_n = 0.0
             for kname, e in json.load(open(tpath))["kernels"].items():
-                if "PolicyBF16X3, 32, 4, 1," in kname and "hbm_bytes_per_launch" in e:
+                if (("PolicyBF16X3, 32, 4, 1," in kname or "tapconv_ws_kernel<PolicyBF16X3" in kname)
+                        and "hbm_bytes_per_launch" in e):
                     tot_b += e["hbm_bytes_per_launch"] * e["launches_per_forward"]
                     tot_n += e["launches_per_forward"]
             if tot_n:
                 traffic = round(tot_b / tot_n)
         mfma_per_product = 3 if args.impl == "mfma_bf16x3" else 1
         roofline = {"bound": "mfma",
-                    "kernel": ("tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *> (3x3 stride-1 family)" % args.impl) if args.impl != "direct"
+                    "kernel": ("3x3 stride-1 family: tapconv_ws_kernel<%s, *> (wave-specialised, Cout %% 64 == 0) + "
+                               "tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *>" % (args.impl, args.impl)) if args.impl != "direct"
                     else "tapconv_direct_kernel",
                     "launches_per_forward": len(dom),
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),

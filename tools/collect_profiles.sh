@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-end evidence, one GPU call: kernel trace of the default bench + the three PMC passes (run from the repo root).
+# Products land in gpurun_out/prof/; copy the summaries into profiles/ (see profiles/README.md).
+set -o pipefail
+R=$PWD
+O=$R/gpurun_out/prof
+mkdir -p $O && cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kt /tmp/f /tmp/w /tmp/sq
+cp $R/bench.py $R/tools/profile_forward.py /tmp/ 2>/dev/null
+cd $R
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o b -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.log || exit 1
+python3 tools/rocpd_stats.py $(find /tmp/kt -name "b_results.db" | head -1) 40 --csv > $O/bench_kernel_stats.csv || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/f -- python3 tools/profile_forward.py --steps 3 > $O/f.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/w -- python3 tools/profile_forward.py --steps 3 > $O/w.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/sq -- python3 tools/profile_forward.py --steps 3 > $O/sq.log 2>&1 || exit 1
+python3 tools/collect_pmc.py $O/pmc_traffic.json 3 /tmp/f /tmp/w /tmp/sq || exit 1
+python3 bench.py > $O/bench_final.json 2> $O/bench_final.log
+tail -c 600 $O/bench_final.json
