@@ -293,7 +293,6 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
     for (int k = 0; k < S; ++k) {
       if (++c == nck) c = 0;
       if (c == 0) item_of(++ord, n, ty0, tx0, n0);
-      const bool second = HAS2 && c >= g.nchunks;
       WS_STAMP(0);
       ws_wait_vm(k ? vm_issued - max(end_win, end_col[0]) : 0);  // raw window k and column 0 of k have landed
       WS_STAMP(1);
