@@ -463,6 +463,8 @@ bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
 
 int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStream_t s) {
   DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_ws: geometry");
+  static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 1;
+  if (env == 2 && impl == DRS_IMPL_MFMA_BF16X3) return drs_launch_tapconv_ws3(d, g, s);  // pipelined variant (opt-in)
   if (impl == DRS_IMPL_MFMA_F32)
     return d.in2 ? ws_launch<PolicyF32, true>(d, g, s) : ws_launch<PolicyF32, false>(d, g, s);
   return d.in2 ? ws_launch<PolicyBF16X3, true>(d, g, s) : ws_launch<PolicyBF16X3, false>(d, g, s);
