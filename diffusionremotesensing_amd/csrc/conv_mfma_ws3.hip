@@ -65,8 +65,10 @@ __device__ __forceinline__ void w3_bump(w3_flag f, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool HAS2>
-__global__ __launch_bounds__(1024, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeom g) {
+// NMOV mover waves; CCONV: the CONSUMERS convert window k+1 (their 5-6 quads each) between the MFMAs of columns 1 and 2
+// of step k - the movers are pure LDS-DMA then - instead of every mover converting the pieces it fetched
+template <bool HAS2, int NMOV, bool CCONV>
+__global__ __launch_bounds__(512 + 64 * NMOV, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   // window image: 16-byte slots, 17 per pixel PAIR (8 quads of the even pixel, 8 of the odd one, 1 pad): the pair stride
@@ -74,11 +76,10 @@ __global__ __launch_bounds__(1024, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeo
   constexpr int KC = 32, IW = 18, NPIX = IW * IW, NSLOT = NPIX / 2 * 17, NPIECE = (NSLOT + 63) / 64;
   constexpr int WBUF = NSLOT * 16, BNB = 64, W_IMAGE = 9 * 4 * BNB * 16;
   constexpr int RPW = 4, NT = 2, BN = 32, TH = 16, TW = 16;
-  constexpr int NMOV = 8;                                  // mover waves (2 per SIMD)
   constexpr int NPW = (NPIECE + NMOV - 1) / NMOV;          // window pieces per mover wave (at most)
   char* sWB = smem;                       // two window buffers, raw fp32 -> {hi, lo} in place
   char* sW = smem + 2 * WBUF;             // [image][kx][ky][kgroup][BNB] operand slots
-  w3_flag sF = (w3_flag)(sW + 2 * W_IMAGE);  // F0, F1, F2
+  w3_flag sF = (w3_flag)(sW + 2 * W_IMAGE);  // F0, F1, F2, LW (mover waves whose window pieces have landed)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 consumers, 8..15 movers
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(1024, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeo
       issue_col(1, 0, n0_);
       issue_col(2, 0, n0_);
       w3_wait_vm(vm_issued - end_win);
-      convert_win(0, 0, ty_, tx_);
+      if constexpr (CCONV) w3_bump(sF + 3, lane); else convert_win(0, 0, ty_, tx_);
       w3_wait_vm(0);
       w3_wait_lds();
     }
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(1024, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeo
         issue_col(0, c1, n01);
         w3_wait_vm(vm_issued - end_win);    // this wave's window pieces have landed
         W3_STAMP(3);
-        convert_win(buf, c1, ty1, tx1);
+        if constexpr (CCONV) w3_bump(sF + 3, lane); else convert_win(buf, c1, ty1, tx1);
         W3_STAMP(4);
         w3_poll(sF + 1, 8u * (unsigned)(k + 1));
         issue_col(1, c1, n01);
@@ -308,6 +309,51 @@ __global__ __launch_bounds__(1024, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeo
       }
     }
   };
+  // ---- consumers' share of the in-place conversion (CCONV): slots tid, tid + 512, ... of the next window ----
+  constexpr int CVI = (NSLOT + 511) / 512;
+  f32x4 cv[CVI];
+  auto cv_load = [&](int buf) {
+    int t_o = tid;  // opaque: the slot arithmetic is redone here instead of living in registers across the MFMA loop
+    asm volatile("" : "+v"(t_o));
+#pragma unroll
+    for (int i = 0; i < CVI; ++i) {
+      const int s = t_o + 512 * i;
+      if (i < CVI - 1 || s < NSLOT) cv[i] = *reinterpret_cast<const f32x4*>(sWB + buf * WBUF + s * 16);
+    }
+  };
+  auto cv_store = [&](int buf, int c_, int ty_, int tx_) {
+    const bool second = HAS2 && c_ >= g.nchunks;
+    const int ylo = second ? 0 : 1 - ty_, xlo = second ? 0 : 1 - tx_;
+    const int yhi = second ? min(TH, d.H2 - ty_) : d.H + 1 - ty_, xhi = second ? min(TW, d.W2 - tx_) : d.W + 1 - tx_;
+    int t_o = tid;
+    asm volatile("" : "+v"(t_o));
+#pragma unroll
+    for (int i = 0; i < CVI; ++i) {
+      const int s = t_o + 512 * i;
+      if (i < CVI - 1 || s < NSLOT) {
+        const int pr = s / 17, r = s - pr * 17;
+        const int p = 2 * pr + (r >= 8 ? 1 : 0), py = p / IW, px = p - py * IW;
+        const bool ok = (unsigned)(py - ylo) < (unsigned)(yhi - ylo) && (unsigned)(px - xlo) < (unsigned)(xhi - xlo);
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+        bf16x4 h, l;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float x = ok ? cv[i][jj] : 0.f;
+          h[jj] = (__bf16)x;
+          l[jj] = (__bf16)(x - (float)h[jj]);
+        }
+        *reinterpret_cast<bf16x8v*>(sWB + buf * WBUF + s * 16) = bf16x8v{h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3]};
+      }
+    }
+  };
+  if constexpr (CCONV) {  // window 0
+    int n_, ty_, tx_, n0_;
+    item_of(0, n_, ty_, tx_, n0_);
+    w3_poll(sF + 3, (unsigned)NMOV);
+    cv_load(0);
+    cv_store(0, 0, ty_, tx_);
+  }
   W3_DECL;
   for (int k = 0; k < S; ++k) {
     if (++c == nck) c = 0;
@@ -327,6 +373,9 @@ __global__ __launch_bounds__(1024, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeo
     read_wf(0);
     w3_wait_lds();
     w3_bump(sF + 0, lane);
+    int c1 = 0, ord1 = 0, n1 = n, ty1 = ty0, tx1 = tx0, n01 = n0;
+    const bool conv_next = CCONV && k + 1 < S;
+    if (conv_next) next_step(c, ord, c1, ord1, n1, ty1, tx1, n01);
     if (second) {
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
@@ -349,9 +398,14 @@ __global__ __launch_bounds__(1024, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeo
       W3_STAMP(4);
       w3_wait_lds();
       w3_bump(sF + 2, lane);
-      mma_col(wb, 2);
-      W3_STAMP(5);
     }
+    if (conv_next) {  // window k+1 has landed by now (the movers' burst started at the barrier): fetch my quads ...
+      w3_poll(sF + 3, (unsigned)NMOV * (unsigned)(k + 2));
+      cv_load((k + 1) & 1);
+    }
+    if (!second) mma_col(wb, 2);
+    if (conv_next) cv_store((k + 1) & 1, c1, ty1, tx1);  // ... and convert them in the shadow of column 2's MFMAs
+    W3_STAMP(5);
     if (c == nck - 1) {
       int lr_e = lr, kg_e = kg;
       asm volatile("" : "+v"(lr_e), "+v"(kg_e));
@@ -363,9 +417,9 @@ __global__ __launch_bounds__(1024, 1) void tapconv_ws3_kernel(TapConv d, MfmaGeo
   if (wid == 4) W3_DUMP(1);
 }
 
-template <bool HAS2>
+template <bool HAS2, int NMOV, bool CCONV>
 int ws3_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
-  auto kern = tapconv_ws3_kernel<HAS2>;
+  auto kern = tapconv_ws3_kernel<HAS2, NMOV, CCONV>;
   static bool attr_done = false;
   static int num_cu = 0;
   constexpr size_t kLds = 2 * (18 * 18 / 2 * 17 * 16) + 2 * 9 * 4 * 64 * 16 + 64;
@@ -382,7 +436,7 @@ int ws3_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
   long long blocks = num_cu;
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kLds, s, d, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512 + 64 * NMOV), kLds, s, d, g);
   DRS_CHECK_HIP(hipGetLastError());
 #ifdef DRS_WS_TIMELINE
   {
@@ -405,5 +459,8 @@ int ws3_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 
 int drs_launch_tapconv_ws3(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
   DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_ws3: geometry");
-  return d.in2 ? ws3_launch<true>(d, g, s) : ws3_launch<false>(d, g, s);
+  static const int variant = getenv("DRS_WS3") ? atoi(getenv("DRS_WS3")) : 0;
+  if (variant == 1)  // 4 pure-DMA movers, the consumers convert window k+1 next to column 2's MFMAs (measured slower)
+    return d.in2 ? ws3_launch<true, 4, true>(d, g, s) : ws3_launch<false, 4, true>(d, g, s);
+  return d.in2 ? ws3_launch<true, 8, false>(d, g, s) : ws3_launch<false, 8, false>(d, g, s);  // 8 movers convert what they fetch
 }

@@ -64,6 +64,8 @@ CONV_CASES = [
     (2, 64, 8, 8, 64, 3, 2, 1, True, 1),        # transform
     (1, 128, 5, 3, 128, 3, 2, 1, True, 1),      # transform, ragged
     (1, 256, 4, 4, 256, 3, 1, 1, False, 0),     # bottleneck width
+    (2, 64, 40, 24, 128, 3, 1, 1, False, 0),    # wave-specialised kernel: 2 channel groups, border + interior patches
+    (1, 128, 17, 33, 64, 3, 1, 1, False, 0),    # wave-specialised kernel: 4 K-chunks, ragged edges on both axes
     (0, 16, 8, 8, 16, 3, 1, 1, False, 0),       # empty batch
 ]
 
@@ -474,3 +476,20 @@ def test_full_length_chain_is_deterministic(dev, model):
     assert outs[0].shape == (16, 3, 256, 256)
     assert torch.equal(outs[0], outs[1])
     assert not torch.isnan(outs[0]).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ws", ["0", "2"])
+def test_conv_kernel_variants_in_subprocess(ws):
+    """The 3x3 kernel family is chosen once per process (DRS_WS: 0 = lock-step kernel only, 1 = wave-specialised
+    default, 2 = pipelined variant).  The default is what every other test runs; the other two must reproduce the same
+    goldens.  Own process, because the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DRS_WS=ws)
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-m", "gpu", "-k",
+           "test_unet_blocks_golden or test_unet_forward_config1_vs_oracle or (test_conv2d_flavours and mfma_bf16x3)"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
