@@ -493,3 +493,20 @@ def test_conv_kernel_variants_in_subprocess(ws):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.gpu
+def test_split_bf16_data_gradients_keep_fp32_grade_accuracy():
+    """DRS_TRAIN_BWD_IMPL=mfma_bf16x3: data-gradient convolutions on split-bf16 next to an exact-fp32 forward and exact
+    fp32 weight gradients.  The gradient error of split-bf16 TRAINING comes from the forward activations (amplified by
+    the BatchNorm-backward cancellations), not from the backward products: with an fp32 forward the golden gradient
+    test holds at its fp32 tolerance (2e-4; 4e-5 measured).  Own process: the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DRS_TRAIN_BWD_IMPL="mfma_bf16x3")
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-m", "gpu", "-k",
+           "test_train_step_gradients_golden and mfma_f32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
