@@ -65,6 +65,17 @@ __device__ unsigned long long drs_ws_tl[48];
 #endif
 
 typedef __attribute__((address_space(1))) void* ws_gptr;
+typedef __attribute__((address_space(3))) unsigned* ws_flag_ptr;
+
+// spin until the LDS counter *f reaches `target`.  A protocol error must never leave waves spinning on the GPU (a hung
+// wave can take the whole node down): after ~2^22 polls (about a second) the wave traps and the launch fails loudly.
+__device__ __forceinline__ void ws_poll(ws_flag_ptr f, unsigned target) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    __builtin_amdgcn_s_sleep(4);
+    if (++spins > (1u << 22)) __builtin_trap();
+  }
+}
 typedef __attribute__((address_space(3))) void* ws_lptr;
 
 template <class P>
@@ -96,7 +107,6 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   char* sStage = smem;                           // [window pixel][quad] raw fp32
   char* sA = smem + G::STAGE;                    // [image][kgroup(4)][window pixel] operand slots
   char* sW = sA + P::IMAGES * A_IMAGE;           // [image][kx(3)][ky(3)][kgroup(4)][BNB] operand slots
-  typedef __attribute__((address_space(3))) unsigned* ws_flag_ptr;
   ws_flag_ptr sFlag = (ws_flag_ptr)(sW + P::IMAGES * W_IMAGE);  // consumer waves that have read column 1 so far
   ws_flag_ptr sFlag2 = sFlag + 1;                                // ... column 2
   ws_flag_ptr sLand2 = sFlag + 2;                                // mover waves whose part of column 2 has landed
@@ -315,10 +325,10 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
         issue_win(c1, n1, ty1, tx1, 0, NPW);
         WS_STAMP(5);
         const unsigned target = 8u * (unsigned)(k + 1);
-        while (__hip_atomic_load(sFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(4);  // every consumer wave has read column 1 of k
+        ws_poll(sFlag, target);  // every consumer wave has read column 1 of k
         WS_STAMP(6);
         issue_col(1, c1, n01);
-        while (__hip_atomic_load(sFlag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(4);
+        ws_poll(sFlag2, target);
         issue_col(2, c1, n01);
       }
       WS_STAMP(7);
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
         if (lane == 0) __hip_atomic_fetch_add(sFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // column 1 is in registers: its ring slot may be refilled
         WS_STAMP(5);
         mma_col(1);
-        while (__hip_atomic_load(sLand2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)(k + 1)) __builtin_amdgcn_s_sleep(2);
+        ws_poll(sLand2, 4u * (unsigned)(k + 1));
         read_wf(2);
         ws_wait_lds();
         if (lane == 0) __hip_atomic_fetch_add(sFlag2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
