@@ -469,7 +469,7 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((size_t)d.N * d.TH * d.TW == 0) return DRS_OK;
   MfmaGeom g; int bn, rpw, mode; size_t lds;
   geom(d, impl, &g, &bn, &rpw, &mode, &lds);
-  if (mode == MODE_CONV3X3 && nwg_of(d, mode) == 2 && drs_tapconv_ws_supported(d, impl))
+  if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_ws_supported(d, impl))
     return drs_launch_tapconv_ws(d, g, impl, s);
   if (impl == DRS_IMPL_MFMA_F32) return launch_p<PolicyF32>(d, g, bn, rpw, mode, lds, s);
   if (impl == DRS_IMPL_MFMA_F16) return launch_p<PolicyF16>(d, g, bn, rpw, mode, lds, s);

@@ -78,7 +78,7 @@ __device__ __forceinline__ void ws_poll(ws_flag_ptr f, unsigned target) {
 }
 typedef __attribute__((address_space(3))) void* ws_lptr;
 
-template <class P>
+template <class P, int BNB_ = 64>
 struct WsGeom {
   static constexpr int KC = 4 * P::SLOT_CH;
   static constexpr int IW = 18, NPIX = 18 * 18;
@@ -88,18 +88,20 @@ struct WsGeom {
   static constexpr int STAGE = NPIECE * 1024;               // bytes of the raw staging area
   static constexpr int APS = (NPIX * 16 + 255) / 256 * 256 + 64;  // k-group plane stride: 64 B skew = conflict-free quad writes
   static constexpr int A_IMAGE = 4 * APS;
-  static constexpr int BNB = 64;
+  static constexpr int BNB = BNB_;  // output channels per block: 64 = 2 channel groups x 4 row-waves, 32 = 1 x 8
   static constexpr int W_IMAGE = 9 * 4 * BNB * 16;
   static constexpr int LDS = STAGE + P::IMAGES * (A_IMAGE + W_IMAGE) + 16;  // + the three counters
 };
 
-template <class P, bool HAS2>
+template <class P, bool HAS2, int BNB_ = 64, bool FUSE = false>
 __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using G = WsGeom<P>;
+  using G = WsGeom<P, BNB_>;
   constexpr int KC = G::KC, IW = G::IW, QPP = G::QPP, NQUAD = G::NQUAD, NPIECE = G::NPIECE;
   constexpr int APS = G::APS, A_IMAGE = G::A_IMAGE, W_IMAGE = G::W_IMAGE, BNB = G::BNB;
-  constexpr int RPW = 4, NT = 2, BN = 32, TH = 16, TW = 16;
+  constexpr int NT = 2, BN = 32, TH = 16, TW = 16;
+  constexpr int NRW = 8 * BN / G::BNB;  // row-waves per channel group: 4 (64 channels per block) or 8 (32)
+  constexpr int RPW = TH / NRW;         // patch rows per consumer wave: 4 or 2
   constexpr int WPI = P::IMAGES * 12 / 4;        // weight pieces per mover wave and kernel column
   constexpr int W2PI = (P::IMAGES * 4 + 3) / 4;  // ... of the second input's single tap
   constexpr int NPW = (NPIECE + 3) / 4;          // raw window pieces per mover wave (at most)
@@ -146,29 +148,64 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   int end_win = 0;                 // ... after the raw window group
   auto issue_col = [&](int col, int c_, int n0_) {
     const bool second = HAS2 && c_ >= g.nchunks;
-    if (!second) {
-#pragma unroll
-      for (int i = 0; i < WPI; ++i) {
-        const int idx = pw * WPI + i;  // (image, ky, k-group) piece of this wave
-        const int im = idx / 12, ky = (idx % 12) >> 2, kq = idx & 3;
-        const char* src = wg + (size_t)im * g.w_gimage + (size_t)c_ * w_chunk +
-                          ((size_t)((ky * 3 + col) * 4 + kq) * d.Cout + n0_ + lane) * 16;
-        char* dst = sW + (size_t)im * W_IMAGE + (size_t)((col * 3 + ky) * 4 + kq) * BNB * 16;
-        __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
-      }
-      vm_issued += WPI;
-    } else if (col == 0) {  // second input: one tap, stored where (kx 0, ky 0) lives
-      const int cc = c_ - g.nchunks;
-#pragma unroll
-      for (int i = 0; i < W2PI; ++i) {
-        const int idx = pw * W2PI + i;
-        const int im = idx >> 2, kq = idx & 3;
-        if (im < P::IMAGES) {
-          const char* src = reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage +
-                            ((size_t)(cc * 4 + kq) * d.Cout + n0_ + lane) * 16;
-          char* dst = sW + (size_t)im * W_IMAGE + (size_t)kq * BNB * 16;
+    if constexpr (BNB == 64) {
+      if (!second) {
+  #pragma unroll
+        for (int i = 0; i < WPI; ++i) {
+          const int idx = pw * WPI + i;  // (image, ky, k-group) piece of this wave
+          const int im = idx / 12, ky = (idx % 12) >> 2, kq = idx & 3;
+          const char* src = wg + (size_t)im * g.w_gimage + (size_t)c_ * w_chunk +
+                            ((size_t)((ky * 3 + col) * 4 + kq) * d.Cout + n0_ + lane) * 16;
+          char* dst = sW + (size_t)im * W_IMAGE + (size_t)((col * 3 + ky) * 4 + kq) * BNB * 16;
           __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
-          vm_issued += 1;
+        }
+        vm_issued += WPI;
+      } else if (col == 0) {  // second input: one tap, stored where (kx 0, ky 0) lives
+        const int cc = c_ - g.nchunks;
+  #pragma unroll
+        for (int i = 0; i < W2PI; ++i) {
+          const int idx = pw * W2PI + i;
+          const int im = idx >> 2, kq = idx & 3;
+          if (im < P::IMAGES) {
+            const char* src = reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage +
+                              ((size_t)(cc * 4 + kq) * d.Cout + n0_ + lane) * 16;
+            char* dst = sW + (size_t)im * W_IMAGE + (size_t)kq * BNB * 16;
+            __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
+            vm_issued += 1;
+          }
+        }
+      }
+    } else {
+      // 32 channels per block: a 1 KB piece = two consecutive k-group rows of 32 channels
+      constexpr int RPP = 2, WPIECES = P::IMAGES * 12 / RPP, WPI32 = (WPIECES + 3) / 4;
+      constexpr int W2PIECES = P::IMAGES * 4 / RPP, W2PI32 = (W2PIECES + 3) / 4;
+      const int prow = lane >> 5, pco = lane & 31;
+      if (!second) {
+#pragma unroll
+        for (int i = 0; i < WPI32; ++i) {
+          const int idx = pw * WPI32 + i;
+          if (idx < WPIECES) {
+            const int row0 = idx * RPP, im = row0 / 12, ky = (row0 % 12) >> 2, kq0 = row0 & 3;
+            const char* src = wg + (size_t)im * g.w_gimage + (size_t)c_ * w_chunk +
+                              ((size_t)((ky * 3 + col) * 4 + kq0 + prow) * d.Cout + n0_ + pco) * 16;
+            char* dst = sW + (size_t)im * W_IMAGE + (size_t)((col * 3 + ky) * 4 + kq0) * BNB * 16;
+            __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
+            vm_issued += 1;
+          }
+        }
+      } else if (col == 0) {
+        const int cc = c_ - g.nchunks;
+#pragma unroll
+        for (int i = 0; i < W2PI32; ++i) {
+          const int idx = pw * W2PI32 + i;
+          if (idx < W2PIECES) {
+            const int row0 = idx * RPP, im = row0 >> 2, kq0 = row0 & 3;
+            const char* src = reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage +
+                              ((size_t)(cc * 4 + kq0 + prow) * d.Cout + n0_ + pco) * 16;
+            char* dst = sW + (size_t)im * W_IMAGE + (size_t)kq0 * BNB * 16;
+            __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
+            vm_issued += 1;
+          }
         }
       }
     }
@@ -202,8 +239,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   };
 
   // ---- consumer state --------------------------------------------------------------------------------------------
-  const int rw = wid & 3;         // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
-  const int ng = (wid >> 2) & 1;  // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
+  const int rw = BNB == 64 ? (wid & 3) : (wid & 7);         // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
+  const int ng = BNB == 64 ? ((wid >> 2) & 1) : 0;          // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
   const char* win = sA + kg * APS + (rw * RPW * IW + lr) * 16;           // this lane's window origin
   const char* wbase = sW + ((size_t)kg * BNB + ng * NT * 16 + lr) * 16;  // this lane's weight origin
   f32x4 acc[RPW][NT];
@@ -387,7 +424,10 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
         // out of the step loop (where it would be spilled and reloaded with vmcnt(0) waits between the stores)
         int lr_e = lr, kg_e = kg;
         asm volatile("" : "+v"(lr_e), "+v"(kg_e));
-        tile_epilogue<RPW, NT, false, RPW>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
+        if constexpr (FUSE)
+          fuse_epilogue<RPW, NT>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e);
+        else
+          tile_epilogue<RPW, NT, false, RPW>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
       }
       WS_STAMP(7);
     }
@@ -409,9 +449,10 @@ bool ws_std3x3(const TapConv& d) {
   return true;
 }
 
-template <class P, bool HAS2>
+template <class P, bool HAS2, int BNB = 64, bool FUSE = false>
 int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
-  auto kern = tapconv_ws_kernel<P, HAS2>;
+  auto kern = tapconv_ws_kernel<P, HAS2, BNB, FUSE>;
+  constexpr size_t kLds = WsGeom<P, BNB>::LDS;
   static bool attr_done = false;
   static int num_cu = 0;
   if (!attr_done) {
@@ -422,12 +463,12 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
     DRS_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_done = true;
   }
-  static_assert(WsGeom<P>::LDS <= 160 * 1024, "LDS budget");
-  const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / 64);
+  static_assert(kLds <= 160 * 1024, "LDS budget");
+  const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / BNB);
   long long blocks = num_cu;  // one 12-wave block per CU
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), WsGeom<P>::LDS, s, d, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);
   DRS_CHECK_HIP(hipGetLastError());
 #ifdef DRS_WS_TIMELINE
   {
@@ -436,7 +477,7 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
     float ms = 0.f;
     DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
     DRS_CHECK_HIP(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), WsGeom<P>::LDS, s, d, g);  // timed repeat (same result)
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);  // timed repeat (same result)
     DRS_CHECK_HIP(hipEventRecord(e1, s));
     DRS_CHECK_HIP(hipStreamSynchronize(s));
     DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
@@ -458,24 +499,35 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 
 }  // namespace
 
-// Eligibility of the wave-specialised kernel (the caller has established the CONV3X3 / 512-thread geometry).
+// Eligibility of the wave-specialised kernel (3x3 stride 1 on 16-row patches; the caller has established that geometry).
+// DRS_WS: 0 off, bits 0-1: 1 = layers with Cout % 64 == 0, 2 = their pipelined variant (conv_mfma_ws3.hip); bit 2 (4) adds
+// the 32-channel flavour (Cout % 64 != 0, incl. the fused output projection of up_convs.2).  Default 5.
 bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
-  static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 1;
+  static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 5;
   if (!env) return false;
   if (impl != DRS_IMPL_MFMA_BF16X3 && impl != DRS_IMPL_MFMA_F32) return false;
   const int KC = impl == DRS_IMPL_MFMA_F32 ? 16 : 32;
-  if (!d.in || !ws_std3x3(d) || d.fuse_out || d.shared_cu || d.gate || d.in_add) return false;
-  if (d.Cout % 64 != 0 || d.Cin % KC != 0 || d.TH <= 8) return false;
+  if (!d.in || !ws_std3x3(d) || d.shared_cu || d.gate || d.in_add) return false;
+  if (d.Cout % 32 != 0 || d.Cin % KC != 0 || d.TH <= 8) return false;
+  if (d.Cout % 64 != 0 && !(env & 4)) return false;
+  if (d.fuse_out && (d.Cout != 32 || d.in2 || !(env & 4))) return false;
   if ((d.in_cs & 3) || (d.in_co & 3)) return false;
   if (d.in2 && (d.Cin2 % KC != 0 || (d.in2_cs & 3) || (d.in2_co & 3))) return false;
   return true;
 }
 
+template <class P>
+static int ws_dispatch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
+  if (d.fuse_out) return ws_launch<P, false, 32, true>(d, g, s);
+  if (d.Cout % 64 == 0) return d.in2 ? ws_launch<P, true>(d, g, s) : ws_launch<P, false>(d, g, s);
+  return d.in2 ? ws_launch<P, true, 32>(d, g, s) : ws_launch<P, false, 32>(d, g, s);
+}
+
 int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStream_t s) {
   DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_ws: geometry");
-  static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 1;
-  if (env == 2 && impl == DRS_IMPL_MFMA_BF16X3) return drs_launch_tapconv_ws3(d, g, s);  // pipelined variant (opt-in)
-  if (impl == DRS_IMPL_MFMA_F32)
-    return d.in2 ? ws_launch<PolicyF32, true>(d, g, s) : ws_launch<PolicyF32, false>(d, g, s);
-  return d.in2 ? ws_launch<PolicyBF16X3, true>(d, g, s) : ws_launch<PolicyBF16X3, false>(d, g, s);
+  static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 5;
+  if ((env & 3) == 2 && impl == DRS_IMPL_MFMA_BF16X3 && d.Cout % 64 == 0 && !d.fuse_out)
+    return drs_launch_tapconv_ws3(d, g, s);  // pipelined variant (opt-in)
+  if (impl == DRS_IMPL_MFMA_F32) return ws_dispatch<PolicyF32>(d, g, s);
+  return ws_dispatch<PolicyBF16X3>(d, g, s);
 }

@@ -479,11 +479,12 @@ def test_full_length_chain_is_deterministic(dev, model):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ws", ["0", "2"])
+@pytest.mark.parametrize("ws", ["0", "1", "6"])
 def test_conv_kernel_variants_in_subprocess(ws):
-    """The 3x3 kernel family is chosen once per process (DRS_WS: 0 = lock-step kernel only, 1 = wave-specialised
-    default, 2 = pipelined variant).  The default is what every other test runs; the other two must reproduce the same
-    goldens.  Own process, because the switch is read once."""
+    """The 3x3 kernel family is chosen once per process (DRS_WS: 0 = lock-step kernel only, 1 = wave-specialised for
+    the 64-channel-group layers only, 5 = default: + the 32-channel flavour, 6 = pipelined variant + 32-channel
+    flavour).  The default is what every other test runs; the others must reproduce the same goldens.  Own process,
+    because the switch is read once."""
     import os
     import subprocess
     import sys
