@@ -215,6 +215,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   auto issue_win = [&](int c_, int n_, int ty_, int tx_, int i0, int i1) {
     const bool second = HAS2 && c_ >= g.nchunks;
     const int cc = second ? c_ - g.nchunks : c_;
+    const int nq = min(QPP, ((second ? d.Cin2 : d.Cin) - cc * KC) >> 2);  // real quads of this chunk
     int lane_o = lane;  // opaque: the per-piece address arithmetic is recomputed here, not hoisted (and spilled)
     asm volatile("" : "+v"(lane_o));
 #pragma unroll
@@ -222,7 +223,9 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
       const int j = pw + 4 * i;  // piece (wave-uniform)
       if (i >= i0 && i < i1 && j < NPIECE) {
         const int e = min(j * 64 + lane_o, NQUAD - 1);
-        const int p = e / QPP, quad = e % QPP, py = p / IW, px = p % IW;
+        // a last chunk with fewer than KC channels (Cin = 16 on the 256x256 level): its missing quads fetch a duplicate
+        // of the last real one - finite data that meets the zero padding of the packed weights
+        const int p = e / QPP, quad = min(e % QPP, nq - 1), py = p / IW, px = p % IW;
         const float* src;
         if (!second) {
           const int iy = min(max(ty_ - 1 + py, 0), d.H - 1), ix = min(max(tx_ - 1 + px, 0), d.W - 1);
@@ -508,6 +511,8 @@ bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
   if (impl != DRS_IMPL_MFMA_BF16X3 && impl != DRS_IMPL_MFMA_F32) return false;
   const int KC = impl == DRS_IMPL_MFMA_F32 ? 16 : 32;
   if (!d.in || !ws_std3x3(d) || d.shared_cu || d.gate || d.in_add) return false;
+  // (partial K-chunks work - the movers duplicate the last real quad - but the 16-channel layers of the 256x256 level
+  //  are HBM-bound and measured 1.3 % slower here than on the lock-step kernel)
   if (d.Cout % 32 != 0 || d.Cin % KC != 0 || d.TH <= 8) return false;
   if (d.Cout % 64 != 0 && !(env & 4)) return false;
   if (d.fuse_out && (d.Cout != 32 || d.in2 || !(env & 4))) return false;
@@ -526,7 +531,8 @@ static int ws_dispatch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStream_t s) {
   DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_ws: geometry");
   static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 5;
-  if ((env & 3) == 2 && impl == DRS_IMPL_MFMA_BF16X3 && d.Cout % 64 == 0 && !d.fuse_out)
+  if ((env & 3) == 2 && impl == DRS_IMPL_MFMA_BF16X3 && d.Cout % 64 == 0 && !d.fuse_out && d.Cin % 32 == 0 &&
+      (!d.in2 || d.Cin2 % 32 == 0))
     return drs_launch_tapconv_ws3(d, g, s);  // pipelined variant (opt-in)
   if (impl == DRS_IMPL_MFMA_F32) return ws_dispatch<PolicyF32>(d, g, s);
   return ws_dispatch<PolicyBF16X3>(d, g, s);
