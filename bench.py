@@ -279,7 +279,8 @@ def main():
             # CONV3X3 schedule of tapconv_mfma_kernel for the rest): launch-weighted mean of their measured HBM bytes
             tot_b = tot_n = 0.0
             for kname, e in json.load(open(tpath))["kernels"].items():
-                if (("PolicyBF16X3, 32, 4, 1," in kname or "tapconv_ws_kernel<PolicyBF16X3" in kname)
+                fused_projection = kname.rstrip().endswith("32, true>")  # up_convs.2: listed on its own, not in `dom`
+                if (("PolicyBF16X3, 32, 4, 1," in kname or ("tapconv_ws_kernel<PolicyBF16X3" in kname and not fused_projection))
                         and "hbm_bytes_per_launch" in e):
                     tot_b += e["hbm_bytes_per_launch"] * e["launches_per_forward"]
                     tot_n += e["launches_per_forward"]
