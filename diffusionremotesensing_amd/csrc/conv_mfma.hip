@@ -471,6 +471,7 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   geom(d, impl, &g, &bn, &rpw, &mode, &lds);
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_ws_supported(d, impl))
     return drs_launch_tapconv_ws(d, g, impl, s);
+  DRS_REQUIRE(!d.dual, DRS_ERR_SHAPE, "tapconv_mfma: the fused conv1 + skip op needs the wave-specialised kernel");
   if (impl == DRS_IMPL_MFMA_F32) return launch_p<PolicyF32>(d, g, bn, rpw, mode, lds, s);
   if (impl == DRS_IMPL_MFMA_F16) return launch_p<PolicyF16>(d, g, bn, rpw, mode, lds, s);
   return launch_p<PolicyBF16X3>(d, g, bn, rpw, mode, lds, s);
@@ -484,25 +485,29 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
                                       char* __restrict__ dst_w, float* __restrict__ dst_b, int Cout, int Cin, int taps,
-                                      int transposed, int nchunks, size_t image_bytes, int cout_src, int flip_taps) {
+                                      int transposed, int nchunks, size_t image_bytes, int cout_src, int flip_taps, int co_off,
+                                      int partial) {
   // cout_src < Cout: the source has only cout_src output channels; the rest of the image is zero (a 16-channel
   // output padded to the kernel's 32-channel tile)
   constexpr int KC = 4 * P::SLOT_CH;
   const size_t nslots = (size_t)nchunks * taps * 4 * Cout;
   for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (size_t)gridDim.x * blockDim.x) {
-    const int co = (int)(s % Cout);
+    // co_off / partial: the source fills channels [co_off, co_off + cout_src) of a wider image; with `partial` the other
+    // channels are left alone (a second layer packed into the same image)
+    const int co = (int)(s % Cout) - co_off;
+    if (partial && (co < 0 || co >= cout_src)) continue;
     const int q = (int)((s / Cout) & 3);
     const int tap = (int)((s / ((size_t)Cout * 4)) % taps);
     const int tap_src = flip_taps ? taps - 1 - tap : tap;  // data gradients convolve with the spatially flipped kernel
     const int c = (int)(s / ((size_t)Cout * 4 * taps));
     float sc = 1.f;
-    if (gamma) sc = gamma[co] / sqrtf(rvar[co] + eps);
+    if (gamma && co >= 0 && co < cout_src) sc = gamma[co] / sqrtf(rvar[co] + eps);
     float x[P::SLOT_CH];
 #pragma unroll
     for (int j = 0; j < P::SLOT_CH; ++j) {
       const int ci = c * KC + q * P::SLOT_CH + j;
       float v = 0.f;
-      if (ci < Cin && co < cout_src) {
+      if (ci < Cin && co >= 0 && co < cout_src) {
         const size_t src = transposed ? (((size_t)ci * cout_src + co) * taps + tap_src)
                                       : (((size_t)co * Cin + ci) * taps + tap_src);
         v = w[src];
@@ -513,13 +518,16 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
     P::cvt_store(dst_w, image_bytes, s * 16, x);
   }
   if (blockIdx.x == 0) {
-    for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
-      float bb = (b && co < cout_src) ? b[co] : 0.f;
-      if (gamma) {
+    for (int cot = threadIdx.x; cot < Cout; cot += blockDim.x) {
+      const int co = cot - co_off;
+      const bool mine = co >= 0 && co < cout_src;
+      if (partial && !mine) continue;
+      float bb = (b && mine) ? b[co] : 0.f;
+      if (gamma && mine) {
         const float sc = gamma[co] / sqrtf(rvar[co] + eps);
         bb = (bb - rmean[co]) * sc + beta[co];
       }
-      dst_b[co] = bb;
+      dst_b[cot] = bb;
     }
   }
 }
@@ -531,7 +539,7 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl) {
 
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
-                              int transposed, int impl, hipStream_t s, int cout_src, int flip_taps) {
+                              int transposed, int impl, hipStream_t s, int cout_src, int flip_taps, int co_off, int partial) {
   if (cout_src <= 0) cout_src = Cout;
   const int KC = 4 * slot_ch(impl);
   const int nchunks = drs_cdiv(Cin, KC);
@@ -542,7 +550,7 @@ int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma
   if (blocks < 1) blocks = 1;
 #define DRS_PACK(P)                                                                                                   \
   hipLaunchKernelGGL(pack_conv_mfma_kernel<P>, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps,    \
-                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps)
+                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps, co_off, partial)
   if (impl == DRS_IMPL_MFMA_F32) DRS_PACK(PolicyF32);
   else if (impl == DRS_IMPL_MFMA_F16) DRS_PACK(PolicyF16);
   else DRS_PACK(PolicyBF16X3);

@@ -93,14 +93,16 @@ struct WsGeom {
   static constexpr int LDS = STAGE + P::IMAGES * (A_IMAGE + W_IMAGE) + 16;  // + the three counters
 };
 
-template <class P, bool HAS2, int BNB_ = 64, bool FUSE = false>
+// DUAL: conv1 + skip convolution of a residual block in one pass (TapConv::dual): 64 weight channels [main | skip], 8
+// row-waves x 2 rows, 4 channel tiles per wave, so both halves of an output pixel meet in one lane
+template <class P, bool HAS2, int BNB_ = 64, bool FUSE = false, bool DUAL = false>
 __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G = WsGeom<P, BNB_>;
   constexpr int KC = G::KC, IW = G::IW, QPP = G::QPP, NQUAD = G::NQUAD, NPIECE = G::NPIECE;
   constexpr int APS = G::APS, A_IMAGE = G::A_IMAGE, W_IMAGE = G::W_IMAGE, BNB = G::BNB;
-  constexpr int NT = 2, BN = 32, TH = 16, TW = 16;
-  constexpr int NRW = 8 * BN / G::BNB;  // row-waves per channel group: 4 (64 channels per block) or 8 (32)
+  constexpr int NT = DUAL ? 4 : 2, BN = 32, TH = 16, TW = 16;
+  constexpr int NRW = DUAL ? 8 : 8 * BN / G::BNB;  // row-waves per channel group: 4 (64 channels per block) or 8 (32, dual)
   constexpr int RPW = TH / NRW;         // patch rows per consumer wave: 4 or 2
   constexpr int WPI = P::IMAGES * 12 / 4;        // weight pieces per mover wave and kernel column
   constexpr int W2PI = (P::IMAGES * 4 + 3) / 4;  // ... of the second input's single tap
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   const int lr = lane & 15, kg = lane >> 4;
 
   // persistent blocks, XCD-aware item order (see tapconv_mfma_kernel)
-  const int ngroups = d.Cout / BNB;
+  const int ngroups = DUAL ? 1 : d.Cout / BNB;
+  const int wcout = DUAL ? 2 * d.Cout : d.Cout;  // channels of the packed weight image
   const int nitems = d.N * g.tiles_y * g.tiles_x * ngroups;
   const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
   const int per = (nitems + 7) >> 3;
@@ -142,7 +145,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   // ---- mover state -----------------------------------------------------------------------------------------------
   const int pw = wid - 8;
   const char* wg = reinterpret_cast<const char*>(d.w);
-  const size_t w_chunk = (size_t)9 * 4 * d.Cout * 16;
+  const size_t w_chunk = (size_t)9 * 4 * wcout * 16;
+  const size_t w_gimage = DUAL ? 2 * (size_t)g.w_gimage : (size_t)g.w_gimage;  // (the geometry was sized for d.Cout channels)
   int vm_issued = 0;               // vector-memory operations this wave has issued so far (program order)
   int end_col[3] = {0, 0, 0};      // issue count right after the DMA group that fills weight ring slot j
   int end_win = 0;                 // ... after the raw window group
@@ -154,8 +158,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
         for (int i = 0; i < WPI; ++i) {
           const int idx = pw * WPI + i;  // (image, ky, k-group) piece of this wave
           const int im = idx / 12, ky = (idx % 12) >> 2, kq = idx & 3;
-          const char* src = wg + (size_t)im * g.w_gimage + (size_t)c_ * w_chunk +
-                            ((size_t)((ky * 3 + col) * 4 + kq) * d.Cout + n0_ + lane) * 16;
+          const char* src = wg + (size_t)im * w_gimage + (size_t)c_ * w_chunk +
+                            ((size_t)((ky * 3 + col) * 4 + kq) * wcout + n0_ + lane) * 16;
           char* dst = sW + (size_t)im * W_IMAGE + (size_t)((col * 3 + ky) * 4 + kq) * BNB * 16;
           __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
         }
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
           const int im = idx >> 2, kq = idx & 3;
           if (im < P::IMAGES) {
             const char* src = reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage +
-                              ((size_t)(cc * 4 + kq) * d.Cout + n0_ + lane) * 16;
+                              ((size_t)(cc * 4 + kq) * wcout + n0_ + lane) * 16;
             char* dst = sW + (size_t)im * W_IMAGE + (size_t)kq * BNB * 16;
             __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
             vm_issued += 1;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
           const int idx = pw * WPI32 + i;
           if (idx < WPIECES) {
             const int row0 = idx * RPP, im = row0 / 12, ky = (row0 % 12) >> 2, kq0 = row0 & 3;
-            const char* src = wg + (size_t)im * g.w_gimage + (size_t)c_ * w_chunk +
+            const char* src = wg + (size_t)im * w_gimage + (size_t)c_ * w_chunk +
                               ((size_t)((ky * 3 + col) * 4 + kq0 + prow) * d.Cout + n0_ + pco) * 16;
             char* dst = sW + (size_t)im * W_IMAGE + (size_t)((col * 3 + ky) * 4 + kq0) * BNB * 16;
             __builtin_amdgcn_global_load_lds((ws_gptr)src, (ws_lptr)dst, 16, 0, 0);
@@ -242,8 +246,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
   };
 
   // ---- consumer state --------------------------------------------------------------------------------------------
-  const int rw = BNB == 64 ? (wid & 3) : (wid & 7);         // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
-  const int ng = BNB == 64 ? ((wid >> 2) & 1) : 0;          // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
+  const int rw = (BNB == 64 && !DUAL) ? (wid & 3) : (wid & 7);         // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
+  const int ng = (BNB == 64 && !DUAL) ? ((wid >> 2) & 1) : 0;          // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
   const char* win = sA + kg * APS + (rw * RPW * IW + lr) * 16;           // this lane's window origin
   const char* wbase = sW + ((size_t)kg * BNB + ng * NT * 16 + lr) * 16;  // this lane's weight origin
   f32x4 acc[RPW][NT];
@@ -427,7 +431,23 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
         // out of the step loop (where it would be spilled and reloaded with vmcnt(0) waits between the stores)
         int lr_e = lr, kg_e = kg;
         asm volatile("" : "+v"(lr_e), "+v"(kg_e));
-        if constexpr (FUSE)
+        if constexpr (DUAL) {
+          // out = relu(main + b_main) + post_add + (skip + b_skip): tiles t (main) and t + 2 (skip) of the same lane
+          f32x4 comb[RPW][2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float4 b1 = *reinterpret_cast<const float4*>(d.bias + t * 16 + kg_e * 4);
+            const float4 b2 = *reinterpret_cast<const float4*>(d.bias + d.Cout + t * 16 + kg_e * 4);
+            const float bm[4] = {b1.x, b1.y, b1.z, b1.w}, bs[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) comb[r][t][j] = fmaxf(acc[r][t][j] + bm[j], 0.f) + (acc[r][t + 2][j] + bs[j]);
+          }
+          TapConv de = d;
+          de.bias = nullptr; de.bias2 = nullptr; de.relu_pre = 0;
+          tile_epilogue<RPW, 2, false, RPW>(de, comb, n, 0, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
+        } else if constexpr (FUSE)
           fuse_epilogue<RPW, NT>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e);
         else
           tile_epilogue<RPW, NT, false, RPW>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
@@ -452,9 +472,9 @@ bool ws_std3x3(const TapConv& d) {
   return true;
 }
 
-template <class P, bool HAS2, int BNB = 64, bool FUSE = false>
+template <class P, bool HAS2, int BNB = 64, bool FUSE = false, bool DUAL = false>
 int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
-  auto kern = tapconv_ws_kernel<P, HAS2, BNB, FUSE>;
+  auto kern = tapconv_ws_kernel<P, HAS2, BNB, FUSE, DUAL>;
   constexpr size_t kLds = WsGeom<P, BNB>::LDS;
   static bool attr_done = false;
   static int num_cu = 0;
@@ -467,7 +487,7 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
     attr_done = true;
   }
   static_assert(kLds <= 160 * 1024, "LDS budget");
-  const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / BNB);
+  const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (DUAL ? 1 : d.Cout / BNB);
   long long blocks = num_cu;  // one 12-wave block per CU
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
@@ -511,6 +531,9 @@ bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
   if (impl != DRS_IMPL_MFMA_BF16X3 && impl != DRS_IMPL_MFMA_F32) return false;
   const int KC = impl == DRS_IMPL_MFMA_F32 ? 16 : 32;
   if (!d.in || !ws_std3x3(d) || d.shared_cu || d.gate || d.in_add) return false;
+  if (d.dual)  // conv1 + skip in one pass: split-bf16 only, one 32-channel output group, partial K-chunk allowed
+    return (env & 4) && impl == DRS_IMPL_MFMA_BF16X3 && d.Cout == 32 && d.Cin % 4 == 0 && d.TH > 8 && !d.in2 && !d.fuse_out &&
+           !d.res && d.bias && !(d.in_cs & 3) && !(d.in_co & 3);
   // (partial K-chunks work - the movers duplicate the last real quad - but the 16-channel layers of the 256x256 level
   //  are HBM-bound and measured 1.3 % slower here than on the lock-step kernel)
   if (d.Cout % 32 != 0 || d.Cin % KC != 0 || d.TH <= 8) return false;
@@ -525,6 +548,7 @@ bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
 
 template <class P>
 static int ws_dispatch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
+  if (d.dual) return ws_launch<P, false, 64, false, true>(d, g, s);
   if (d.fuse_out) return ws_launch<P, false, 32, true>(d, g, s);
   if (d.Cout % 64 == 0) return d.in2 ? ws_launch<P, true>(d, g, s) : ws_launch<P, false>(d, g, s);
   return d.in2 ? ws_launch<P, true, 32>(d, g, s) : ws_launch<P, false, 32>(d, g, s);

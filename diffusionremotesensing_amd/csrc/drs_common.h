@@ -64,6 +64,11 @@ struct TapConv {
   // either kernel fits on every CU at the same time) and no 512-thread variant; 2 = two blocks per CU for the small-LDS
   // 1x1 flavours (37 KB each next to the partner's 80 KB)
   int shared_cu;
+  // fused pair of 3x3 convolutions of the SAME input (ResConvBlock conv1 + its skip convolution, reference :153-166): `w`
+  // is one operand image of 2 * Cout channels [main | skip], `bias` holds 2 * Cout values, and the epilogue computes
+  //   out[c] = relu(acc[c] + bias[c]) + post_add[c] + acc[Cout + c] + bias[Cout + c].
+  // Wave-specialised kernel only (both halves of a pixel end up in one lane: no exchange, no round trip of the skip tensor).
+  int dual;
 };
 
 struct DrsErr {
@@ -93,6 +98,7 @@ static inline int drs_cdiv(int a, int b) { return (a + b - 1) / b; }
 int drs_launch_tapconv_direct(const TapConv& d, hipStream_t s);
 int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s);
 bool drs_tapconv_mfma_supported(const TapConv& d, int impl);
+bool drs_tapconv_ws_supported(const TapConv& d, int impl);  // wave-specialised 3x3 kernel (conv_mfma_ws.hip) takes this op
 
 // weight packing: src is torch layout (Cout,Cin,KH,KW) or, transposed, (Cin,Cout,KH,KW).
 // bn = {gamma,beta,running_mean,running_var} or all null.  dst_w layout:
@@ -105,7 +111,8 @@ int drs_launch_pack_conv(const float* w, const float* b, const float* gamma, con
 size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl);
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
-                              int transposed, int impl, hipStream_t s, int cout_src = 0, int flip_taps = 0);
+                              int transposed, int impl, hipStream_t s, int cout_src = 0, int flip_taps = 0, int co_off = 0,
+                              int partial = 0);
 
 int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
                             hipStream_t s);

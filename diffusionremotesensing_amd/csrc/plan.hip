@@ -220,7 +220,12 @@ struct WsTensor {
   bool planar;
 };
 
-struct ResBlock { ConvLayer conv1, conv2, shortcut, skip; bool has_skip; Mlp mlp; };
+struct ResBlock {
+  ConvLayer conv1, conv2, shortcut, skip; bool has_skip; Mlp mlp;
+  // eval split-bf16 plans: conv1 (+BN1) and the skip convolution packed as ONE 2*Cout-channel operand image (TapConv::dual)
+  bool dual = false;
+  size_t dual_w_off = 0, dual_b_off = 0;
+};
 struct DecStage { ConvLayer gate, wg, wx, psi, result, conv, transform, upconv; Mlp mlp; };
 
 }  // namespace
@@ -437,6 +442,15 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     }
     L->b_off = cur; cur += align_up((size_t)L->Cout * 4);
   }
+  for (int i = 0; i < 4; ++i) {
+    ResBlock& rb = p->enc[i];
+    rb.dual = rb.has_skip && !(cfg->flags & DRS_PLAN_TRAIN) && cfg->impl == DRS_IMPL_MFMA_BF16X3 && rb.conv1.Cout == 32 &&
+              rb.skip.Cout == 32 && rb.skip.Cin == rb.conv1.Cin;
+    if (rb.dual) {
+      rb.dual_w_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(64, rb.conv1.Cin, 9, DRS_IMPL_MFMA_BF16X3));
+      rb.dual_b_off = cur; cur += align_up((size_t)64 * 4);
+    }
+  }
   for (PlanarConv* L : p->planars) {
     L->w_off = cur; cur += align_up((size_t)L->Cout * L->Cin * 9 * 4);
     L->b_off = cur; cur += align_up((size_t)L->Cout * 4);
@@ -590,6 +604,18 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
       rc = drs_launch_pack_conv(F(L->w), F(L->b), g, be, rm, rv, plan->cfg.bn_eps, (float*)(base + L->w_off),
                                 (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0, 0, s);
     if (rc) return rc;
+  }
+  for (int i = 0; i < 4; ++i) {
+    const ResBlock& rb = plan->enc[i];
+    if (!rb.dual) continue;
+    const ConvLayer& a = rb.conv1;  // channels [0, 32): conv1 with BatchNorm1 folded; [32, 64): the skip convolution
+    const ConvLayer& b = rb.skip;
+    if ((rc = drs_launch_pack_conv_mfma(F(a.w), F(a.b), F(a.bn), F(a.bn + 1), F(a.bn + 2), F(a.bn + 3), plan->cfg.bn_eps,
+                                        base + rb.dual_w_off, (float*)(base + rb.dual_b_off), 64, a.Cin, 9, 0, impl, s, 32, 0, 0, 0)))
+      return rc;
+    if ((rc = drs_launch_pack_conv_mfma(F(b.w), F(b.b), nullptr, nullptr, nullptr, nullptr, 0.f, base + rb.dual_w_off,
+                                        (float*)(base + rb.dual_b_off), 64, b.Cin, 9, 0, impl, s, 32, 0, 32, 1)))
+      return rc;
   }
   for (PlanarConv* L : plan->planars) {
     DRS_CHECK_HIP(hipMemcpyAsync(base + L->w_off, F(L->w), (size_t)L->Cout * L->Cin * 9 * 4, hipMemcpyDeviceToDevice, s));
@@ -786,11 +812,28 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                             1, 1, 0);
       RUN(conv_bn(rb.shortcut, d));
     }
-    if (rb.has_skip) {  // conv_upsampled_lr_img(x_skip), x_skip == block input
+    bool dual = false;
+    if (rb.dual && !train && !(c.flags & DRS_PLAN_KEEP_ALL)) {
+      // h = relu(BN1(conv1(x))) + skip(x) + relu(time_mlp(t)) in ONE launch: the skip tensor never exists in HBM
+      TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, (const float*)(pk + rb.dual_w_off), (const float*)(pk + rb.dual_b_off),
+                            TP(plan->t_H[i]), co, co, 0, 3, 3, 1, 1);
+      d.dual = 1;
+      d.relu_pre = 1;
+      d.post_add = temb + rb.mlp.temb_off; d.post_cs = plan->temb_total;
+      if (drs_tapconv_ws_supported(d, c.impl)) {
+        const std::string& wn = plan->params[rb.conv1.w].name;
+        prof_begin(plan, wn.substr(0, wn.size() - 7) + "+skip", 2.0 * conv_flops(d), conv_bytes(d), s);
+        rc = drs_launch_tapconv_mfma(d, c.impl, s);
+        prof_end(plan, s);
+        if (rc) return rc;
+        dual = true;
+      }
+    }
+    if (rb.has_skip && !dual) {  // conv_upsampled_lr_img(x_skip), x_skip == block input
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.skip), PB(rb.skip), TP(plan->t_K0), co, co, 0, 3, 3, 1, 1);
       RUN(plan_conv(plan, rb.skip, d, s));
     }
-    {  // h = relu(BN1(conv1(x))) [+ skip] + relu(time_mlp(t))
+    if (!dual) {  // h = relu(BN1(conv1(x))) [+ skip] + relu(time_mlp(t))
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.conv1), PB(rb.conv1), TP(plan->t_H[i]), co, co, 0, 3, 3, 1,
                             1);
       d.relu_pre = 1;
