@@ -12,6 +12,7 @@ N > 1 is launched by the driver through torch.distributed.run (one rank per GPU,
 """
 import argparse
 import json
+import re
 import os
 import platform
 import sys
@@ -256,11 +257,11 @@ def main():
             x.copy_(x_cpu)
             ops = engine.profile_forward(x, t.fill_(750), lr, MAG, iters=5)
         # dominant kernel = the 3x3 stride-1 implicit-GEMM family (tapconv_ws_kernel / tapconv_mfma_kernel<.., CONV3X3>):
-        # every conv1 / conv2 / skip conv of the residual blocks, ups.*.conv and up_convs.0/1 (up_convs.2 is the
-        # fused-projection instantiation and is listed separately).  achieved = algorithmic FLOPs of those launches
+        # every conv1 / conv2 / skip conv of the residual blocks (block 0: conv1 + skip fused into one launch), ups.*.conv
+        # and up_convs.0/1 (up_convs.2 is the fused-projection instantiation and is listed separately).  achieved = algorithmic FLOPs of those launches
         # (2*MACs) / their HIP-event durations, i.e. FLOPs per launch / average launch duration.
         def is_dom(name):
-            return (name.endswith((".conv1.0", ".conv2.0", ".conv_upsampled_lr_img")) or
+            return (name.endswith((".conv1.0", ".conv2.0", ".conv_upsampled_lr_img", ".conv1.0+skip")) or
                     (name.startswith("ups.") and name.endswith(".conv")) or name in ("up_convs.0", "up_convs.1"))
         conv = [o for o in ops if o[2] > 0 and o[0] not in ("lr_branch", "conv0")]
         dom = [o for o in conv if is_dom(o[0])] if args.impl != "direct" else conv
@@ -279,7 +280,8 @@ def main():
             # CONV3X3 schedule of tapconv_mfma_kernel for the rest): launch-weighted mean of their measured HBM bytes
             tot_b = tot_n = 0.0
             for kname, e in json.load(open(tpath))["kernels"].items():
-                fused_projection = kname.rstrip().endswith("32, true>")  # up_convs.2: listed on its own, not in `dom`
+                # tapconv_ws_kernel<P, HAS2, BNB, FUSE, DUAL>: FUSE = up_convs.2, listed on its own, not in `dom`
+                fused_projection = re.search(r"tapconv_ws_kernel<[^,]+, (true|false), \d+, true", kname) is not None
                 if (("PolicyBF16X3, 32, 4, 1," in kname or ("tapconv_ws_kernel<PolicyBF16X3" in kname and not fused_projection))
                         and "hbm_bytes_per_launch" in e):
                     tot_b += e["hbm_bytes_per_launch"] * e["launches_per_forward"]
