@@ -1,4 +1,9 @@
-// Wave-specialised 3x3 stride-1 tap-convolution for the wide layers (Cout % 64 == 0, Cin % KC == 0).
+// Wave-specialised 3x3 stride-1 tap-convolution for the wide layers (Cin % KC == 0).  Flavours (template arguments):
+//   BNB = 64  Cout % 64 == 0: two channel groups x 4 row-waves per block (described below);
+//   BNB = 32  one channel group x 8 row-waves of 2 rows (Cout = 32: up_convs.2, with FUSE = the fused output projection);
+//   DUAL      TapConv::dual: conv1 + skip convolution of a residual block from ONE 64-channel operand image, 8 row-waves
+//             x 4 channel tiles, the epilogue adds a lane's tiles t (main, ReLU) and t + 2 (skip);
+//   HAS2      the block's 1x1 shortcut input as extra one-tap K-chunks.
 //
 // Same GEMM view, operand slots, MFMA schedule and epilogue as tapconv_mfma_kernel<.., CONV3X3, .., NWG = 2>
 // (conv_mfma.hip); what changes is WHO moves the operands and WHEN.  In that kernel every wave alternates between
