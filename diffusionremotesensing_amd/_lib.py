@@ -35,6 +35,7 @@ SIGNATURES = {
     "drs_sampler_step": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _L, _P]),
     "drs_sampler_step_cfg": (_I, [_P, _P, _P, C.c_float, _P, _I, _P, _P, _P, _I, C.c_int64, _P]),
     "drs_adam_multi": (_I, [_P, _I, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
+    "drs_ema_multi": (_I, [_P, _I, C.c_int64, C.c_double, _I, _P]),
     "drs_downblur_scratch_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "drs_downblur_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _Z, _P]),
     "drs_aggregate_tiles": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

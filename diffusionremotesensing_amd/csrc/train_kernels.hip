@@ -574,3 +574,34 @@ extern "C" int drs_adam_multi(const drs_adam_tensor* table, int ntensors, int64_
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-tensor EMA of the parameters (include/drs_hip.h: drs_ema_multi; reference EMA, UNet_model_superres.py:12-55):
+// grid = (chunks of the largest tensor, tensors).  mode 0: old * beta + (1 - beta) * new with torch's rounding (scalar
+// operands rounded to fp32, two products and one sum, no fused multiply-add); mode 1: word copy (warm-up).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ema_multi_kernel(const drs_ema_tensor* __restrict__ table, float beta, float w, int mode) {
+  const drs_ema_tensor t = table[blockIdx.y];
+  const long long lo = (long long)blockIdx.x * 4096;
+  if (lo >= t.n) return;
+  const long long hi = min((long long)t.n, lo + 4096);
+  if (mode == 1) {
+    unsigned* dst = (unsigned*)t.ema;
+    const unsigned* src = (const unsigned*)t.cur;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) dst[i] = src[i];
+  } else {
+    float* e = (float*)t.ema;
+    const float* c = (const float*)t.cur;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) e[i] = __fadd_rn(__fmul_rn(e[i], beta), __fmul_rn(w, c[i]));
+  }
+}
+extern "C" int drs_ema_multi(const drs_ema_tensor* table, int ntensors, int64_t max_numel, double beta, int mode,
+                             drs_stream_t stream) {
+  DRS_REQUIRE(table && ntensors >= 0 && (mode == 0 || mode == 1), DRS_ERR_ARG, "ema_multi: bad arguments");
+  if (ntensors == 0 || max_numel <= 0) return DRS_OK;
+  const unsigned gx = (unsigned)((max_numel + 4095) / 4096);
+  hipLaunchKernelGGL(ema_multi_kernel, dim3(gx, ntensors), dim3(256), 0, (hipStream_t)stream, table, (float)beta,
+                     (float)(1.0 - beta), mode);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}

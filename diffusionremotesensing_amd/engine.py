@@ -134,7 +134,9 @@ class HipUNetEngine:
             if t.numel() != numel:
                 raise RuntimeError(f"parameter {name} has {t.numel()} elements, plan expects {numel}")
             tensors.append(t)
-        sig = tuple((t.data_ptr(), t._version) for t in tensors) + (self._bn_epoch,)
+        # `_drs_param_epoch`: bumped by updates that write the parameters through the C-ABI (multi-tensor EMA), which torch's
+        # version counters do not see
+        sig = tuple((t.data_ptr(), t._version) for t in tensors) + (self._bn_epoch, getattr(self._module(), "_drs_param_epoch", 0))
         if sig == plan.signature:
             return
         arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

@@ -91,6 +91,21 @@ typedef struct drs_adam_tensor {
 int drs_adam_multi(const drs_adam_tensor* table, int ntensors, int64_t max_numel, double lr, double beta1, double beta2,
                    double eps, drs_stream_t stream);
 
+/* Multi-tensor exponential moving average of the parameters, ONE launch for all tensors:
+ *   mode 0:  ema[i] = ema[i] * beta + (1 - beta) * cur[i]   (fp32; `1 - beta` is formed in double and rounded to fp32, the
+ *            two products and the sum are rounded separately - reference EMA.update_average, UNet_model_superres.py:25-30,
+ *            applied per parameter by EMA.update_model_average :18-23);
+ *   mode 1:  ema[i] = cur[i] as 32-bit words (the warm-up copy of EMA.reset_parameters :52-55, which load_state_dict()s
+ *            parameters AND buffers: int64 counters are two words).
+ * `table` (device): ntensors x drs_ema_tensor {ema, cur, n}; n counts 32-bit elements.  Replaces the 176 (mode 0) /
+ * 299 (mode 1) small kernels of `ema.step_ema(ema_model, model)` in the training loop body, train_diffusion_superres.py:396. */
+typedef struct drs_ema_tensor {
+  void* ema;
+  const void* cur;
+  int64_t n;
+} drs_ema_tensor;
+int drs_ema_multi(const drs_ema_tensor* table, int ntensors, int64_t max_numel, double beta, int mode, drs_stream_t stream);
+
 /* Gaussian-weighted blend of n overlapping super-resolved tiles into one image, normalised and clamped to [0,1]:
  *   out[c][y][x] = clamp( sum_i w[y-y0_i][x-x0_i] * tiles[i][c][y-y0_i][x-x0_i] / sum_i w[y-y0_i][x-x0_i], 0, 1 )
  * over the tiles i (in index order, like the reference's sequential `+=`) whose window [y0_i, y0_i+S) x [x0_i, x0_i+S)

@@ -511,3 +511,39 @@ def test_split_bf16_data_gradients_keep_fp32_grade_accuracy():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.gpu
+def test_ema_multi_tensor_matches_reference_formula(dev, seeded_sd):
+    """EMA on device models = ONE `drs_ema_multi` launch: bit-identical to the reference's per-parameter
+    `old * beta + (1 - beta) * new` (UNet_model_superres.py:18-30) and, during warm-up, to `load_state_dict`
+    (parameters and buffers, including the int64 BatchNorm counters)."""
+    import copy
+    from diffusionremotesensing_amd.UNet_model_superres import EMA, Residual_Attention_UNet_superres
+    from diffusionremotesensing_amd import synthetic
+    a = Residual_Attention_UNet_superres(3, 3, dev)
+    a.load_state_dict(seeded_sd)
+    a = a.to(dev)
+    b = Residual_Attention_UNet_superres(3, 3, dev)
+    b.load_state_dict(synthetic.seeded_state_dict(b.state_dict(), 7))
+    b = b.to(dev)
+    for m in b.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.num_batches_tracked.fill_(12345678901)  # needs both 32-bit halves
+    ema_model = copy.deepcopy(a).eval().requires_grad_(False)
+    ema = EMA(0.995)
+    ema.step_ema(ema_model, b, step_start_ema=1)  # warm-up: copy of the whole state_dict
+    for (k, p), q in zip(ema_model.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(p, q), k
+    old = [p.detach().clone() for p in ema_model.parameters()]
+    ema.step_ema(ema_model, a, step_start_ema=1)
+    for (name, p), o, new in zip(ema_model.named_parameters(), old, a.parameters()):
+        assert torch.equal(p, o * 0.995 + (1 - 0.995) * new.detach()), name
+    assert ema.step == 2
+    # the folded weights of the EMA model follow the update (the engine watches the module's parameter epoch)
+    x, t, lr = golden_inputs("g3", 2, 2, 3, 16, 2, 1500)
+    with torch.no_grad():
+        y1 = ema_model(x.to(dev), t.to(dev), lr.to(dev), 2).clone()
+        ema.step_ema(ema_model, b, step_start_ema=1)
+        y2 = ema_model(x.to(dev), t.to(dev), lr.to(dev), 2)
+    assert not torch.equal(y1, y2)
