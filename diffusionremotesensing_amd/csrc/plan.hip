@@ -21,7 +21,7 @@ void DrsErr::set(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* drs_last_error(void) { return g_err; }
-extern "C" int drs_abi_version(void) { return 3; }
+extern "C" int drs_abi_version(void) { return 4; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
