@@ -33,10 +33,22 @@ DTYPE = {"direct": "f32", "mfma_f32": "f32", "mfma_bf16x3": "bf16x3 (hi+lo split
 HBM_PEAK_GBS = 8000.0
 
 
+def _host_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(sd, x, t, lr):
-    """The oracle (CPU port of the reference graph, stock torch ops) on this box's host cores: bounded sample of
-    the same workload = 1 warm-up + 2 timed 16-image forwards."""
-    from oracle import unet_oracle
+    """The oracle (CPU port of the reference graph, stock torch ops) on this box's host cores, BASELINE.md section 3
+    protocol: 1 warm-up + 5 timed 16-image forwards of configs[1] (min and median), and the configs[0] end-to-end
+    `sample` (n=4, 64x64 -> 128x128, T=50: 49 forwards + updates).  About 20 s of CPU work."""
+    from oracle import diffusion_oracle, unet_oracle
+    from diffusionremotesensing_amd import synthetic
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -47,14 +59,47 @@ def cpu_baseline(sd, x, t, lr):
     with torch.no_grad():
         unet_oracle.unet_forward(sd, x, t, lr, MAG)
         times = []
-        for _ in range(2):
+        for _ in range(5):
             t0 = time.perf_counter()
             unet_oracle.unet_forward(sd, x, t, lr, MAG)
             times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": 1.0 / best, "unit": "batch16_steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"2 timed eval forwards of the B=16 256x256 batch after 1 warm-up (min {best:.3f} s), "
-                      f"torch {torch.__version__} CPU ops, {platform.processor() or platform.machine()}"}
+        a, ah, b = diffusion_oracle.schedule("cosine", 50)
+        lr1 = synthetic.tensor_uniform("g7.cfg1.lr", (3, 64, 64))
+        gen = torch.Generator().manual_seed(4321)
+        t0 = time.perf_counter()
+        diffusion_oracle.sample(unet_oracle.OracleUNet(sd), 4, lr1, 50, a, ah, b, 2, 128,
+                                noise_source=lambda i, shape: torch.randn(shape, generator=gen))
+        cfg1_s = time.perf_counter() - t0
+    best, med = min(times), sorted(times)[len(times) // 2]
+    return {"value": round(1.0 / best, 4), "unit": "batch16_steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "median_forward_s": round(med, 3), "config0_sample_s": round(cfg1_s, 3),
+            "sample": f"5 timed eval forwards of the B=16 256x256 batch after 1 warm-up (min {best:.3f} s, median "
+                      f"{med:.3f} s) + the configs[0] end-to-end sample n=4 128x128 T=50 ({cfg1_s:.2f} s); "
+                      f"torch {torch.__version__} CPU ops, host: {_host_model()}"}
+
+
+def psnr_vs_reference(model, dev, impl):
+    """BASELINE metric "PSNR vs ref": the configs[0] chain (n=4, 64x64 -> 128x128, T=50, cosine) with the reference's CPU
+    generator draws replayed (seed 4321), against the reference's own output committed as a fixture
+    (tests/golden/superres_golden.npz: g7_cfg1_x, made by tools/make_golden.py from the imported reference;
+    train_diffusion_superres.py:207-255).  PSNR on [0,1]-clamped images, like the reference's callers display them."""
+    import numpy as np
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.train_diffusion_superres import Diffusion
+    path = os.path.join(ROOT, "tests", "golden", "superres_golden.npz")
+    if not os.path.exists(path):
+        return None
+    ref = torch.from_numpy(np.load(path)["g7_cfg1_x"]).float()
+    d = Diffusion("cosine", model, "/nonexistent/snapshot.pt", noise_steps=50, device=dev, magnification_factor=MAG,
+                  image_size=128, Degradation_type="DownBlur")
+    gen = torch.Generator().manual_seed(4321)
+    x = d.sample(4, model, synthetic.tensor_uniform("g7.cfg1.lr", (3, 64, 64)), input_channels=3,
+                 noise_source=lambda i, shape: torch.randn(shape, generator=gen)).cpu()
+    model.eval()
+    mse = ((x.clamp(0, 1) - ref.clamp(0, 1)) ** 2).mean().item()
+    rel_l2 = ((x - ref).norm() / ref.norm()).item()
+    return {"psnr_db": round(-10 * torch.log10(torch.tensor(max(mse, 1e-20))).item(), 2), "rel_l2": float(f"{rel_l2:.3e}"),
+            "chain": "configs[0]: n=4, 64x64->128x128, T=50, reference noise replayed; fixture stored as fp16"}
 
 
 def other_workload(args):
@@ -67,7 +112,7 @@ def other_workload(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: there is no CPU path to measure")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or "RANK" in os.environ:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
         dist.init_process_group("nccl")
@@ -84,7 +129,7 @@ def other_workload(args):
         m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 0))
         m = m.to(dev).train()
         d = Diffusion("cosine", m, "/nonexistent/snapshot.pt", noise_steps=1500, device=dev, magnification_factor=2,
-                      image_size=256, Degradation_type="DownBlur", multiple_gpus=world > 1)
+                      image_size=256, Degradation_type="DownBlur", multiple_gpus=dist.is_initialized())
         hr = synthetic.tensor_uniform("train.hr", (16, 3, 256, 256), seed=rank).to(dev)
         lr = synthetic.tensor_uniform("train.lr", (16, 3, 128, 128), seed=rank).to(dev)
         opt = FusedAdam(m.parameters(), lr=1e-4)
@@ -179,6 +224,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--impl", default=os.environ.get("DRS_IMPL", "mfma_bf16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PSNR chain and the exact-fp32 line")
     ap.add_argument("--workload", default="superres", choices=["superres", "train", "sar", "generation"],
                     help="superres = the headline (BASELINE configs[1]); the others are the remaining configs")
     args = ap.parse_args()
@@ -193,7 +239,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: there is no CPU path to measure")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU, RCCL
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
         dist.init_process_group("nccl")
@@ -313,11 +359,37 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Residual_Attention_UNet_superres 128x128->256x256 mag=2 DownBlur, "
                                    "batch 16 per GPU, cosine T=1500, eval-mode UNet forward + ancestral update per step",
                        "batch_per_gpu": BATCH, "image_size": IMAGE, "noise_steps": T_STEPS, "impl": args.impl,
-                       "weights": "seeded random (no pretrained weights exist)"},
+                       "weights": "seeded random (no pretrained weights exist)",
+                       "process_group": torch.distributed.get_backend() if dist.is_initialized() else None},
             "image_steps_per_s": round(value * BATCH, 2),
             "tflops_algorithmic": round(value * GFLOP_PER_FWD / 1e3, 3),
             "roofline": roofline,
         }
+        if not args.no_extras:
+            with torch.no_grad():
+                q = psnr_vs_reference(model, dev, args.impl)
+                if q is not None:
+                    result["psnr_vs_ref_db"] = q["psnr_db"]
+                    result["psnr_detail"] = q
+                if args.impl != "mfma_f32":
+                    # the exact-fp32 line beside the headline (same step, v_mfma_f32_16x16x4_f32 kernels): what the
+                    # precision choice buys, in the driver's own record
+                    engine.set_impl("mfma_f32")
+                    x.copy_(x_cpu)
+                    step(T_STEPS - 1, True)
+                    step(T_STEPS - 2, False)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    nf = max(5, args.steps // 2)
+                    for k in range(nf):
+                        step(T_STEPS - 3 - k, False)
+                    torch.cuda.synchronize()
+                    ms32 = 1e3 * (time.perf_counter() - t1) / nf
+                    engine.set_impl(args.impl)
+                    result["fp32_line"] = {"impl": "mfma_f32", "dtype": "f32", "value": round(1e3 / ms32, 3),
+                                           "unit": "batch16_steps/s", "ms_per_step": round(ms32, 4), "steps": nf,
+                                           "tflops_algorithmic": round(GFLOP_PER_FWD / ms32, 2),
+                                           "frac_of_157TF": round(GFLOP_PER_FWD / ms32 / PEAK_TFLOPS["mfma_f32"], 4)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, x_cpu, torch.full((BATCH,), 750, dtype=torch.int64), lr_cpu)
         if os.environ.get("DRS_BENCH_OPS"):

@@ -24,6 +24,10 @@ from . import dist as drs_dist
 from . import hip_ops
 
 
+# tiles per sampling chain (per rank): bounds the plan workspace (~0.1 GB per 256x256 tile) independently of the scene size
+TILE_BATCH = 16
+
+
 class split_aggregation_sampling:
     def __init__(self, img_lr, patch_size, stride, magnification_factor, diffusion_model, device):
         assert stride <= patch_size
@@ -80,8 +84,28 @@ class split_aggregation_sampling:
         if noise_source is not None:
             def src(i, shape, lo=lo):  # stack the per-tile draws of this rank's tiles
                 return torch.cat([noise_source(lo + k, i, (1,) + tuple(shape[1:])) for k in range(shape[0])], dim=0)
-        mine = d.sample(hi - lo, self.model, lr[lo:hi], input_channels=lr.shape[1], generate_video=False,
-                        noise_source=src) if hi > lo else lr.new_zeros((0, lr.shape[1], d.image_size, d.image_size))
+        # fixed-size chunks of this rank's tiles: one chain per chunk, ONE plan / workspace whatever the scene size (a
+        # 2048 x 2048 scene at stride 32 has ~4000 tiles: as a single batch its workspace would not fit any device).
+        # The last chunk is padded with repeats of its last tile so that it runs on the same plan.
+        chunk = max(1, int(getattr(self, "tile_batch", 0) or TILE_BATCH))
+        outs = []
+        for c0 in range(lo, hi, chunk):
+            c1 = min(c0 + chunk, hi)
+            take = c1 - c0
+            size = take if (hi - lo) <= chunk else chunk  # a scene smaller than one chunk runs at its own size
+            lr_c = lr[c0:c1]
+            if size > take:
+                lr_c = torch.cat([lr_c, lr_c[-1:].expand(size - take, -1, -1, -1)], dim=0).contiguous()
+            csrc = None
+            if src is not None:
+                def csrc(i, shape, c0=c0, take=take):
+                    real = src(i, (take,) + tuple(shape[1:]), lo=c0)
+                    if shape[0] > take:
+                        real = torch.cat([real, real[-1:].expand(shape[0] - take, -1, -1, -1)], dim=0)
+                    return real
+            out_c = d.sample(size, self.model, lr_c, input_channels=lr.shape[1], generate_video=False, noise_source=csrc)
+            outs.append(out_c[:take])
+        mine = torch.cat(outs, dim=0) if outs else lr.new_zeros((0, lr.shape[1], d.image_size, d.image_size))
         if drs_dist.world_size() > 1:
             mine = drs_dist.gather_shards(mine, n)
         return mine

@@ -424,15 +424,10 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
 template <class P, int BN, int RPW, int MODE, bool HAS2 = false, int NWG = 1>
 static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t s) {
   auto kern = tapconv_mfma_kernel<P, BN, RPW, MODE, HAS2, NWG>;
-  static bool attr_done = false;  // per instantiation
-  static int num_cu = 0;
-  if (!attr_done) {
-    DRS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kLdsLimit));
-    int dev = 0;
-    DRS_CHECK_HIP(hipGetDevice(&dev));
-    DRS_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_done = true;
+  int num_cu = 0;
+  {
+    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), kLdsLimit, &num_cu);
+    if (rc) return rc;
   }
   // persistent grid: 2 blocks per CU (what the LDS footprint admits), a multiple of the 8 XCDs, never more than items
   const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / (BN * NWG));

@@ -76,7 +76,7 @@ typedef __attribute__((address_space(3))) unsigned* ws_flag_ptr;
 // wave can take the whole node down): after ~2^22 polls (about a second) the wave traps and the launch fails loudly.
 __device__ __forceinline__ void ws_poll(ws_flag_ptr f, unsigned target) {
   unsigned spins = 0;
-  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
     __builtin_amdgcn_s_sleep(4);
     if (++spins > (1u << 22)) __builtin_trap();
   }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
       WS_STAMP(4);
       // column 2 of k was issued last in the previous burst and is read late in the step: certified by a counter
       ws_wait_vm(vm_issued - end_col[2]);
-      if (lane == 0) __hip_atomic_fetch_add(sLand2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_fetch_add(sLand2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (k + 1 < S) {
         int c1 = c + 1, n1 = n, ty1 = ty0, tx1 = tx0, n01 = n0;
         if (c1 == nck) {
@@ -413,21 +413,21 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
         }
         ws_wait_lds();
         if (lane == 0) {
-          __hip_atomic_fetch_add(sFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(sFlag2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(sFlag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(sFlag2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       } else {
         mma_col(0);
         read_wf(1);
         WS_STAMP(4);
         ws_wait_lds();
-        if (lane == 0) __hip_atomic_fetch_add(sFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // column 1 is in registers: its ring slot may be refilled
+        if (lane == 0) __hip_atomic_fetch_add(sFlag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // column 1 is in registers: its ring slot may be refilled
         WS_STAMP(5);
         mma_col(1);
         ws_poll(sLand2, 4u * (unsigned)(k + 1));
         read_wf(2);
         ws_wait_lds();
-        if (lane == 0) __hip_atomic_fetch_add(sFlag2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_add(sFlag2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         mma_col(2);
       }
       WS_STAMP(6);
@@ -481,15 +481,10 @@ template <class P, bool HAS2, int BNB = 64, bool FUSE = false, bool DUAL = false
 int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
   auto kern = tapconv_ws_kernel<P, HAS2, BNB, FUSE, DUAL>;
   constexpr size_t kLds = WsGeom<P, BNB>::LDS;
-  static bool attr_done = false;
-  static int num_cu = 0;
-  if (!attr_done) {
-    DRS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024));
-    int dev = 0;
-    DRS_CHECK_HIP(hipGetDevice(&dev));
-    DRS_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_done = true;
+  int num_cu = 0;
+  {
+    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
+    if (rc) return rc;
   }
   static_assert(kLds <= 160 * 1024, "LDS budget");
   const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (DUAL ? 1 : d.Cout / BNB);
@@ -528,7 +523,7 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 }  // namespace
 
 // Eligibility of the wave-specialised kernel (3x3 stride 1 on 16-row patches; the caller has established that geometry).
-// DRS_WS: 0 off, bits 0-1: 1 = layers with Cout % 64 == 0, 2 = their pipelined variant (conv_mfma_ws3.hip); bit 2 (4) adds
+// DRS_WS: 0 off, bit 0: layers with Cout % 64 == 0; bit 2 (4) adds
 // the 32-channel flavour (Cout % 64 != 0, incl. the fused output projection of up_convs.2).  Default 5.
 bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
   static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 5;
@@ -561,10 +556,6 @@ static int ws_dispatch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 
 int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStream_t s) {
   DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_ws: geometry");
-  static const int env = getenv("DRS_WS") ? atoi(getenv("DRS_WS")) : 5;
-  if ((env & 3) == 2 && impl == DRS_IMPL_MFMA_BF16X3 && d.Cout % 64 == 0 && !d.fuse_out && d.Cin % 32 == 0 &&
-      (!d.in2 || d.Cin2 % 32 == 0))
-    return drs_launch_tapconv_ws3(d, g, s);  // pipelined variant (opt-in)
   if (impl == DRS_IMPL_MFMA_F32) return ws_dispatch<PolicyF32>(d, g, s);
   return ws_dispatch<PolicyBF16X3>(d, g, s);
 }

@@ -94,6 +94,10 @@ struct DrsErr {
 
 static inline int drs_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Per-DEVICE launch facts: sets the kernel's dynamic-LDS limit once per (current device, kernel) and returns that device's
+// CU count.  Keyed by device, mutex-protected: correct with several devices in one process and from several host threads.
+int drs_kernel_prepare(const void* kernel, int max_dynamic_lds, int* num_cu);
+
 // ---- kernel launchers (each returns a DRS_* status) ------------------------------------------
 int drs_launch_tapconv_direct(const TapConv& d, hipStream_t s);
 int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s);
@@ -129,7 +133,8 @@ int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1
                         const float* b2, float* out, int out_stride, int B, int dim_in, int dim_out, hipStream_t s);
 int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const char* packed, const long long* table,
                               int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in,
-                              const float* label_emb, const long long* labels, int label_batch, hipStream_t s);
+                              const float* label_emb, const long long* labels, int label_batch, int num_classes,
+                              hipStream_t s);
 
 // train-mode BatchNorm (bn_train.hip): statistics of Z, running-stat update, normalise + the block's epilogue
 int drs_launch_bn_train(const float* z, int z_cs, int z_co, long long npix, long long pix_per_image, int C,
@@ -169,5 +174,5 @@ int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre
 int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
                             const float* temb, const float* dtemb, int stride, int B, int dim, float* dW1, float* db1,
                             float* dW2, float* db2, const float* label_emb, const long long* labels, int label_batch,
-                            float* dlabel, hipStream_t s);
+                            int num_classes, float* dlabel, hipStream_t s);
 int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, hipStream_t s);

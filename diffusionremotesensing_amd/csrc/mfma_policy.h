@@ -82,4 +82,3 @@ struct MfmaGeom {
 // wave-specialised 3x3 kernel (conv_mfma_ws.hip); `g` is the CONV3X3 / 512-thread geometry of conv_mfma.hip
 bool drs_tapconv_ws_supported(const TapConv& d, int impl);
 int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStream_t s);
-int drs_launch_tapconv_ws3(const TapConv& d, const MfmaGeom& g, hipStream_t s);  // conv_mfma_ws3.hip (bf16x3 only)

@@ -5,7 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "drs_common.h"
@@ -24,6 +27,28 @@ extern "C" const char* drs_last_error(void) { return g_err; }
 extern "C" int drs_abi_version(void) { return 4; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+int drs_kernel_prepare(const void* kernel, int max_dynamic_lds, int* num_cu) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, bool> attr_set;  // (device, kernel) -> dynamic-LDS attribute applied
+  static std::map<int, int> cus;                                  // device -> CU count
+  int dev = 0;
+  DRS_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cus.find(dev);
+  if (it == cus.end()) {
+    int n = 0;
+    DRS_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    it = cus.emplace(dev, n).first;
+  }
+  *num_cu = it->second;
+  bool& done = attr_set[std::make_pair(dev, kernel)];
+  if (!done && max_dynamic_lds > 0) {
+    DRS_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_dynamic_lds));
+    done = true;
+  }
+  return DRS_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // TapConv builders
@@ -753,7 +778,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   prof_begin(plan, "time_mlp", 0, 0, s);
   RUN(drs_launch_time_mlp_multi(t, inv_freq, pk, (const long long*)(pk + plan->o_mlp_table), (int)plan->mlps.size(), 256,
                                 temb, plan->temb_total, B, 100, labels ? (const float*)(pk + plan->o_label) : nullptr,
-                                (const long long*)labels, label_batch, st_mlp));
+                                (const long long*)labels, label_batch, plan->cfg.num_classes, st_mlp));
   prof_end(plan, s);
   if (concurrent) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, st_mlp));
 

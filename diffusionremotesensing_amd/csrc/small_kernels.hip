@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __re
                                                              const long long* __restrict__ table,
                                                              float* __restrict__ out, int out_stride, int dim_in,
                                                              const float* __restrict__ label_emb,
-                                                             const long long* __restrict__ labels, int label_batch) {
+                                                             const long long* __restrict__ labels, int label_batch,
+                                                             int num_classes) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* e = smem;
   float* h = smem + dim_in;
@@ -358,8 +359,11 @@ __global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __re
   __syncthreads();
   if (labels) {  // class-conditional generation: t += label_emb(y) (reference UNet_model_generation.py:300-301)
     const long long lab = labels[label_batch == 1 ? 0 : b];  // < 0: this row runs unconditionally (no embedding)
+    // a class id >= num_classes never indexes the table (nn.Embedding raises a device assert in the reference): the
+    // row's encoding is poisoned with NaN instead, so the mistake shows in the output without a host synchronisation
     if (lab >= 0)
-      for (int j = threadIdx.x; j < dim_in; j += blockDim.x) e[j] += label_emb[(size_t)lab * dim_in + j];
+      for (int j = threadIdx.x; j < dim_in; j += blockDim.x)
+        e[j] = lab < num_classes ? e[j] + label_emb[(size_t)lab * dim_in + j] : __builtin_nanf("");
     __syncthreads();
   }
   for (int c = threadIdx.x; c < dim_out; c += blockDim.x) {
@@ -380,11 +384,12 @@ __global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __re
 }
 int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const char* packed, const long long* table,
                               int nmlp, int max_dim, float* out, int out_stride, int B, int dim_in,
-                              const float* label_emb, const long long* labels, int label_batch, hipStream_t s) {
+                              const float* label_emb, const long long* labels, int label_batch, int num_classes,
+                              hipStream_t s) {
   if (B == 0 || nmlp == 0) return DRS_OK;
   const size_t shmem = (size_t)(dim_in + max_dim) * sizeof(float);
   hipLaunchKernelGGL(time_mlp_multi_kernel, dim3(B, nmlp), dim3(256), shmem, s, t, inv_freq, packed, table, out,
-                     out_stride, dim_in, label_emb, labels, label_batch);
+                     out_stride, dim_in, label_emb, labels, label_batch, num_classes);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

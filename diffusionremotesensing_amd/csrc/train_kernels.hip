@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
                                                            float* __restrict__ dW2, float* __restrict__ db2,
                                                            const float* __restrict__ label_emb,
                                                            const long long* __restrict__ labels, int label_batch,
-                                                           float* __restrict__ dlabel) {
+                                                           int num_classes, float* __restrict__ dlabel) {
   // Block `blockIdx.x` owns rows [r0, r0 + RB) of dW2 / db2 (index c) and of dW1 / db1 (index k): it re-derives the
   // cheap per-sample vectors (e, pre1, h1, d2: dim x 100 MACs) and keeps its rows' sums over the batch in registers.
   constexpr int RB = 8;
@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
   for (int r = 0; r < RB; ++r) acc2[r] = acc1[r] = 0.f;
   for (int b = 0; b < B; ++b) {
     const float tf = (float)t[b];
-    const long long lab = labels ? labels[label_batch == 1 ? 0 : b] : 0;
+    long long lab = labels ? labels[label_batch == 1 ? 0 : b] : 0;
+    if (lab >= num_classes) lab = -1;  // out-of-range class id (the forward poisoned that row with NaN): never index with it
     if (tid < 50) {
       const float arg = tf * inv_freq[tid];
       e[tid] = sinf(arg);
@@ -486,10 +487,10 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
 int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
                             const float* temb, const float* dtemb, int stride, int B, int dim, float* dW1, float* db1,
                             float* dW2, float* db2, const float* label_emb, const long long* labels, int label_batch,
-                            float* dlabel, hipStream_t s) {
+                            int num_classes, float* dlabel, hipStream_t s) {
   DRS_REQUIRE(dim <= 256, DRS_ERR_SHAPE, "time_mlp_bwd: dim=%d", dim);
   hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3((dim + 7) / 8), dim3(256), 0, s, t, inv_freq, W1, b1, W2, temb, dtemb, stride, B, dim, dW1,
-                     db1, dW2, db2, label_emb, labels, label_batch, dlabel);
+                     db1, dW2, db2, label_emb, labels, label_batch, num_classes, dlabel);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -4,10 +4,11 @@
 Replaces the reference's DistributedDataParallel(find_unused_parameters=True) +
 DistributedSampler wiring (train_diffusion_superres.py:586,631-640,658):
   * sampling shards the n independent reverse chains over ranks, no collective on the data path;
-  * training exchanges ONE flat fp32 gradient vector per step (17.5 MB for the 4.38 M-parameter UNet).
-    xGMI is point-to-point, so a single large all-reduce beats DDP's 1 MiB + 25 MiB buckets and the
-    176-entry "used parameter" bitmap; the 6 parameter tensors that never receive a gradient
-     are skipped statically because `p.grad is None` on every rank alike.
+  * training exchanges ONE flat fp32 gradient vector per step (16 MB for the UNet's live parameters), reduced IN PLACE
+    in the buffer the backward wrote (the `.grad`s are views of it).  xGMI is point-to-point, so a single large
+    all-reduce beats DDP's 1 MiB + 25 MiB buckets; the 6 parameter tensors that never receive a gradient (SURVEY.md
+    quirk Q3) are not part of the plan and have no slot; parameters that MAY go unused on some ranks (label embedding)
+    carry a "used" flag in the same message, which replaces DDP's 176-entry bitmap all-reduce.
 BatchNorm statistics stay local to each rank, like the reference (no SyncBatchNorm).
 """
 import os
@@ -80,19 +81,107 @@ def broadcast_module(module, src=0):
             _unflat_into(flat, group)
 
 
-def allreduce_gradients(module):
-    """Mean of the gradients over ranks through one flat all-reduce (SUM, then / world)."""
+class _PendingReduce:
+    """Handle of one gradient exchange.  `wait()` makes the CURRENT stream wait for the collective, applies the mean and
+    hands every rank the same set of `.grad`s (see `allreduce_gradients`).  Idempotent."""
+
+    def __init__(self, work, flat, n_grad, slots, world, need_div):
+        self.work, self.flat, self.n_grad, self.slots, self.world, self.need_div = work, flat, n_grad, slots, world, need_div
+        self.done = False
+
+    def wait(self):
+        if self.done:
+            return self.n_grad
+        self.done = True
+        if self.work is not None:
+            self.work.wait()  # RCCL: the current stream waits for the communicator's stream; gloo: blocks the host
+        if self.need_div:
+            self.flat[: self.n_grad].div_(self.world)
+        tail = self.flat[self.n_grad:]
+        if tail.numel():  # some parameter can be unused on SOME ranks: who used what, summed over ranks
+            used = tail.tolist()
+            for (p, view, copy_back), u in zip(self.slots, used):
+                if u <= 0:
+                    continue  # unused everywhere: .grad stays None on every rank, Adam skips it everywhere (like DDP)
+                if p.grad is None:
+                    p.grad = view  # unused here, used elsewhere: the averaged gradient, so that Adam steps identically
+                elif copy_back:
+                    p.grad.copy_(view)
+        else:
+            for p, view, copy_back in self.slots:
+                if copy_back:
+                    p.grad.copy_(view)
+        return self.n_grad
+
+
+def allreduce_gradients(module, async_op=False):
+    """Mean of the gradients over ranks through ONE flat all-reduce, replacing DDP's bucketed reducer
+    (reference train_diffusion_superres.py:658, `find_unused_parameters=True`).
+
+    The reduced set is RANK-INVARIANT: every parameter that can receive a gradient has a slot whether or not this rank
+    produced one (the class-conditional trainer drops its label per rank at random, so `label_emb.weight.grad` is None on
+    some ranks only).  Like DDP, a parameter used on ANY rank ends up with the same averaged gradient on EVERY rank
+    (ranks that did not use it contribute zeros); a parameter used on no rank keeps `.grad = None` everywhere.
+      * HIP engine path: `engine.backward` already wrote all gradients into ONE flat buffer that the `.grad`s are views
+        of; it is reduced in place (no gather / scatter copies).  Its tail carries one "used" flag per parameter when
+        the model has parameters that may go unused (label embedding); models without such parameters skip the flags
+        and the host read-back they need.
+      * generic path (any nn.Module; the gloo tests): flat buffer built over all `requires_grad` parameters.
+    `async_op=True` returns a handle whose `wait()` must be called before the optimizer's kernels are enqueued; the
+    collective then overlaps the host-side work in between (optimizer table build)."""
     w = world_size()
     if w == 1:
-        return 0
-    grads = [p.grad for p in module.parameters() if p.grad is not None]
-    if not grads:
-        return 0
-    flat = _flat(grads)
-    td.all_reduce(flat, op=td.ReduceOp.SUM)
-    flat.div_(w)
-    _unflat_into(flat, grads)
-    return flat.numel()
+        return _PendingReduce(None, torch.empty(0), 0, [], 1, False) if async_op else 0
+    slots = None
+    eng = module.__dict__.get("_hip_engine") if hasattr(module, "__dict__") else None
+    buf = eng.last_gradient_buffer() if eng is not None else None
+    if buf is not None:
+        flat, n_grad, entries, has_flags = buf
+        slots = []
+        for p, view in entries:
+            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                slots = None  # gradients were accumulated elsewhere: take the generic path
+                break
+            slots.append((p, view, False))
+        if slots is not None and has_flags:
+            flags = torch.tensor([0.0 if p.grad is None else 1.0 for p, _ in entries], dtype=torch.float32)
+            flat[n_grad:].copy_(flags.pin_memory() if flat.is_cuda else flags, non_blocking=True)
+    if slots is None:  # generic: gather into a fresh flat buffer, zero where this rank has no gradient
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            return _PendingReduce(None, torch.empty(0), 0, [], w, False) if async_op else 0
+        n_grad = sum(p.numel() for p in params)
+        dev = next((p.grad.device for p in params if p.grad is not None), params[0].device)
+        flat = torch.zeros(n_grad + len(params), dtype=torch.float32, device=dev)
+        slots, off = [], 0
+        for i, p in enumerate(params):
+            view = flat[off:off + p.numel()].view_as(p)
+            if p.grad is not None:
+                view.copy_(p.grad)
+                flat[n_grad + i] = 1.0
+            slots.append((p, view, p.grad is not None))
+            off += p.numel()
+    backend = td.get_backend()
+    use_avg = backend == "nccl" and flat.numel() == n_grad  # RCCL averages in the collective; flags must stay sums
+    work = td.all_reduce(flat, op=td.ReduceOp.AVG if use_avg else td.ReduceOp.SUM, async_op=True)
+    pending = _PendingReduce(work, flat, n_grad, slots, w, not use_avg)
+    if async_op:
+        return pending
+    return pending.wait()
+
+
+def allreduce_mean_scalar(value, device=None):
+    """Mean over ranks of a host scalar (validation loss): every rank then takes the same best-loss / early-stopping
+    branch and leaves the training loop together (the reference decides per rank, train_diffusion_superres.py:492-510:
+    with a collective inside the loop that is a deadlock as soon as one rank stops)."""
+    w = world_size()
+    if w == 1:
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return float(t.item()) / w
 
 
 def gather_shards(local, n_total):

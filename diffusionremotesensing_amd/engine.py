@@ -5,6 +5,7 @@ One `_Plan` per (batch, lr_batch, H, W, magnification, device); buffers are size
 288 GB of an MI355X: every intermediate activation keeps its own slot in one workspace
 (about 1.6 GB at batch 16, 256x256), nothing is re-allocated between calls.
 """
+import collections
 import ctypes as C
 import os
 import weakref
@@ -65,7 +66,11 @@ class HipUNetEngine:
         # training steps run the exact-fp32 MFMA kernels by default: gradients pass through ~25 BatchNorm backward
         # cancellations and the split-bf16 rounding (1e-5 per op) grows to ~4e-3 on the deepest (LR encoder) gradients
         self.train_impl = _lib.IMPL_BY_NAME[os.environ.get("DRS_TRAIN_IMPL", "mfma_f32")]
-        self._plans = {}
+        # least-recently-used cache of plans: every distinct (batch, lr batch, H, W, mag, impl, train) owns a workspace
+        # (~1.6 GB at batch 16, 256x256); train + validation + preview + tiler shapes would otherwise pile up
+        self._plans = collections.OrderedDict()
+        self.max_plans = int(os.environ.get("DRS_MAX_PLANS", "6"))
+        self._grad_buffer = None
         self._bn_epoch = 0  # bumped by every train-mode forward (running statistics change under the eval plans)
         self.keep_intermediates = False  # True: every block output stays readable (read_tensor), used by parity tests
         self._inv_freq = inv_freq_table(module.time_emb_dim)
@@ -100,6 +105,8 @@ class HipUNetEngine:
         impl = self.train_impl if train else self.impl
         key = (B, Bl, H, W, mag, device.index, impl, self.keep_intermediates, train)
         plan = self._plans.get(key)
+        if plan is not None:
+            self._plans.move_to_end(key)
         if plan is None:
             m = self._module()
             if self.variant == "sar_to_ndvi":  # UNet_model_SAR_TO_NDVI.py:264-267: x has NDVI_channels, cond SAR_channels
@@ -115,6 +122,8 @@ class HipUNetEngine:
             plan = _Plan(_lib.load(), cfg, device)
             plan.train = train
             self._plans[key] = plan
+            while len(self._plans) > max(self.max_plans, 1):
+                self._plans.popitem(last=False)  # its workspace is freed once no autograd node / caller holds the plan
         return plan
 
     def set_impl(self, impl, train_impl=None):
@@ -193,7 +202,11 @@ class HipUNetEngine:
             labels = labels.to(torch.int64).contiguous()
             if labels.shape not in ((B,), (1,)):
                 raise RuntimeError(f"labels must have shape ({B},) or (1,), got {tuple(labels.shape)}")
-            # (values: class ids in [0, num_classes); -1 marks a row that runs unconditionally)
+            # values: class ids in [0, num_classes); -1 marks a row that runs unconditionally.  An id >= num_classes
+            # (nn.Embedding raises in the reference) never indexes the table on the device: the kernels poison that row
+            # with NaN and skip its embedding gradient; host tensors are checked right here, for free.
+            if not labels.is_cuda and labels.numel() and int(labels.max()) >= int(m.num_classes):
+                raise IndexError(f"class label {int(labels.max())} out of range for num_classes={m.num_classes}")
         x = x.contiguous()
         if has_cond:
             lr_img = lr_img.contiguous()
@@ -233,7 +246,11 @@ class HipUNetEngine:
         lib = plan.lib
         wanted = [(i, n) for i, n in enumerate(plan.param_names) if sd[n].requires_grad]
         total = sum(plan.param_numels[i] for i, _ in wanted)
-        flat = torch.empty(total, dtype=torch.float32, device=plan.device)  # fresh per step: .grad may alias it
+        # parameters that this rank may leave without a gradient while another rank produces one (the label embedding when
+        # the label is dropped): the multi-GPU exchange then appends one "used" flag per parameter to the same buffer
+        has_flags = any(n == "label_emb.weight" for _, n in wanted)
+        flat = torch.empty(total + (len(wanted) if has_flags else 0), dtype=torch.float32,
+                           device=plan.device)  # fresh per step: .grad may alias it
         ptrs = (C.c_void_p * len(plan.param_names))()
         views, off = {}, 0
         for i, n in wanted:
@@ -254,7 +271,13 @@ class HipUNetEngine:
                 int(labels.shape[0]) if labels is not None else 0, C.c_void_p(dout.data_ptr()), ptrs,
                 C.c_void_p(plan.workspace.data_ptr()), plan.ws_bytes, stream)
         _lib.check(st, "drs_unet_backward")
+        self._grad_buffer = (flat, total, [(sd[n], views[n]) for _, n in wanted], has_flags)
         return views
+
+    def last_gradient_buffer(self):
+        """(flat buffer, number of gradient elements, [(parameter, view)], has flag tail) of the last backward: the
+        `.grad`s of the parameters are views of `flat`, which `dist.allreduce_gradients` reduces in place."""
+        return self._grad_buffer
 
     # -- per-op timing (bench.py roofline) ------------------------------------------------------
     def profile_forward(self, x, timestep, lr_img, magnification_factor, iters=5, **kw):

@@ -28,6 +28,9 @@ class Residual_Attention_UNet_generation(_HipUNet):
         self._build_trunk(out_dim, device)
         if num_classes is not None:
             self.label_emb = nn.Embedding(num_classes, self.time_emb_dim).to(device=device)
+            # an unconditional step leaves this parameter without a gradient on THIS rank only: the multi-GPU gradient
+            # exchange and FusedAdam resolve it after the all-reduce (dist.allreduce_gradients)
+            self.label_emb.weight._drs_maybe_unused = True
         self._hip_engine = None
 
     def forward(self, x, timestep, y=None):

@@ -47,6 +47,9 @@ class Diffusion(_SuperresDiffusion):
         engine = net.hip_engine()
         shape = (n, input_channels, self.image_size, self.image_size)
         if target_class is not None:
+            ncls = getattr(net, "num_classes", None)
+            if not target_class.is_cuda and ncls and target_class.numel() and int(target_class.max()) >= int(ncls):
+                raise IndexError(f"target_class {int(target_class.max())} out of range for num_classes={ncls}")
             target_class = target_class.to(self.device)
         with torch.no_grad():
             x = (noise_source(self.noise_steps, shape) if noise_source is not None else torch.randn(shape)).to(self.device)

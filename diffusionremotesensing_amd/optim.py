@@ -25,12 +25,20 @@ class FusedAdam(torch.optim.Optimizer):
         self._tables = {}
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_ready=None):
+        """`grad_ready`, when given, is called after the host-side table build and right before the update kernel is
+        enqueued: the multi-GPU step passes the wait of its asynchronous gradient all-reduce, so the collective overlaps
+        the table build (`dist.allreduce_gradients(async_op=True)`).  Gradients that are None at call time but may be
+        produced by that wait (parameters unused on this rank only) are resolved first."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        if grad_ready is not None and any(p.grad is None and getattr(p, "_drs_maybe_unused", False)
+                                          for g in self.param_groups for p in g["params"]):
+            grad_ready()  # which gradients exist is only known after the exchange
+            grad_ready = None
         for gi, group in enumerate(self.param_groups):
             params = group["params"]
             if not params:
@@ -77,9 +85,17 @@ class FusedAdam(torch.optim.Optimizer):
             ev.record(torch.cuda.current_stream(dev))
             ring["event"][k] = ev
             b1, b2 = group["betas"]
+            if grad_ready is not None:
+                grad_ready()
+                grad_ready = None
             with torch.cuda.device(dev):
                 st = lib.drs_adam_multi(C.c_void_p(devt.data_ptr()), n, max(r[4] for r in rows), float(group["lr"]),
                                         float(b1), float(b2), float(group["eps"]),
                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             _lib.check(st, "drs_adam_multi")
+            # the kernel wrote the parameters through raw pointers: advance their version counters (no kernel launch) so
+            # that everything keyed on `_version` (the engine's packed-weight cache) sees the update
+            torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
+        if grad_ready is not None:
+            grad_ready()
         return loss

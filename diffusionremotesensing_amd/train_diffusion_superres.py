@@ -192,8 +192,16 @@ class Diffusion:
         train_loss = loss_function(predicted_noise, noise)
         train_loss.backward()
         if self.multiple_gpus:
-            drs_dist.allreduce_gradients(model)
-        optimizer.step()
+            # ONE in-place all-reduce of the backward's flat gradient buffer on RCCL's stream, overlapped with the
+            # optimizer's host-side table build; the update kernel is enqueued behind it
+            pending = drs_dist.allreduce_gradients(model, async_op=True)
+            if isinstance(optimizer, FusedAdam):
+                optimizer.step(grad_ready=pending.wait)
+            else:
+                pending.wait()
+                optimizer.step()
+        else:
+            optimizer.step()
         if ema is not None:
             ema.step_ema(ema_model, model)
         return train_loss
@@ -240,6 +248,10 @@ class Diffusion:
                         net = ema_model if self.ema_smoothing else model
                         running_val_loss += loss_function(self._predict(net, x_t, t, self._train_cond(lr_img)), noise)
                 running_val_loss = running_val_loss.item() / max(len(val_loader), 1)
+                if self.multiple_gpus:
+                    # the reference decides per rank on its own validation shard (:492-510, quirk Q9); with a collective in
+                    # every training step the ranks must leave the loop together: one mean over ranks, same branch everywhere
+                    running_val_loss = drs_dist.allreduce_mean_scalar(running_val_loss)
                 print(f"Epoch {epoch}: Running Val loss ({loss}){running_val_loss}")
                 if running_val_loss < best_loss:
                     best_loss = running_val_loss
@@ -318,7 +330,12 @@ def launch(args):
         r, wsz = (drs_dist.rank(), drs_dist.world_size()) if args.multiple_gpus else (0, 1)
 
         def feed(ds):
-            u8 = (ds.hr[r::wsz] * 255).round().clamp(0, 255).to(torch.uint8).to(device)
+            # equal shard sizes on every rank (DistributedSampler pads; here the remainder is dropped): ranks must run
+            # the same number of steps, or the per-step all-reduce of the longer shard never completes
+            per_rank = len(ds) // wsz
+            if per_rank == 0:
+                raise ValueError(f"dataset of {len(ds)} images cannot be sharded over {wsz} ranks")
+            u8 = (ds.hr[r::wsz][:per_rank] * 255).round().clamp(0, 255).to(torch.uint8).to(device)
             return DeviceSuperresFeed(u8, args.magnification_factor, radius, args.batch_size, shuffle=True)
         train_loader, val_loader = feed(train_dataset), feed(val_dataset)
     elif args.multiple_gpus:

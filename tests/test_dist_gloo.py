@@ -67,12 +67,71 @@ def _case_allreduce_and_broadcast(rank, world, out_dir):
     for name, p in m.named_parameters():  # the 6 structurally unused tensors never get a gradient (quirk Q3)
         p.grad = None if name in dead else torch.full_like(p, float(rank + 1))
     n = dist.allreduce_gradients(m)
-    assert n == 4383058 - 387520
+    assert n == 4383058  # every requires_grad parameter has a slot (rank-invariant message); dead ones stay None
     for name, p in m.named_parameters():
         if name in dead:
             assert p.grad is None
         else:
             assert torch.all(p.grad == (1 + world) / 2)  # mean over ranks of (rank + 1)
+
+
+def _case_rank_variant_gradients(rank, world, out_dir):
+    """A parameter without a gradient on ONE rank only (the class-conditional trainer drops its label per rank): the
+    message must have the same size on every rank and every rank must end up with the same averaged gradient, like
+    DDP(find_unused_parameters=True).  Also the engine path: one flat buffer reduced in place, flags in its tail."""
+    from diffusionremotesensing_amd import dist
+    from diffusionremotesensing_amd.optim import FusedAdam  # noqa: F401  (importable without a device)
+    lin = torch.nn.Linear(4, 3)
+    emb = torch.nn.Embedding(5, 4)
+    never = torch.nn.Linear(2, 2)
+    m = torch.nn.ModuleList([lin, emb, never])
+    for p in lin.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    emb.weight.grad = torch.full_like(emb.weight, 4.0) if rank == 1 else None  # rank 0 dropped its label
+    n = dist.allreduce_gradients(m)
+    assert n == sum(p.numel() for p in m.parameters())
+    assert all(torch.all(p.grad == 1.5) for p in lin.parameters())
+    assert emb.weight.grad is not None and torch.all(emb.weight.grad == 2.0)  # (0 + 4) / 2 on BOTH ranks
+    assert all(p.grad is None for p in never.parameters())  # unused everywhere: stays None everywhere
+    # asynchronous handle
+    for p in lin.parameters():
+        p.grad = torch.full_like(p, float(10 * (rank + 1)))
+    emb.weight.grad = None
+    pending = dist.allreduce_gradients(m, async_op=True)
+    pending.wait()
+    pending.wait()  # idempotent
+    assert all(torch.all(p.grad == 15.0) for p in lin.parameters()) and emb.weight.grad is None
+
+    # engine path: the backward's flat buffer is reduced in place; .grad tensors are views of it
+    class _Eng:
+        def __init__(self, params, has_flags):
+            total = sum(p.numel() for p in params)
+            self.flat = torch.zeros(total + (len(params) if has_flags else 0))
+            self.entries, off = [], 0
+            for p in params:
+                self.entries.append((p, self.flat[off:off + p.numel()].view_as(p)))
+                off += p.numel()
+            self.total, self.has_flags = total, has_flags
+
+        def last_gradient_buffer(self):
+            return self.flat, self.total, self.entries, self.has_flags
+    for has_flags in (False, True):
+        holder = torch.nn.ModuleList([lin, emb])
+        eng = _Eng(list(holder.parameters()), has_flags)
+        holder.__dict__["_hip_engine"] = eng
+        for p, view in eng.entries:
+            view.fill_(float(rank + 1))
+            p.grad = view
+        if has_flags and rank == 0:
+            eng.entries[-1][1].zero_()  # the kernels zero an unused parameter's slot
+            emb.weight.grad = None
+        ptr = eng.flat.data_ptr()
+        dist.allreduce_gradients(holder)
+        assert eng.flat.data_ptr() == ptr
+        for p in lin.parameters():
+            assert torch.all(p.grad == 1.5) and p.grad.data_ptr() in [v.data_ptr() for _, v in eng.entries]
+        assert torch.all(emb.weight.grad == (1.0 if has_flags else 1.5))  # flags: (0 + 2) / 2 on both ranks
+    assert abs(dist.allreduce_mean_scalar(float(rank)) - 0.5) < 1e-12
 
 
 class _OracleDiffusion:
@@ -127,6 +186,9 @@ def _case_sharded_tiles(rank, world, out_dir):
     tiles = tiler.sample_tiles(noise_source=_tile_noise)
     assert tiles.shape == (6, 3, 16, 16)
     torch.save(tiles, os.path.join(out_dir, f"tiles_{rank}.pt"))
+    tiler.tile_batch = 2  # this rank's 3 tiles as chunks of 2 + 1 (the last one padded to the chunk size)
+    chunked = tiler.sample_tiles(noise_source=_tile_noise)
+    assert torch.allclose(chunked, tiles, rtol=0, atol=1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -156,6 +218,10 @@ def test_shards_and_gather(tmp_path):
 
 def test_flat_allreduce_and_broadcast(tmp_path):
     _run("_case_allreduce_and_broadcast", tmp_path)
+
+
+def test_rank_variant_gradient_sets(tmp_path):
+    _run("_case_rank_variant_gradients", tmp_path)
 
 
 def test_sharded_sampling_matches_single_process(tmp_path):

@@ -297,8 +297,48 @@ def test_end_to_end_sample_golden(dev, model, golden, impl):
     mse = ((x.clamp(0, 1) - ref.clamp(0, 1)) ** 2).mean().item()
     psnr = float("inf") if mse == 0 else -10 * torch.log10(torch.tensor(mse)).item()
     print(f"e2e sample [{impl}]: max-rel {e_max:.3e} rel-L2 {e_l2:.3e} PSNR {psnr:.1f} dB")
-    # 49 chained forwards amplify rounding differences; the chain is still held to the per-forward tolerance
-    assert e_l2 <= (1e-4 if impl in ("direct", "mfma_f32") else 5e-3) and psnr > 40
+    # 49 chained forwards amplify rounding differences.  Bounds = ~10x what was measured on MI355X (fp32 kernels 2e-6 /
+    # 101 dB, split-bf16 2.5e-5 / 78 dB): a regression of one order of magnitude fails
+    if impl in ("direct", "mfma_f32"):
+        assert e_l2 <= 3e-5 and psnr >= 85, (e_l2, psnr)
+    elif impl == "mfma_bf16x3":
+        assert e_l2 <= 3e-4 and psnr >= 65, (e_l2, psnr)
+    else:
+        assert e_l2 <= 5e-3 and psnr > 40, (e_l2, psnr)
+
+
+def _psnr_clamped(a, b):
+    mse = ((a.clamp(0, 1) - b.clamp(0, 1)) ** 2).mean().item()
+    return float("inf") if mse == 0 else -10 * torch.log10(torch.tensor(mse)).item()
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_config1_sample_chain_golden(dev, model, golden, impl):
+    """BASELINE configs[0] end to end (the reference's own CPU-runnable case): Diffusion.sample with n=4, 64x64 -> 128x128,
+    T=50, cosine, the reference's CPU-generator draws replayed (seed 4321) against the reference's output G7 `cfg1`
+    (train_diffusion_superres.py:207-255; stored as fp16 + fp64 checksums by tools/make_golden.py).  This is the
+    "PSNR vs ref" of BASELINE.json's metric."""
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.train_diffusion_superres import Diffusion
+    model.hip_engine().set_impl(impl)
+    d = Diffusion("cosine", model, "/nonexistent/snapshot.pt", noise_steps=50, device=dev, magnification_factor=2,
+                  image_size=128, Degradation_type="DownBlur")
+    lr1 = synthetic.tensor_uniform("g7.cfg1.lr", (3, 64, 64))
+    x = d.sample(4, model, lr1, input_channels=3, noise_source=replay_noise_source(4321)).cpu()
+    model.eval()
+    ref = torch.from_numpy(golden["g7_cfg1_x"]).float()
+    assert x.shape == ref.shape == (4, 3, 128, 128)
+    e_max, e_l2 = rel_errors(x, ref)
+    psnr = _psnr_clamped(x, ref)
+    csum = golden["g7_cfg1_checksum"]  # fp64 sum and abs-sum of the reference's fp32 output
+    d_sum = abs(x.double().sum().item() - csum[0]) / csum[1]
+    d_abs = abs(x.double().abs().sum().item() - csum[1]) / csum[1]
+    print(f"config-1 chain [{impl}]: max-rel {e_max:.3e} rel-L2 {e_l2:.3e} PSNR {psnr:.1f} dB checksum {d_sum:.2e} {d_abs:.2e}")
+    # the fixture itself is fp16-rounded (2^-11 relative per element: ~2.5e-4 rel-L2); the checksums are exact
+    tol = 4e-4 if impl != "mfma_f16" else 5e-3
+    assert e_l2 <= tol and psnr >= (65 if impl != "mfma_f16" else 40), (e_l2, psnr)
+    assert d_sum <= (1e-5 if impl in ("direct", "mfma_f32") else 1e-4 if impl != "mfma_f16" else 1e-2)
+    assert d_abs <= (1e-5 if impl in ("direct", "mfma_f32") else 1e-4 if impl != "mfma_f16" else 1e-2)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -383,6 +423,58 @@ def test_train_step_gradients_golden(dev, seeded_sd, golden, impl):
         if abs(got - ref) > 0.02 * ref + 1e-9:  # Adam's first step is sign-like: only tiny gradients can flip
             badd.append((name, got, float(ref)))
     assert len(badd) <= 4, badd[:12]
+
+
+def test_train_step_config2_per_rank_shape(dev, seeded_sd):
+    """BASELINE configs[2] at its full per-rank size: ONE training step on 16 images of 256x256 (train-mode forward with
+    batch statistics, MSE, backward; loop body of reference train_diffusion_superres.py:378-393) against the CPU oracle's
+    own autograd on the SAME batch: prediction, loss and the gradient of every live parameter (norms, plus three full
+    tensors from the top, the middle and the bottom of the network)."""
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    from oracle import unet_oracle as U
+    m = Residual_Attention_UNet_superres(3, 3, dev)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).train()
+    # (the shipped training default: exact-fp32 MFMA kernels unless DRS_TRAIN_IMPL says otherwise)
+    x, t, lr = golden_inputs("cfg2", 16, 16, 3, 256, 2, 1500)
+    noise = synthetic.tensor_normal("cfg2.noise", (16, 3, 256, 256))
+    pred = m(x.to(dev), t.to(dev), lr.to(dev), 2)
+    loss = torch.nn.MSELoss()(pred, noise.to(dev))
+    loss.backward()
+    assert torch.isfinite(loss).item()
+    # oracle: the same step with torch autograd on the host (about 10 s on the box's 16 cores)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    live = {k for k, _ in m.named_parameters()}
+    sd = {k: (v.clone().requires_grad_(True) if k in live and v.dtype.is_floating_point else v.clone())
+          for k, v in seeded_sd.items()}
+    # the state_dict registers every BatchNorm twice (aliased keys): route both names to ONE leaf
+    for k in list(sd):
+        for a, b in ((".conv1.1.", ".batch_norm1."), (".conv2.1.", ".batch_norm2."), (".shortcut_conv.1.", ".shortcut_batch_norm.")):
+            if a in k:
+                sd[k] = sd[k.replace(a, b)]
+    want = U.unet_forward(sd, x, t, lr, 2, training=True)
+    ref_loss = torch.nn.functional.mse_loss(want, noise)
+    ref_loss.backward()
+    _assert_close(pred.detach(), want.detach(), 1e-4, "configs[2] train-mode prediction")
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * ref_loss.item()
+    scale = max(v.grad.norm().item() for v in sd.values() if v.requires_grad and v.grad is not None)
+    worst, bad = 0.0, []
+    for name, p in m.named_parameters():
+        ref = sd[name].grad
+        if ref is None:
+            assert p.grad is None, f"{name} is structurally unused and must get no gradient"
+            continue
+        assert p.grad is not None, name
+        got, rn = p.grad.norm().item(), ref.norm().item()
+        dev_rel = abs(got - rn) / (rn + 2e-6 * scale)
+        worst = max(worst, dev_rel)
+        if dev_rel > 1e-3:
+            bad.append((name, got, rn))
+    print(f"configs[2] train step: loss {loss.item():.6f} vs {ref_loss.item():.6f}, worst gradient-norm deviation {worst:.2e}")
+    assert not bad, bad[:10]
+    for name in ("output.weight", "bottle_neck.conv2.0.weight", "conv0.weight"):
+        _assert_close(dict(m.named_parameters())[name].grad, sd[name].grad, 2e-3, "grad " + name)
 
 
 def test_diffusion_train_loop_end_to_end(dev, seeded_sd, tmp_path):
@@ -479,12 +571,11 @@ def test_full_length_chain_is_deterministic(dev, model):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ws", ["0", "1", "6"])
+@pytest.mark.parametrize("ws", ["0", "1"])
 def test_conv_kernel_variants_in_subprocess(ws):
     """The 3x3 kernel family is chosen once per process (DRS_WS: 0 = lock-step kernel only, 1 = wave-specialised for
-    the 64-channel-group layers only, 5 = default: + the 32-channel flavour, 6 = pipelined variant + 32-channel
-    flavour).  The default is what every other test runs; the others must reproduce the same goldens.  Own process,
-    because the switch is read once."""
+    the 64-channel-group layers only, 5 = default: + the 32-channel flavour).  The default is what every other test
+    runs; the others must reproduce the same goldens.  Own process, because the switch is read once."""
     import os
     import subprocess
     import sys

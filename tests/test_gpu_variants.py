@@ -135,7 +135,7 @@ def test_sar_sample_golden(dev, seeded_sd_sar, vgolden, impl):
     assert m.training
     e_max, e_l2 = rel_errors(x, torch.from_numpy(vgolden["g8s_x"]))
     print(f"sar sample [{impl}]: max-rel {e_max:.3e} rel-L2 {e_l2:.3e}")
-    assert e_l2 <= (1e-4 if impl == "mfma_f32" else 5e-3)
+    assert e_l2 <= (3e-5 if impl == "mfma_f32" else 5e-4)  # ~10x the measured chain error
 
 
 # ---------------------------------------------------------------------------------------------
@@ -204,7 +204,7 @@ def test_generation_sample_golden(dev, seeded_sd_gen, vgolden, impl):
                      noise_source=replay_noise_source(seed)).cpu()
         e_max, e_l2 = rel_errors(x, torch.from_numpy(vgolden[f"g9s_{tag}_x"]))
         print(f"generation sample {tag} [{impl}]: max-rel {e_max:.3e} rel-L2 {e_l2:.3e}")
-        assert e_l2 <= (1e-4 if impl == "mfma_f32" else 5e-3), tag
+        assert e_l2 <= (3e-5 if impl == "mfma_f32" else 5e-4), tag  # ~10x the measured chain error
 
 
 def test_variant_train_loops(dev, seeded_sd_sar, seeded_sd_gen, tmp_path):
@@ -291,7 +291,8 @@ def test_aggregation_sampling_golden(dev, seeded_sd, vgolden, impl):
     # random weights drive most pixels into the clamp; the un-saturated ones carry the numerical comparison
     mid = (ref > 0) & (ref < 1)
     assert mid.float().mean() > 0.03
-    tol = 1e-4 if impl == "mfma_f32" else 5e-3
+    tol = 3e-5 if impl == "mfma_f32" else 5e-4  # ~10x the measured error
+    print(f"tiler [{impl}]: max abs error of the blended image {(out - ref).abs().max().item():.3e}")
     assert (out - ref).abs().max().item() <= tol, (out - ref).abs().max().item()
     # tile level (un-clamped): the batched chain equals the oracle's per-tile chains
     from oracle import diffusion_oracle as D
@@ -302,7 +303,7 @@ def test_aggregation_sampling_golden(dev, seeded_sd, vgolden, impl):
     y0, x0 = lr_origins[3]
     want = D.sample(U.OracleUNet(seeded_sd), 1, img[0, :, y0:y0 + 32, x0:x0 + 32].cpu(), T, a, ah, b, 2, 64,
                     noise_source=lambda i, shape: src(3, i, shape))
-    _assert_close(tiles[3:4], want, 1e-4 if impl == "mfma_f32" else 5e-3, "tile 3")
+    _assert_close(tiles[3:4], want, 3e-5 if impl == "mfma_f32" else 5e-4, "tile 3")
 
 
 def np_equal(infos, arr):
