@@ -128,6 +128,130 @@ __device__ __forceinline__ void tile_epilogue(const TapConv& d, f32x4 (&acc)[RPW
   }
 }
 
+// ---- SP-format epilogue (TapConv::out_sp): the tile is stored as bf16 hi | lo operand halves -------------------------------
+// The layer's weights were packed with the output-channel permutation of drs_sp_cout_perm(): lane (lr, kg) then holds
+// EIGHT CONSECUTIVE logical channels of pixel lr for every pair of n-tiles: n0 + pr*32 + kg*8 + {0..3} (tile 2*pr) and
+// + {4..7} (tile 2*pr + 1) = one 16-byte hi slot and one 16-byte lo slot of the pixel's 128-byte channel group.
+// Stores: lanes lr and lr^8 swap one half (DPP row rotate, as above) so that every store instruction writes 8 pixels x
+// [4 hi slots | 4 lo slots] = full 128-byte lines: pass 0 covers pixels 0..7 of the row, pass 1 pixels 8..15; lanes
+// lr < 8 store hi slots, lanes lr >= 8 lo slots.
+__device__ __forceinline__ int drs_sp_group_bytes(int cs) { return cs >= 32 ? 64 : cs * 2; }  // bytes of the hi half of a group
+
+typedef __bf16 drs_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void drs_sp_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+  drs_bf16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h[j] = (__bf16)v[j];
+    l[j] = (__bf16)(v[j] - (float)h[j]);
+  }
+  hi = __builtin_bit_cast(u32x4, h);
+  lo = __builtin_bit_cast(u32x4, l);
+}
+__device__ __forceinline__ void drs_sp_join8(const u32x4& hi, const u32x4& lo, float (&v)[8]) {
+  const drs_bf16x8 h = __builtin_bit_cast(drs_bf16x8, hi), l = __builtin_bit_cast(drs_bf16x8, lo);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)h[j] + (float)l[j];
+}
+__device__ __forceinline__ u32x4 drs_dpp_swap8(const u32x4& x) {  // value of lane lr ^ 8 (same k-group row)
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[j], 0x128, 0xf, 0xf, false);
+  return r;
+}
+
+// OUT2: also write TapConv::out2 (= value + post2).  Register-lean: everything is loaded right where it is used.
+template <int RPW, int NT, bool OUT2 = false>
+__device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[RPW][NT], int n, int n0, int ty0, int tx0,
+                                                 int wave, int lr, int kg, int out_oy, int out_ox) {
+  constexpr int NP = NT / 2;
+  const bool lo = lr < 8;
+  const int pl = lr & 7;
+  auto load8 = [&](const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  };
+  // one store pass per half row: lanes lr < 8 write hi slots, lanes lr >= 8 lo slots, of pixels pl (+8): full 128-byte lines
+  auto store_sp = [&](float* base, int cs, int co, const float (&w8)[8], int ty, int oy) {
+    u32x4 H, L;
+    drs_sp_split8(w8, H, L);
+    const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int tx = tx0 + pl + 8 * h;
+      if (ty < d.TH && tx < d.TW) {
+        const size_t opix = ((size_t)n * d.OH + oy) * d.OW + (size_t)tx * d.out_scale + out_ox;
+        char* g = reinterpret_cast<char*>(base) + (opix * cs + co) * 4 + (lo ? 0 : 64) + kg * 16;
+        // pass 0: lanes lr < 8 own the pixel (own hi), lanes lr >= 8 store the received lo of pixel lr - 8;
+        // pass 1: lanes lr < 8 store the received hi of pixel lr + 8, lanes lr >= 8 own the pixel (own lo)
+        *reinterpret_cast<u32x4*>(g) = (h == 0) ? (lo ? H : got) : (lo ? got : L);
+      }
+    }
+  };
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) {
+    const int cg = n0 + pr * 32;       // first logical channel of the 32-channel group
+    const int c8 = cg + kg * 8;        // this lane's 8 channels
+    float bias8[8], post8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias8[j] = post8[j] = 0.f;
+    if (d.bias) load8(d.bias + c8, bias8);
+    if (d.bias2) {
+      float b2[8];
+      load8(d.bias2 + c8, b2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bias8[j] += b2[j];
+    }
+    if (d.post_add) load8(d.post_add + (size_t)n * d.post_cs + c8, post8);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int ty = ty0 + wave * RPW + r;
+      const int oy = min(ty, d.TH - 1) * d.out_scale + out_oy;
+      const int ox_own = min(tx0 + lr, d.TW - 1) * d.out_scale + out_ox;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = acc[r][2 * pr][j]; v[4 + j] = acc[r][2 * pr + 1][j]; }
+      if (d.gate) {
+        const float gv = d.gate[((size_t)n * (d.OH >> 1) + (oy >> 1)) * (d.OW >> 1) + (ox_own >> 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= gv;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] += bias8[j];
+        if (d.relu_pre) v[j] = fmaxf(v[j], 0.f);
+        v[j] += post8[j];
+      }
+      if (d.res) {
+        const size_t rp = d.res_bstride_zero ? (size_t)oy * d.OW + ox_own : ((size_t)n * d.OH + oy) * d.OW + ox_own;
+        float rv[8];
+        if (d.res_sp) {
+          const char* g = reinterpret_cast<const char*>(d.res) + (rp * d.res_cs + d.res_co + cg) * 4 + kg * 16;
+          drs_sp_join8(*reinterpret_cast<const u32x4*>(g), *reinterpret_cast<const u32x4*>(g + 64), rv);
+        } else {
+          load8(d.res + rp * d.res_cs + d.res_co + c8, rv);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rv[j];
+      }
+      if (d.relu_post) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (d.out) store_sp(d.out, d.out_cs, d.out_co + cg, v, ty, oy);
+      if constexpr (OUT2) {
+        if (d.out2) {
+          float p2[8];
+          load8(d.post2 + (size_t)n * d.post2_cs + c8, p2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p2[j] += v[j];
+          store_sp(d.out2, d.out2_cs, d.out2_co + cg, p2, ty, oy);
+        }
+      }
+    }
+  }
+}
+
 // ---- fused 1x1 projection epilogue (the UNet's `output` conv riding on up_convs.2) ------------------------------
 // Works in MFMA layout: lane (lr, kg) holds channels t*16 + kg*4 .. +3 of pixel lr.  y[j] = fuse_b[j] + sum over the 32
 // channels of (acc + bias) * fuse_w[j][co]: 8 in-lane products, then 2 cross-lane steps over the 4 k-group lanes.

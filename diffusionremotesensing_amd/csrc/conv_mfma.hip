@@ -43,7 +43,10 @@ struct ModeTraits {
 // NWG = 2: 512 threads, two groups of 4 waves share ONE staged input window and each compute their own BN output
 // channels (BNB = 64 per block): half the activation loads / conversions / LDS writes per MFMA for layers with
 // Cout % 64 == 0, at one block per CU (117 KB of LDS).
-template <class P, int BN, int RPW, int MODE, bool HAS2, int NWG>
+// SP (compile-time, so that an instantiation carries ONE staging path and ONE epilogue: the kernel sits at the 256-register
+// limit): 0 = fp32 tensors; 1 = the activation operands (in, in2) are in SP format (TapConv::in_sp), fp32 output;
+// 2 = operands and output in SP format
+template <class P, int BN, int RPW, int MODE, bool HAS2, int NWG, int SP = 0>
 __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KC = 4 * P::SLOT_CH;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
   const int nck = g.nchunks + (HAS2 ? g.nchunks2 : 0);  // K-chunks per item: main input, then the optional second input
   const int S = my_items * nck;            // steps (item x chunk) of this block
   if (S == 0) return;
-  auto item_of = [&](int ordinal, int& n_, int& ty0_, int& tx0_, int& n0_) {
+  auto item_of = [&](int ordinal, int& n_, int& ty0_, int& tx0_, int& n0_) __attribute__((always_inline)) {
     int it = lo_item + ordinal * nb8 + j8;
     n0_ = (it % ngroups) * BNB;
     it /= ngroups;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
   const int aq = ((ai & 1) << 1) | (ai >> 3);  // k-group of all of this thread's slots
   const int ap0 = (tid >> 4) * 4 + ((ai & 7) >> 1);
   // window coordinates of slot pixel p: py = p / IW through a 16-bit reciprocal (exact for p < 1024, IW <= 64)
-  auto win_yx = [&](int it, int& py, int& px) {
+  auto win_yx = [&](int it, int& py, int& px) __attribute__((always_inline)) {
     const int p = min(ap0 + it * PPI, npix - 1);
     py = (p * g.iw_magic) >> 16;
     px = p - py * g.IW;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
     const int nn = s % BNB, q = (s / BNB) & 3, tap = s / (BNB * 4);
     w_goff[it] = ((sTapW[tap] * 4 + q) * d.Cout + nn) * 16;
   }
-  const bool has_add = d.in_add != nullptr;
+  const bool has_add = SP == 0 && d.in_add != nullptr;
   const char* wg = reinterpret_cast<const char*>(d.w);
   const size_t w_chunk = (size_t)d.wtaps_total * 4 * d.Cout * 16;
   const int a_qoff = aq * g.a_plane + (aq >> 1) * 128;  // byte offset of this thread's k-group plane
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
 
   bool held_second = false;  // the registers hold a chunk of the second input
   int held_cc = 0;           // its chunk index within its input
-  auto load_step = [&](int k) {  // global -> registers for step k, everything issued back to back
+  auto load_step = [&](int k) __attribute__((always_inline)) {  // global -> registers for step k, everything issued back to back
     const int c = k % nck;
     int ln, lty0, ltx0, ln0;
     item_of(k / nck, ln, lty0, ltx0, ln0);
@@ -156,12 +159,24 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
         a_base[it] = (iyc * d.W + ixc) * d.in_cs + d.in_co;
         a_ok |= (ok ? 1u : 0u) << it;
       }
+      if constexpr (P::IMAGES == 2 && SP != 0) {
+        // SP format: the hi and lo operand slots of this thread's k-group, no conversion
+        const int aqc = (held_cc * KC + aq * P::SLOT_CH < d.Cin) ? aq : 0;
+        const int half = drs_sp_group_bytes(d.in_cs);
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+          const char* gp = reinterpret_cast<const char*>(in_n + a_base[it]) + held_cc * 128 + aqc * 16;
+          areg[it][0] = *reinterpret_cast<const float4*>(gp);
+          areg[it][1] = *reinterpret_cast<const float4*>(gp + half);
+        }
+      } else {
 #pragma unroll
       for (int v = 0; v < V4; ++v) {
         const int ch = min(held_cc * KC + aq * P::SLOT_CH + 4 * v, d.Cin - 4);
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) areg[it][v] = *reinterpret_cast<const float4*>(in_n + a_base[it] + ch);
         if (has_add) addreg[v] = *reinterpret_cast<const float4*>(d.in_add + (size_t)ln * d.in_add_cs + ch);
+      }
       }
 #pragma unroll
       for (int it = 0; it < W_ITERS; ++it)
@@ -182,11 +197,22 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
         a_base[it] = (iyc * d.W2 + ixc) * d.in2_cs + d.in2_co;
         a_ok |= (ok ? 1u : 0u) << it;
       }
+      if constexpr (P::IMAGES == 2 && SP != 0) {
+        const int aqc = (held_cc * KC + aq * P::SLOT_CH < d.Cin2) ? aq : 0;
+        const int half = drs_sp_group_bytes(d.in2_cs);
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+          const char* gp = reinterpret_cast<const char*>(in_n + a_base[it]) + held_cc * 128 + aqc * 16;
+          areg[it][0] = *reinterpret_cast<const float4*>(gp);
+          areg[it][1] = *reinterpret_cast<const float4*>(gp + half);
+        }
+      } else {
 #pragma unroll
       for (int v = 0; v < V4; ++v) {
         const int ch = min(held_cc * KC + aq * P::SLOT_CH + 4 * v, d.Cin2 - 4);
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) areg[it][v] = *reinterpret_cast<const float4*>(in_n + a_base[it] + ch);
+      }
       }
       {  // 1 tap: 4 * BNB weight slots, all in the first staging pass
         const int s2 = min(tid, 4 * BNB - 1);
@@ -197,7 +223,23 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
       }
     }
   };
-  auto store_chunk = [&](int c) {  // registers -> LDS (operand conversion happens here)
+  auto store_chunk = [&](int c) __attribute__((always_inline)) {  // registers -> LDS (operand conversion happens here)
+    if constexpr (P::IMAGES == 2 && SP != 0) {
+      // SP format: the registers hold the operand slots themselves
+      const bool ch_ok = held_cc * KC + aq * P::SLOT_CH < (held_second ? d.Cin2 : d.Cin);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        const int p = ap0 + it * PPI;
+        const bool ok = ch_ok && ((a_ok >> it) & 1u);
+        float4 h = areg[it][0], l = areg[it][1];  // (by value: a conditional on the array elements would take their address)
+        if (!ok) { h = z; l = z; }
+        if (p < npix) {
+          *reinterpret_cast<float4*>(sA + (size_t)a_qoff + (size_t)p * 16) = h;
+          *reinterpret_cast<float4*>(sA + (size_t)g.a_image + (size_t)a_qoff + (size_t)p * 16) = l;
+        }
+      }
+    } else {
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
       const int p = ap0 + it * PPI;
@@ -213,6 +255,7 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
         x[4 * v] = ok ? a.x : 0.f; x[4 * v + 1] = ok ? a.y : 0.f; x[4 * v + 2] = ok ? a.z : 0.f; x[4 * v + 3] = ok ? a.w : 0.f;
       }
       if (p < npix) P::cvt_store(sA, g.a_image, (size_t)a_qoff + (size_t)p * 16, x);
+    }
     }
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it)
@@ -325,10 +368,15 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
     if (c == nck - 1 && !(g.debug & 8)) {  // item complete
       if constexpr (MODE == MODE_CONVT) {
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) tile_epilogue<RPW, NT, false>(d, acc[ph], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
+        for (int ph = 0; ph < 4; ++ph) {
+          if constexpr (SP == 2) tile_epilogue_sp<RPW, NT>(d, acc[ph], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
+          else tile_epilogue<RPW, NT, false>(d, acc[ph], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
+        }
       } else {
         if constexpr (MODE == MODE_CONV3X3_FUSE)
           fuse_epilogue<RPW, NT>(d, acc[0], n, n0 + ng * BN, ty0, tx0, wave, lr, kg);
+        else if constexpr (SP == 2)
+          tile_epilogue_sp<RPW, NT>(d, acc[0], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, d.out_oy, d.out_ox);
         else
           tile_epilogue<RPW, NT, false>(d, acc[0], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, d.out_oy, d.out_ox);
       }
@@ -407,6 +455,16 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
   if (d.fuse_out && (d.Cout != 32 || d.fuse_dim > 4 || (d.in && !is_std3x3(d)) || d.res || d.gate || d.post_add ||
                      d.relu_pre || d.relu_post))
     return false;
+  if ((d.in_sp || d.in2_sp || d.out_sp || d.res_sp || d.out2) && impl != DRS_IMPL_MFMA_BF16X3) return false;
+  // SP instantiations: input(s) and output all in SP format (the plan's SP layers are); fp32 in -> SP out does not occur.
+  // An fp32 OUTPUT from SP inputs (w_g, w_x: their results feed fp32 consumers) is the SP kernel with the fp32 epilogue.
+  if (d.out_sp && !d.in_sp) return false;
+  if (d.in2 && d.in2_sp != d.in_sp) return false;
+  if (d.out2) return false;  // second outputs come from the wave-specialised SP kernel (or a separate add, plan.hip)
+  if (d.in_sp && (d.in_add || (d.in_co & 31) || (d.in_cs != 16 && (d.in_cs & 31)))) return false;
+  if (d.in2_sp && ((d.in2_co & 31) || (d.in2_cs != 16 && (d.in2_cs & 31)))) return false;
+  if (d.out_sp && ((d.out_co & 31) || (d.out_cs & 31) || d.fuse_out || (d.out2 && ((d.out2_co & 31) || (d.out2_cs & 31))))) return false;
+  if (d.res_sp && ((d.res_co & 31) || (d.res_cs & 31))) return false;
   if (d.in == nullptr) return true;  // shape-only probe (weight packing): spatial details decided per launch
   if ((d.in_cs & 3) || (d.in_co & 3) || (d.out_cs & 3) || (d.out_co & 3)) return false;
   if (d.res && ((d.res_cs & 3) || (d.res_co & 3))) return false;
@@ -421,9 +479,9 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
   return geom(d, impl, &g, &bn, &rpw, &mode, &lds);
 }
 
-template <class P, int BN, int RPW, int MODE, bool HAS2 = false, int NWG = 1>
+template <class P, int BN, int RPW, int MODE, bool HAS2 = false, int NWG = 1, int SP = 0>
 static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t s) {
-  auto kern = tapconv_mfma_kernel<P, BN, RPW, MODE, HAS2, NWG>;
+  auto kern = tapconv_mfma_kernel<P, BN, RPW, MODE, HAS2, NWG, SP>;
   int num_cu = 0;
   {
     const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), kLdsLimit, &num_cu);
@@ -442,18 +500,20 @@ static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t
   return DRS_OK;
 }
 
-template <class P>
+template <class P, int SP>
 static int launch_p(const TapConv& d, const MfmaGeom& g, int bn, int rpw, int mode, size_t lds, hipStream_t s) {
-  if (mode == MODE_CONVT) return launch_t<P, 32, 2, MODE_CONVT>(d, g, lds, s);
+  if (mode == MODE_CONVT) return launch_t<P, 32, 2, MODE_CONVT, false, 1, SP>(d, g, lds, s);
   if (bn == 32 && mode == MODE_CONV3X3 && nwg_of(d, mode) == 2) {
-    if (d.in2) return launch_t<P, 32, 4, MODE_CONV3X3, true, 2>(d, g, lds, s);
-    return launch_t<P, 32, 4, MODE_CONV3X3, false, 2>(d, g, lds, s);
+    if (d.in2) return launch_t<P, 32, 4, MODE_CONV3X3, true, 2, SP>(d, g, lds, s);
+    return launch_t<P, 32, 4, MODE_CONV3X3, false, 2, SP>(d, g, lds, s);
   }
-  if (bn == 32 && mode == MODE_CONV3X3 && d.in2) return launch_t<P, 32, 4, MODE_CONV3X3, true>(d, g, lds, s);
-  if (bn == 32 && mode == MODE_CONV3X3) return launch_t<P, 32, 4, MODE_CONV3X3>(d, g, lds, s);
-  if (bn == 32 && mode == MODE_CONV3X3_FUSE) return launch_t<P, 32, 4, MODE_CONV3X3_FUSE>(d, g, lds, s);
-  if (bn == 32 && rpw == 4) return launch_t<P, 32, 4, MODE_GENERIC>(d, g, lds, s);
-  if (bn == 32 && rpw == 2) return launch_t<P, 32, 2, MODE_GENERIC>(d, g, lds, s);
+  if (bn == 32 && mode == MODE_CONV3X3 && d.in2) return launch_t<P, 32, 4, MODE_CONV3X3, true, 1, SP>(d, g, lds, s);
+  if (bn == 32 && mode == MODE_CONV3X3) return launch_t<P, 32, 4, MODE_CONV3X3, false, 1, SP>(d, g, lds, s);
+  if constexpr (SP != 2) {
+    if (bn == 32 && mode == MODE_CONV3X3_FUSE) return launch_t<P, 32, 4, MODE_CONV3X3_FUSE, false, 1, SP>(d, g, lds, s);
+  }
+  if (bn == 32 && rpw == 4) return launch_t<P, 32, 4, MODE_GENERIC, false, 1, SP>(d, g, lds, s);
+  if (bn == 32 && rpw == 2) return launch_t<P, 32, 2, MODE_GENERIC, false, 1, SP>(d, g, lds, s);
   DrsErr::set("tapconv_mfma: no kernel for BN=%d RPW=%d mode=%d", bn, rpw, mode);
   return DRS_ERR_SHAPE;
 }
@@ -467,9 +527,11 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_ws_supported(d, impl))
     return drs_launch_tapconv_ws(d, g, impl, s);
   DRS_REQUIRE(!d.dual, DRS_ERR_SHAPE, "tapconv_mfma: the fused conv1 + skip op needs the wave-specialised kernel");
-  if (impl == DRS_IMPL_MFMA_F32) return launch_p<PolicyF32>(d, g, bn, rpw, mode, lds, s);
-  if (impl == DRS_IMPL_MFMA_F16) return launch_p<PolicyF16>(d, g, bn, rpw, mode, lds, s);
-  return launch_p<PolicyBF16X3>(d, g, bn, rpw, mode, lds, s);
+  if (impl == DRS_IMPL_MFMA_F32) return launch_p<PolicyF32, 0>(d, g, bn, rpw, mode, lds, s);
+  if (impl == DRS_IMPL_MFMA_F16) return launch_p<PolicyF16, 0>(d, g, bn, rpw, mode, lds, s);
+  if (d.in_sp) return d.out_sp ? launch_p<PolicyBF16X3, 2>(d, g, bn, rpw, mode, lds, s)
+                               : launch_p<PolicyBF16X3, 1>(d, g, bn, rpw, mode, lds, s);
+  return launch_p<PolicyBF16X3, 0>(d, g, bn, rpw, mode, lds, s);
 }
 
 // ---- weight packing for the MFMA kernels ------------------------------------------------------------------------
@@ -481,7 +543,7 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
                                       char* __restrict__ dst_w, float* __restrict__ dst_b, int Cout, int Cin, int taps,
                                       int transposed, int nchunks, size_t image_bytes, int cout_src, int flip_taps, int co_off,
-                                      int partial) {
+                                      int partial, int perm) {
   // cout_src < Cout: the source has only cout_src output channels; the rest of the image is zero (a 16-channel
   // output padded to the kernel's 32-channel tile)
   constexpr int KC = 4 * P::SLOT_CH;
@@ -489,7 +551,14 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
   for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (size_t)gridDim.x * blockDim.x) {
     // co_off / partial: the source fills channels [co_off, co_off + cout_src) of a wider image; with `partial` the other
     // channels are left alone (a second layer packed into the same image)
-    const int co = (int)(s % Cout) - co_off;
+    // perm (layers that store their output in SP format): MFMA row 4*kg + j of n-tile t of a 32-channel group carries
+    // logical channel kg*8 + t*4 + j, so that a lane's accumulators of a tile pair are 8 consecutive channels
+    int co_phys = (int)(s % Cout);
+    if (perm) {
+      const int nn = co_phys & 31;
+      co_phys = (co_phys & ~31) + ((nn & 15) >> 2) * 8 + (nn >> 4) * 4 + (nn & 3);
+    }
+    const int co = co_phys - co_off;
     if (partial && (co < 0 || co >= cout_src)) continue;
     const int q = (int)((s / Cout) & 3);
     const int tap = (int)((s / ((size_t)Cout * 4)) % taps);
@@ -534,7 +603,8 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl) {
 
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
-                              int transposed, int impl, hipStream_t s, int cout_src, int flip_taps, int co_off, int partial) {
+                              int transposed, int impl, hipStream_t s, int cout_src, int flip_taps, int co_off, int partial,
+                              int perm) {
   if (cout_src <= 0) cout_src = Cout;
   const int KC = 4 * slot_ch(impl);
   const int nchunks = drs_cdiv(Cin, KC);
@@ -545,7 +615,7 @@ int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma
   if (blocks < 1) blocks = 1;
 #define DRS_PACK(P)                                                                                                   \
   hipLaunchKernelGGL(pack_conv_mfma_kernel<P>, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps,    \
-                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps, co_off, partial)
+                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps, co_off, partial, perm)
   if (impl == DRS_IMPL_MFMA_F32) DRS_PACK(PolicyF32);
   else if (impl == DRS_IMPL_MFMA_F16) DRS_PACK(PolicyF16);
   else DRS_PACK(PolicyBF16X3);

@@ -531,6 +531,7 @@ bool drs_tapconv_ws_supported(const TapConv& d, int impl) {
   if (impl != DRS_IMPL_MFMA_BF16X3 && impl != DRS_IMPL_MFMA_F32) return false;
   const int KC = impl == DRS_IMPL_MFMA_F32 ? 16 : 32;
   if (!d.in || !ws_std3x3(d) || d.shared_cu || d.gate || d.in_add) return false;
+  if (d.in_sp || d.in2_sp || d.out_sp || d.res_sp || d.out2) return false;  // SP-format tensors: conv_mfma_sp.hip
   if (d.dual)  // conv1 + skip in one pass: split-bf16 only, one 32-channel output group, partial K-chunk allowed
     return (env & 4) && impl == DRS_IMPL_MFMA_BF16X3 && d.Cout == 32 && d.Cin % 4 == 0 && d.TH > 8 && !d.in2 && !d.fuse_out &&
            !d.res && d.bias && !(d.in_cs & 3) && !(d.in_co & 3);
@@ -559,3 +560,6 @@ int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStre
   if (impl == DRS_IMPL_MFMA_F32) return ws_dispatch<PolicyF32>(d, g, s);
   return ws_dispatch<PolicyBF16X3>(d, g, s);
 }
+
+// (placeholder until conv_mfma_sp.hip lands)
+bool drs_tapconv_sp_supported(const TapConv&, int) { return false; }

@@ -64,6 +64,21 @@ struct TapConv {
   // either kernel fits on every CU at the same time) and no 512-thread variant; 2 = two blocks per CU for the small-LDS
   // 1x1 flavours (37 KB each next to the partner's 80 KB)
   int shared_cu;
+  // ---- split-bf16 activation storage ("SP" format; eval plans of DRS_IMPL_MFMA_BF16X3) --------------------------------
+  // A tensor in SP format keeps the byte geometry of its fp32 channels-last form (pixel stride = cs * 4 bytes, a group of
+  // 32 channels = 128 bytes), but every 32-channel group holds [32 x bf16 hi | 32 x bf16 lo] with x ~ hi + lo (16
+  // mantissa bits: exactly the operands the split-bf16 MFMA path multiplies) instead of 32 floats.  A 16-channel tensor
+  // (the stem output) is one group of [16 x hi | 16 x lo] = 64 bytes per pixel.  Producers write the operand halves
+  // once, consumers stage them with no conversion (register staging, or LDS-DMA straight into the operand planes).
+  int in_sp, in2_sp, out_sp, res_sp;  // 1: that tensor is in SP format (the pointers stay `float*`: same byte offsets)
+  // optional second output of the epilogue (SP format, channels-last, same spatial size and channel count as `out`):
+  //   out2[n][oy][ox][c] = v[c] + post2[n][c]   (v = the value stored to `out`)
+  // Used for x + relu(time_mlp(t)) of the next UpConvBlock (reference :199): its 3x3 convolution then needs no input add.
+  float* out2;
+  int out2_cs, out2_co;
+  const float* post2;  // [N][post2_cs] (already offset to the layer's slice)
+  int post2_cs;
+  const void* zero_line;  // >= 256 bytes of zeros in device memory (source of out-of-image pixels for LDS-DMA staging)
   // fused pair of 3x3 convolutions of the SAME input (ResConvBlock conv1 + its skip convolution, reference :153-166): `w`
   // is one operand image of 2 * Cout channels [main | skip], `bias` holds 2 * Cout values, and the epilogue computes
   //   out[c] = relu(acc[c] + bias[c]) + post_add[c] + acc[Cout + c] + bias[Cout + c].
@@ -116,18 +131,24 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl);
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
                               int transposed, int impl, hipStream_t s, int cout_src = 0, int flip_taps = 0, int co_off = 0,
-                              int partial = 0);
+                              int partial = 0, int perm = 0);
 
 int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
                             hipStream_t s);
 int drs_launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int src_cs, int src_co,
                             hipStream_t s);
 
+int drs_launch_sp_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int src_cs, int src_co, hipStream_t s);
+
+int drs_launch_sp_add_rowvec(const float* src, float* dst, const float* vec, int vec_stride, int N, long long pix_per_image,
+                             int C, hipStream_t s);
+bool drs_tapconv_sp_supported(const TapConv& d, int impl);  // wave-specialised SP-format 3x3 kernel (conv_mfma_sp.hip) takes this op
+
 // planar (NCHW) small-channel kernels
 int drs_launch_conv3x3_planar(const float* in, const float* w, const float* b, const float* res, float* out, int N,
                               int Cin, int Cout, int H, int W, int relu, hipStream_t s);
 int drs_launch_stem(const float* in_nchw, const float* w, const float* b, const float* res_nhwc, int res_batch,
-                    float* out_nhwc, int N, int Cin, int Cout, int H, int W, hipStream_t s);
+                    float* out_nhwc, int N, int Cin, int Cout, int H, int W, hipStream_t s, int out_sp = 0);
 int drs_launch_bicubic(const float* x, float* y, int N, int C, int H, int W, int scale, hipStream_t s);
 int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
                         const float* b2, float* out, int out_stride, int B, int dim_in, int dim_out, hipStream_t s);

@@ -230,6 +230,7 @@ struct ConvLayer {
   int w = -1, b = -1, bn = -1;  // param indices; bn = index of gamma (beta, mean, var follow)
   int Cout = 0, Cin = 0, taps = 0;
   bool transposed = false, mfma = false;
+  bool out_sp = false;  // this layer stores its output in SP format: weights packed with the output-channel permutation
   size_t w_off = 0, b_off = 0;
   int t_Z = -1;         // train plans: pre-BatchNorm tensor
   size_t stats_off = 0;  // train plans: saved batch mean / rstd (2 x Cout floats) in the workspace
@@ -243,6 +244,7 @@ struct WsTensor {
   int n, c, h, w;
   int cs, co;   // channel stride / offset (NHWC); planar tensors have cs = 0
   bool planar;
+  bool sp = false;  // SP format (split bf16 hi | lo per 32-channel group, drs_common.h)
 };
 
 struct ResBlock {
@@ -271,7 +273,10 @@ struct drs_plan {
   ConvLayer output;
 
   size_t packed_bytes = 0, ws_bytes = 0;
-  size_t o_inv_freq = 0, o_mlp_table = 0, o_out_w = 0, o_out_b = 0, o_label = 0;
+  size_t o_inv_freq = 0, o_mlp_table = 0, o_out_w = 0, o_out_b = 0, o_label = 0, o_zero = 0;
+  // eval plans of the split-bf16 implementation keep every MFMA-consumed activation in SP format (drs_common.h)
+  bool sp = false;
+  int t_XT[3] = {-1, -1, -1};  // x + relu(time_mlp(t)) of UpConvBlock i (reference :199), second output of its producer
   int label_emb = -1;  // param index of label_emb.weight (generation variant)
   int temb_total = 0;
   std::vector<long long> mlp_table_host;
@@ -335,7 +340,7 @@ struct drs_plan {
     return m;
   }
   int T(const std::string& name, size_t& cursor, int n, int c, int h, int w, bool planar = false) {
-    WsTensor t{name, cursor, n, c, h, w, planar ? 0 : c, 0, planar};
+    WsTensor t{name, cursor, n, c, h, w, planar ? 0 : c, 0, planar, false};
     cursor += align_up((size_t)n * c * h * w * 4);
     tensors.push_back(t);
     return (int)tensors.size() - 1;
@@ -385,6 +390,10 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     delete p;
     return DRS_ERR_SHAPE;
   }
+  {
+    static const bool sp_env = !(getenv("DRS_SP") && atoi(getenv("DRS_SP")) == 0);
+    p->sp = sp_env && !(cfg->flags & DRS_PLAN_TRAIN) && cfg->impl == DRS_IMPL_MFMA_BF16X3;
+  }
   const bool has_cond = p->cfg.variant != DRS_VARIANT_GENERATION;
   const std::string enc_name = p->cfg.variant == DRS_VARIANT_SAR_TO_NDVI ? "SAR_encoder" : "LR_encoder";
   const std::string cond_name = p->cfg.variant == DRS_VARIANT_SAR_TO_NDVI ? "conv_SAR_img" : "conv_upsampled_lr_img";
@@ -429,6 +438,18 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     d.upconv = p->mk_conv("up_convs." + si, Ch, Cc + Ch, 9);
   }
   p->output = p->mk_conv("output", cfg->out_dim, kUp[3], 1);
+  if (p->sp) {
+    for (int i = 0; i < 4; ++i) {
+      p->enc[i].conv1.out_sp = p->enc[i].conv2.out_sp = true;
+      p->enc[i].shortcut.out_sp = true;  // rides inside conv2 as extra K-chunks: same accumulator rows, same permutation
+      if (i < 3) p->downs[i].out_sp = true;
+    }
+    for (int i = 0; i < 3; ++i) {
+      DecStage& d = p->dec[i];
+      d.gate.out_sp = d.result.out_sp = d.conv.out_sp = d.transform.out_sp = true;
+      d.upconv.out_sp = i < 2;  // up_convs.2 feeds the fused / direct output projection in fp32
+    }
+  }
 
   // ---- registries ----
   for (int i = 0; i < 4; ++i) {
@@ -490,6 +511,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
   p->o_label = cur; cur += align_up((size_t)(cfg->num_classes > 0 ? cfg->num_classes : 0) * 100 * 4);
   p->o_out_w = cur; cur += align_up((size_t)cfg->out_dim * kUp[3] * 4);
   p->o_out_b = cur; cur += align_up((size_t)cfg->out_dim * 4);
+  p->o_zero = cur; cur += 256;  // a line of zeros: source of out-of-image pixels for LDS-DMA staging
   p->packed_bytes = cur;
 
   // ---- workspace layout ----
@@ -525,6 +547,22 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     p->Tview("ups." + si, p->t_CAT[i], Cc, 0);
     p->Tview("attention_blocks." + si, p->t_CAT[i], Ch, Cc);
     p->t_X[i] = p->T("up_convs." + si, ws, B, Ch, 2 * lh, 2 * lw);
+  }
+  if (p->sp) {
+    for (int i = 0; i < 3; ++i) {
+      const int lh = H >> (3 - i), lw = W >> (3 - i);
+      p->t_XT[i] = p->T("ups." + std::to_string(i) + ".in", ws, B, kUp[i], lh, lw);
+    }
+    auto mark = [&](int t) { p->tensors[t].sp = true; };
+    mark(p->t_x0);
+    for (int i = 0; i < 4; ++i) { mark(p->t_H[i]); mark(p->t_R[i]); if (i < 3) mark(p->t_D[i]); }
+    for (int i = 0; i < 3; ++i) {
+      mark(p->t_G[i]); mark(p->t_U[i]); mark(p->t_CAT[i]); mark(p->t_XT[i]);
+      if (i < 2) mark(p->t_X[i]);
+    }
+    for (WsTensor& t : p->tensors)  // channel-slice views of the concat buffers
+      for (int i = 0; i < 3; ++i)
+        if (t.off == p->tensors[p->t_CAT[i]].off) t.sp = true;
   }
   if (cfg->flags & DRS_PLAN_TRAIN) {
     p->o_bn_sums = ws; ws += align_up(2 * 1024 * sizeof(double));
@@ -624,7 +662,8 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     if (L->bn >= 0 && !(plan->cfg.flags & DRS_PLAN_TRAIN)) { g = F(L->bn); be = F(L->bn + 1); rm = F(L->bn + 2); rv = F(L->bn + 3); }
     if (L->mfma)
       rc = drs_launch_pack_conv_mfma(F(L->w), F(L->b), g, be, rm, rv, plan->cfg.bn_eps, base + L->w_off,
-                                     (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0, impl, s);
+                                     (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0, impl, s, 0, 0, 0,
+                                     0, L->out_sp ? 1 : 0);
     else
       rc = drs_launch_pack_conv(F(L->w), F(L->b), g, be, rm, rv, plan->cfg.bn_eps, (float*)(base + L->w_off),
                                 (float*)(base + L->b_off), L->Cout, L->Cin, L->taps, L->transposed ? 1 : 0, 0, s);
@@ -636,10 +675,12 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     const ConvLayer& a = rb.conv1;  // channels [0, 32): conv1 with BatchNorm1 folded; [32, 64): the skip convolution
     const ConvLayer& b = rb.skip;
     if ((rc = drs_launch_pack_conv_mfma(F(a.w), F(a.b), F(a.bn), F(a.bn + 1), F(a.bn + 2), F(a.bn + 3), plan->cfg.bn_eps,
-                                        base + rb.dual_w_off, (float*)(base + rb.dual_b_off), 64, a.Cin, 9, 0, impl, s, 32, 0, 0, 0)))
+                                        base + rb.dual_w_off, (float*)(base + rb.dual_b_off), 64, a.Cin, 9, 0, impl, s, 32, 0, 0, 0,
+                                        plan->sp ? 1 : 0)))
       return rc;
     if ((rc = drs_launch_pack_conv_mfma(F(b.w), F(b.b), nullptr, nullptr, nullptr, nullptr, 0.f, base + rb.dual_w_off,
-                                        (float*)(base + rb.dual_b_off), 64, b.Cin, 9, 0, impl, s, 32, 0, 32, 1)))
+                                        (float*)(base + rb.dual_b_off), 64, b.Cin, 9, 0, impl, s, 32, 0, 32, 1,
+                                        plan->sp ? 1 : 0)))
       return rc;
   }
   for (PlanarConv* L : plan->planars) {
@@ -670,6 +711,7 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_b, F(plan->output.b), (size_t)plan->cfg.out_dim * 4,
                                  hipMemcpyDeviceToDevice, s));
   }
+  DRS_CHECK_HIP(hipMemsetAsync(base + plan->o_zero, 0, 256, s));
   plan->param_ptrs.assign(params, params + plan->params.size());
   plan->packed_ok = true;
   plan->packed_ptr = packed;
@@ -687,12 +729,20 @@ static void prof_begin(drs_plan* plan, const std::string& name, double flops, do
 static void prof_end(drs_plan* plan, hipStream_t s) {
   if (plan->profiling) (void)hipEventRecord(plan->ops.back().e1, s);
 }
-static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d, hipStream_t s) {
+static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d_in, hipStream_t s) {
+  // second output (TapConv::out2): written by the wave-specialised SP kernel's epilogue; shapes that kernel does not
+  // take get it from a separate pass over the first output
+  TapConv d = d_in;
+  const bool split_out2 = d.out2 && !drs_tapconv_sp_supported(d, plan->cfg.impl);
+  if (split_out2) d.out2 = nullptr;
   std::string name = plan->params[L.w].name;
   name = name.substr(0, name.size() - 7);  // strip ".weight"
   if (d.out_scale == 2 && d.mode != DRS_TAPMODE_CONVT) name += ".phase" + std::to_string(d.out_oy * 2 + d.out_ox);
   prof_begin(plan, name, conv_flops(d), conv_bytes(d), s);
-  const int rc = run_conv(d, L.mfma ? plan->cfg.impl : DRS_IMPL_DIRECT, s);
+  int rc = run_conv(d, L.mfma ? plan->cfg.impl : DRS_IMPL_DIRECT, s);
+  if (!rc && split_out2)
+    rc = drs_launch_sp_add_rowvec(d_in.out, d_in.out2, d_in.post2, d_in.post2_cs, d_in.N, (long long)d_in.OH * d_in.OW,
+                                  d_in.Cout, s);
   prof_end(plan, s);
   return rc;
 }
@@ -730,6 +780,8 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   auto PB = [&](const ConvLayer& L) { return (const float*)(pk + L.b_off); };
   auto TP = [&](int i) { return plan->tp(ws, i); };
   const bool train = (c.flags & DRS_PLAN_TRAIN) != 0;
+  const int sp = plan->sp ? 1 : 0;  // SP-format activations (eval, split-bf16)
+  const void* zero_line = pk + plan->o_zero;
   // A convolution followed by BatchNorm.  Eval: BatchNorm is folded into the weights, one launch.  Train: the raw
   // convolution writes Z (input add and gate act before the norm and stay in the conv), then batch statistics,
   // running-stat update and the normalisation carry the rest of the block's epilogue.
@@ -820,7 +872,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   // --- x = conv0(x) + cond (reference :342,:355) ---
   prof_begin(plan, "conv0", 2.0 * B * H * W * C * kDown[0] * 9, 4.0 * B * H * W * (C + 2.0 * kDown[0]), s);
   RUN(drs_launch_stem(x, (const float*)(pk + plan->stem0.w_off), (const float*)(pk + plan->stem0.b_off),
-                      has_cond ? TP(plan->t_cond) : nullptr, Bl, TP(plan->t_x0), B, C, kDown[0], H, W, s));
+                      has_cond ? TP(plan->t_cond) : nullptr, Bl, TP(plan->t_x0), B, C, kDown[0], H, W, s, plan->sp ? 1 : 0));
   prof_end(plan, s);
 
   if (concurrent) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));  // time embeddings are ready
@@ -835,6 +887,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     if (!fuse_shortcut) {  // shortcut = BNs(conv1x1(x))
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.shortcut), PB(rb.shortcut), TP(plan->t_S[i]), co, co, 0, 1,
                             1, 1, 0);
+      d.in_sp = sp; d.out_sp = rb.shortcut.out_sp ? 1 : 0;
       RUN(conv_bn(rb.shortcut, d));
     }
     bool dual = false;
@@ -844,6 +897,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                             TP(plan->t_H[i]), co, co, 0, 3, 3, 1, 1);
       d.dual = 1;
       d.relu_pre = 1;
+      d.in_sp = d.out_sp = sp; d.zero_line = zero_line;
       d.post_add = temb + rb.mlp.temb_off; d.post_cs = plan->temb_total;
       if (drs_tapconv_ws_supported(d, c.impl)) {
         const std::string& wn = plan->params[rb.conv1.w].name;
@@ -856,12 +910,14 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     }
     if (rb.has_skip && !dual) {  // conv_upsampled_lr_img(x_skip), x_skip == block input
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.skip), PB(rb.skip), TP(plan->t_K0), co, co, 0, 3, 3, 1, 1);
+      d.in_sp = sp; d.zero_line = zero_line;
       RUN(plan_conv(plan, rb.skip, d, s));
     }
     if (!dual) {  // h = relu(BN1(conv1(x))) [+ skip] + relu(time_mlp(t))
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, PW(rb.conv1), PB(rb.conv1), TP(plan->t_H[i]), co, co, 0, 3, 3, 1,
                             1);
       d.relu_pre = 1;
+      d.in_sp = d.out_sp = sp; d.zero_line = zero_line;
       d.post_add = temb + rb.mlp.temb_off; d.post_cs = plan->temb_total;
       if (rb.has_skip) { d.res = TP(plan->t_K0); d.res_cs = co; d.res_co = 0; }
       RUN(conv_bn(rb.conv1, d));
@@ -872,15 +928,22 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       if (fuse_shortcut) {
         d.in2 = xin; d.in2_cs = ci; d.in2_co = 0; d.Cin2 = ci; d.H2 = hh; d.W2 = ww;
         d.w2 = PW(rb.shortcut); d.bias2 = PB(rb.shortcut);
+        d.in2_sp = sp;
       } else {
-        d.res = TP(plan->t_S[i]); d.res_cs = co; d.res_co = 0;
+        d.res = TP(plan->t_S[i]); d.res_cs = co; d.res_co = 0; d.res_sp = rb.shortcut.out_sp ? 1 : 0;
       }
       d.relu_post = 1;
+      d.in_sp = d.out_sp = sp; d.zero_line = zero_line;
+      if (sp && i == 3) {  // second output: x + relu(time_mlp(t)) of the first UpConvBlock (its conv then needs no input add)
+        d.out2 = TP(plan->t_XT[0]); d.out2_cs = co; d.out2_co = 0;
+        d.post2 = temb + plan->dec[0].mlp.temb_off; d.post2_cs = plan->temb_total;
+      }
       RUN(conv_bn(rb.conv2, d));
     }
     if (i < 3) {
       TapConv d = conv_desc(TP(plan->t_R[i]), B, hh, ww, co, co, 0, PW(plan->downs[i]), PB(plan->downs[i]),
                             TP(plan->t_D[i]), co, co, 0, 3, 3, 2, 1);
+      d.in_sp = d.out_sp = sp;
       RUN(plan_conv(plan, plan->downs[i], d, s));
       xin = TP(plan->t_D[i]);
     }
@@ -919,6 +982,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.gate), PB(st.gate), TP(plan->t_G[i]), Ch, Ch, 0, 1, 1, 1,
                             0);
       d.relu_pre = 1;
+      d.in_sp = d.out_sp = sp;
       RUN(att_conv(st.gate, d));
     }
     // (fusing w_g into the stride-2 w_x kernel was measured slower: its 16x32 window staging is 4x too large for g;
@@ -927,6 +991,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       {  // g1 = w_g(g)   (:101)
         TapConv d = conv_desc(TP(plan->t_G[i]), B, lh, lw, Ch, Ch, 0, PW(st.wg), PB(st.wg), TP(plan->t_Q[i]), Ch, Ch, 0, 1,
                               1, 1, 0);
+        d.in_sp = sp;
         RUN(att_plain(st.wg, d));
       }
       {  // relu(g1 + w_x(x))   (:102-103)
@@ -934,6 +999,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                               2, 0);
         d.res = TP(plan->t_Q[i]); d.res_cs = Ch; d.res_co = 0;
         d.relu_post = 1;
+        d.in_sp = sp;
         RUN(att_plain(st.wx, d));
       }
     }
@@ -947,6 +1013,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       TapConv d = conv_desc(xres, B, 2 * lh, 2 * lw, Ch, Ch, 0, PW(st.result), PB(st.result), cat, Ch, Cc + Ch, Cc, 1, 1,
                             1, 0);
       d.gate = TP(plan->t_PSI[i]);
+      d.in_sp = d.out_sp = sp;
       RUN(att_conv(st.result, d));
       if (concurrent) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, sa));
     }
@@ -954,7 +1021,12 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.conv), PB(st.conv), TP(plan->t_U[i]), Cc, Cc, 0, 3, 3, 1,
                             1);
       d.relu_pre = 1;
-      d.in_add = temb + st.mlp.temb_off; d.in_add_cs = plan->temb_total;
+      if (sp) {  // the producer of the stage input also wrote x + relu(time_mlp(t)) (TapConv::out2)
+        d.in = TP(plan->t_XT[i]);
+        d.in_sp = d.out_sp = 1; d.zero_line = zero_line;
+      } else {
+        d.in_add = temb + st.mlp.temb_off; d.in_add_cs = plan->temb_total;
+      }
       d.shared_cu = concurrent ? 1 : 0;
       RUN(conv_bn(st.conv, d));
     }
@@ -962,6 +1034,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       TapConv d = convT_fused_desc(TP(plan->t_U[i]), B, lh, lw, Cc, Cc, 0, PW(st.transform), PB(st.transform), cat, Cc,
                                    Cc + Ch, 0);
       d.shared_cu = concurrent ? 1 : 0;
+      d.in_sp = d.out_sp = sp;
       RUN(plan_conv(plan, st.transform, d, s));
     } else
     for (int py = 0; py < 2; ++py)
@@ -981,6 +1054,12 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         d.fuse_dim = c.out_dim;
         if (!(c.flags & (DRS_PLAN_KEEP_ALL | DRS_PLAN_TRAIN))) d.out = nullptr;  // the wide tensor is only a parity tap
         fused_output = true;
+      }
+      d.in_sp = sp; d.zero_line = zero_line;
+      d.out_sp = st.upconv.out_sp ? 1 : 0;
+      if (sp && i < 2) {  // second output for the next stage's UpConvBlock
+        d.out2 = TP(plan->t_XT[i + 1]); d.out2_cs = Ch; d.out2_co = 0;
+        d.post2 = temb + plan->dec[i + 1].mlp.temb_off; d.post2_cs = plan->temb_total;
       }
       RUN(plan_conv(plan, st.upconv, d, s));
     }
@@ -1017,6 +1096,7 @@ extern "C" int drs_unet_read_tensor(const drs_plan* plan, int i, const void* wor
     DRS_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)t.n * t.c * t.h * t.w * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DRS_OK;
   }
+  if (t.sp) return drs_launch_sp_to_nchw(src, dst, t.n, t.c, t.h, t.w, t.cs, t.co, (hipStream_t)stream);
   return drs_launch_nhwc_to_nchw(src, dst, t.n, t.c, t.h, t.w, t.cs, t.co, (hipStream_t)stream);
 }
 

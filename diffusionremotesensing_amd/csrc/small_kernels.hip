@@ -83,6 +83,46 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
     dst[i] = src[((int64_t)n * hw + r) * src_cs + src_co + c];
   }
 }
+// SP-format tensor (drs_common.h) -> NCHW fp32 (parity taps): x = hi + lo
+__global__ void sp_to_nchw_kernel(const char* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
+                                  int src_cs, int src_co) {
+  const int64_t total = (int64_t)N * C * H * W;
+  const int64_t hw = (int64_t)H * W;
+  const int gw = src_cs >= 32 ? 32 : src_cs;  // channels per group
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i % hw;
+    const int c = (int)((i / hw) % C) + src_co;
+    const int n = (int)(i / (hw * C));
+    const char* g = src + (((int64_t)n * hw + r) * src_cs + (c / gw) * gw) * 4;
+    const __bf16 h = *reinterpret_cast<const __bf16*>(g + (c % gw) * 2);
+    const __bf16 l = *reinterpret_cast<const __bf16*>(g + gw * 2 + (c % gw) * 2);
+    dst[i] = (float)h + (float)l;
+  }
+}
+// dst = src + vec[n][c] on SP-format tensors of C (multiple of 32) channels: x + relu(time_mlp(t)) of an UpConvBlock
+// (reference :199) when the producing convolution could not write it as its second output (small shapes).
+__global__ void sp_add_rowvec_kernel(const char* __restrict__ src, char* __restrict__ dst, const float* __restrict__ vec,
+                                     int vec_stride, int64_t slots, int64_t slots_per_image, int C) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  const int spp = C / 8;  // 16-byte (hi) slots per pixel
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / spp;
+    const int sl = (int)(i % spp), grp = sl >> 2, kg = sl & 3;
+    const int n = (int)(i / slots_per_image);
+    const int64_t off = (pix * C + grp * 32) * 4 + kg * 16;
+    const bf16x8_t h = *reinterpret_cast<const bf16x8_t*>(src + off), l = *reinterpret_cast<const bf16x8_t*>(src + off + 64);
+    const float* v = vec + (int64_t)n * vec_stride + grp * 32 + kg * 8;
+    bf16x8_t oh, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)h[j] + (float)l[j] + v[j];
+      oh[j] = (__bf16)x;
+      ol[j] = (__bf16)(x - (float)oh[j]);
+    }
+    *reinterpret_cast<bf16x8_t*>(dst + off) = oh;
+    *reinterpret_cast<bf16x8_t*>(dst + off + 64) = ol;
+  }
+}
 static inline int ew_blocks(int64_t total) {
   int64_t b = (total + 255) / 256;
   if (b > 8192) b = 8192;
@@ -93,6 +133,23 @@ int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, i
                             hipStream_t s) {
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H,
                      W, dst_cs, dst_co);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+int drs_launch_sp_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int src_cs, int src_co,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(sp_to_nchw_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, s,
+                     reinterpret_cast<const char*>(src), dst, N, C, H, W, src_cs, src_co);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+int drs_launch_sp_add_rowvec(const float* src, float* dst, const float* vec, int vec_stride, int N, long long pix_per_image,
+                             int C, hipStream_t s) {
+  DRS_REQUIRE(C % 32 == 0, DRS_ERR_SHAPE, "sp_add_rowvec: C=%d", C);
+  const int64_t per_image = (int64_t)pix_per_image * (C / 8), slots = per_image * N;
+  if (slots == 0) return DRS_OK;
+  hipLaunchKernelGGL(sp_add_rowvec_kernel, dim3(ew_blocks(slots)), dim3(256), 0, s, reinterpret_cast<const char*>(src),
+                     reinterpret_cast<char*>(dst), vec, vec_stride, slots, per_image, C);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -173,7 +230,7 @@ template <int COUT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ b, const float* __restrict__ res,
                                                    int res_batch, float* __restrict__ out, int N, int Cin, int H,
-                                                   int W) {
+                                                   int W, int out_sp) {
   __shared__ float sw[COUT * 4 * 9 + COUT];  // [tap][ci][co] + bias
   for (int i = threadIdx.x; i < COUT * Cin * 9; i += blockDim.x) {
     const int co = i / (Cin * 9), r = i % (Cin * 9), ci = r / 9, tap = r % 9;
@@ -213,16 +270,31 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
 #pragma unroll
       for (int co = 0; co < COUT; ++co) acc[co] += rp[co];
     }
+    if (out_sp) {  // SP format (drs_common.h): one group of [COUT x bf16 hi | COUT x bf16 lo] per pixel
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int co = 0; co < COUT; co += 8) {
+        bf16x8_t h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          h[j] = (__bf16)acc[co + j];
+          l[j] = (__bf16)(acc[co + j] - (float)h[j]);
+        }
+        *reinterpret_cast<bf16x8_t*>(reinterpret_cast<char*>(op) + co * 2) = h;
+        *reinterpret_cast<bf16x8_t*>(reinterpret_cast<char*>(op) + COUT * 2 + co * 2) = l;
+      }
+    } else {
 #pragma unroll
     for (int co = 0; co < COUT; co += 4)
       *reinterpret_cast<float4*>(op + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+    }
   }
 }
 int drs_launch_stem(const float* in_nchw, const float* w, const float* b, const float* res_nhwc, int res_batch,
-                    float* out_nhwc, int N, int Cin, int Cout, int H, int W, hipStream_t s) {
+                    float* out_nhwc, int N, int Cin, int Cout, int H, int W, hipStream_t s, int out_sp) {
   DRS_REQUIRE(Cout == 16 && Cin >= 1 && Cin <= 4, DRS_ERR_SHAPE, "stem: Cin=%d Cout=%d unsupported", Cin, Cout);
   hipLaunchKernelGGL(stem_kernel<16>, dim3(ew_blocks((int64_t)N * H * W)), dim3(256), 0, s, in_nchw, w, b, res_nhwc,
-                     res_batch, out_nhwc, N, Cin, H, W);
+                     res_batch, out_nhwc, N, Cin, H, W, out_sp);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

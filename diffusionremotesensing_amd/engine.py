@@ -252,11 +252,12 @@ class HipUNetEngine:
         flat = torch.empty(total + (len(wanted) if has_flags else 0), dtype=torch.float32,
                            device=plan.device)  # fresh per step: .grad may alias it
         ptrs = (C.c_void_p * len(plan.param_names))()
-        views, off = {}, 0
+        views, off, slots = {}, 0, []
         for i, n in wanted:
             k = plan.param_numels[i]
             views[n] = flat[off:off + k].view_as(sd[n])
             ptrs[i] = flat.data_ptr() + 4 * off
+            slots.append((sd[n], off, k))
             off += k
         if getattr(plan, "packed_bwd", None) is None:
             plan.packed_bwd_bytes = lib.drs_unet_packed_bwd_bytes(plan.handle)
@@ -271,13 +272,18 @@ class HipUNetEngine:
                 int(labels.shape[0]) if labels is not None else 0, C.c_void_p(dout.data_ptr()), ptrs,
                 C.c_void_p(plan.workspace.data_ptr()), plan.ws_bytes, stream)
         _lib.check(st, "drs_unet_backward")
-        self._grad_buffer = (flat, total, [(sd[n], views[n]) for _, n in wanted], has_flags)
+        # (offsets, not view tensors: an extra reference to a view would make autograd CLONE it into .grad instead of
+        # adopting it, 176 copy kernels per step)
+        self._grad_buffer = (flat, total, slots, has_flags)
         return views
 
     def last_gradient_buffer(self):
-        """(flat buffer, number of gradient elements, [(parameter, view)], has flag tail) of the last backward: the
-        `.grad`s of the parameters are views of `flat`, which `dist.allreduce_gradients` reduces in place."""
-        return self._grad_buffer
+        """(flat buffer, number of gradient elements, [(parameter, view of its slot)], has flag tail) of the last backward:
+        the `.grad`s of the parameters are views of `flat`, which `dist.allreduce_gradients` reduces in place."""
+        if self._grad_buffer is None:
+            return None
+        flat, total, slots, has_flags = self._grad_buffer
+        return flat, total, [(p, flat[off:off + k].view_as(p)) for p, off, k in slots], has_flags
 
     # -- per-op timing (bench.py roofline) ------------------------------------------------------
     def profile_forward(self, x, timestep, lr_img, magnification_factor, iters=5, **kw):

@@ -467,7 +467,10 @@ def test_train_step_config2_per_rank_shape(dev, seeded_sd):
             continue
         assert p.grad is not None, name
         got, rn = p.grad.norm().item(), ref.norm().item()
-        dev_rel = abs(got - rn) / (rn + 2e-6 * scale)
+        if rn < 1e-5 * scale:  # conv biases in front of a BatchNorm: the true gradient is 0, both sides hold rounding noise
+            assert got < 1e-4 * scale, (name, got, rn)
+            continue
+        dev_rel = abs(got - rn) / rn
         worst = max(worst, dev_rel)
         if dev_rel > 1e-3:
             bad.append((name, got, rn))
