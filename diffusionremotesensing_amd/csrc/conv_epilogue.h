@@ -161,7 +161,9 @@ __device__ __forceinline__ u32x4 drs_dpp_swap8(const u32x4& x) {  // value of la
 }
 
 // OUT2: also write TapConv::out2 (= value + post2).  Register-lean: everything is loaded right where it is used.
-template <int RPW, int NT, bool OUT2 = false>
+// LEAN: bias only (no gate / ReLU / per-image add / residual): the transposed convolution, whose four accumulator sets
+// leave no registers for the general form.
+template <int RPW, int NT, bool OUT2 = false, bool LEAN = false>
 __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[RPW][NT], int n, int n0, int ty0, int tx0,
                                                  int wave, int lr, int kg, int out_oy, int out_ox) {
   constexpr int NP = NT / 2;
@@ -196,13 +198,13 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
 #pragma unroll
     for (int j = 0; j < 8; ++j) bias8[j] = post8[j] = 0.f;
     if (d.bias) load8(d.bias + c8, bias8);
-    if (d.bias2) {
+    if (!LEAN && d.bias2) {
       float b2[8];
       load8(d.bias2 + c8, b2);
 #pragma unroll
       for (int j = 0; j < 8; ++j) bias8[j] += b2[j];
     }
-    if (d.post_add) load8(d.post_add + (size_t)n * d.post_cs + c8, post8);
+    if (!LEAN && d.post_add) load8(d.post_add + (size_t)n * d.post_cs + c8, post8);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       const int ty = ty0 + wave * RPW + r;
@@ -211,6 +213,10 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
       float v[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] = acc[r][2 * pr][j]; v[4 + j] = acc[r][2 * pr + 1][j]; }
+      if constexpr (LEAN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+      } else {
       if (d.gate) {
         const float gv = d.gate[((size_t)n * (d.OH >> 1) + (oy >> 1)) * (d.OW >> 1) + (ox_own >> 1)];
 #pragma unroll
@@ -222,7 +228,8 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
         if (d.relu_pre) v[j] = fmaxf(v[j], 0.f);
         v[j] += post8[j];
       }
-      if (d.res) {
+      }
+      if (!LEAN && d.res) {
         const size_t rp = d.res_bstride_zero ? (size_t)oy * d.OW + ox_own : ((size_t)n * d.OH + oy) * d.OW + ox_own;
         float rv[8];
         if (d.res_sp) {
@@ -234,7 +241,7 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += rv[j];
       }
-      if (d.relu_post) {
+      if (!LEAN && d.relu_post) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256 * NWG, NWG == 1 ? 2 : 1) void tapconv_mfma_kern
       if constexpr (MODE == MODE_CONVT) {
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
-          if constexpr (SP == 2) tile_epilogue_sp<RPW, NT>(d, acc[ph], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
+          if constexpr (SP == 2) tile_epilogue_sp<RPW, NT, false, true>(d, acc[ph], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
           else tile_epilogue<RPW, NT, false>(d, acc[ph], n, n0 + ng * BN, ty0, tx0, wave, lr, kg, ph >> 1, ph & 1);
         }
       } else {
@@ -460,7 +460,8 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
   // An fp32 OUTPUT from SP inputs (w_g, w_x: their results feed fp32 consumers) is the SP kernel with the fp32 epilogue.
   if (d.out_sp && !d.in_sp) return false;
   if (d.in2 && d.in2_sp != d.in_sp) return false;
-  if (d.out2) return false;  // second outputs come from the wave-specialised SP kernel (or a separate add, plan.hip)
+  if ((d.out2 || d.dual) && !drs_tapconv_sp_supported(d, impl) && !(d.dual && drs_tapconv_ws_supported(d, impl)))
+    return false;  // second outputs / fused pairs come from the wave-specialised kernels only (plan.hip has the fallbacks)
   if (d.in_sp && (d.in_add || (d.in_co & 31) || (d.in_cs != 16 && (d.in_cs & 31)))) return false;
   if (d.in2_sp && ((d.in2_co & 31) || (d.in2_cs != 16 && (d.in2_cs & 31)))) return false;
   if (d.out_sp && ((d.out_co & 31) || (d.out_cs & 31) || d.fuse_out || (d.out2 && ((d.out2_co & 31) || (d.out2_cs & 31))))) return false;
@@ -472,6 +473,7 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
   if (d.in_add && (d.in_add_cs & 3)) return false;
   if (d.in_stride != 1 && d.in_stride != 2) return false;
   if (d.mode == DRS_TAPMODE_CONVT && (d.ntaps != 9 || d.in_stride != 1 || d.out_scale != 2)) return false;
+  if (d.mode == DRS_TAPMODE_CONVT && d.out_sp && (d.gate || d.relu_pre || d.relu_post || d.post_add || d.res || d.bias2)) return false;
   if (d.in2 && (!is_std3x3(d) || d.fuse_out || !d.w2 || (d.Cin2 & 3) || (d.in2_cs & 3) || (d.in2_co & 3) ||
                 d.H2 != d.TH || d.W2 != d.TW))
     return false;
@@ -524,6 +526,8 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((size_t)d.N * d.TH * d.TW == 0) return DRS_OK;
   MfmaGeom g; int bn, rpw, mode; size_t lds;
   geom(d, impl, &g, &bn, &rpw, &mode, &lds);
+  if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_sp_supported(d, impl))
+    return drs_launch_tapconv_sp(d, g, s);
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_ws_supported(d, impl))
     return drs_launch_tapconv_ws(d, g, impl, s);
   DRS_REQUIRE(!d.dual, DRS_ERR_SHAPE, "tapconv_mfma: the fused conv1 + skip op needs the wave-specialised kernel");

@@ -1,0 +1,545 @@
+// Wave-specialised 3x3 stride-1 tap-convolution over SP-format activations (split bf16 hi | lo, drs_common.h): the
+// default kernel of every wide 3x3 layer of the eval split-bf16 plan (conv1 / conv2 (+ fused 1x1 shortcut) of the residual
+// blocks, ups.*.conv, up_convs.*; reference UNet_model_superres.py:153-172,197-207,377).
+//
+// Same GEMM view, MFMA schedule and weight ring as tapconv_ws_kernel (conv_mfma_ws.hip); what is gone is every
+// conversion: the producers stored the operand halves, so the mover waves LDS-DMA the input window STRAIGHT INTO THE
+// OPERAND IMAGE (global_load_lds_dwordx4, whole 128-byte lines: 8 pixels x [4 hi slots | 4 lo slots] per instruction), and
+// the consumer waves only read fragments and issue MFMAs.  Zero padding costs nothing either: a lane whose window pixel
+// lies outside the image (or whose channels lie beyond Cin) takes a line of zeros as its source address.
+//   block = 12 waves on one CU: 8 consumer waves (2 per SIMD) + 4 mover waves (1 per SIMD, no vector registers to speak of)
+//   LDS   = 2 window buffers x 41 KB (double-buffered: window k+1 lands while window k is multiplied)
+//           + weight ring of the 3 kernel columns (72 KB at 64 output channels per block) + 5 counters = 154 KB
+//   step k (one 32-channel K-chunk of one 16x16 patch): NO block-wide barrier, ten monotonic LDS counters ("landed" /
+//   "released" per window buffer and per weight ring slot; protocol at the mover loop).  Waves drift apart by up to a
+//   step: while one wave of a SIMD waits for fragments or writes its tile out, its partner's MFMAs keep the pipe busy
+//   (with a barrier per step both waves of a SIMD stalled and multiplied at the same times: 65 % pipe occupancy).
+// Window image in LDS: like memory, 128 bytes per window pixel (18 x 18 window, row-major) = the pixel's 8 operand slots
+// [hi k-groups 0-3 | lo k-groups 0-3], ROTATED by the pixel index: slot c of pixel p sits at position (c + p) & 7.  The
+// DMA reads whole lines (8 consecutive lanes = one pixel's 128 bytes: full coalescing; without the rotation a fragment
+// read would hit 4-way bank conflicts, with a pixel-minor layout every lane of a DMA would touch a different line and the
+// instruction takes 320 instead of 140 cycles to issue).  A fragment read (16 consecutive pixels of one k-group) touches
+// 16 different 16-byte bank groups in each of the hardware's ds_read_b128 lane groups (MI355X_MICROARCH.md): conflict-free.
+// Lane addresses come from 2 x 8 per-wave tables (one per residue of the window offset mod 8) plus immediates.
+// Flavours (template arguments): BNB = 64 (2 channel groups x 4 row-waves) / 32 (1 x 8 row-waves); HAS2 = the block's 1x1
+// shortcut input as extra one-tap K-chunks; FUSE = up_convs.2 with the fused `output` projection (fp32 NCHW result);
+// DUAL = conv1 + skip convolution of the first residual block from one 64-channel operand image.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "conv_epilogue.h"
+#include "mfma_policy.h"
+
+namespace {
+
+__device__ __forceinline__ void sp_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void sp_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform)
+__device__ __forceinline__ void sp_wait_vm(int n) {
+#define DRS_SP_CASE(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
+  switch (n) {
+    DRS_SP_CASE(1) DRS_SP_CASE(2) DRS_SP_CASE(3) DRS_SP_CASE(4) DRS_SP_CASE(5) DRS_SP_CASE(6) DRS_SP_CASE(7)
+    DRS_SP_CASE(8) DRS_SP_CASE(9) DRS_SP_CASE(10) DRS_SP_CASE(11) DRS_SP_CASE(12) DRS_SP_CASE(13) DRS_SP_CASE(14)
+    DRS_SP_CASE(15) DRS_SP_CASE(16) DRS_SP_CASE(17) DRS_SP_CASE(18) DRS_SP_CASE(19) DRS_SP_CASE(20) DRS_SP_CASE(21)
+    DRS_SP_CASE(22) DRS_SP_CASE(23) DRS_SP_CASE(24) DRS_SP_CASE(25) DRS_SP_CASE(26) DRS_SP_CASE(27) DRS_SP_CASE(28)
+    DRS_SP_CASE(29) DRS_SP_CASE(30) DRS_SP_CASE(31)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef DRS_SP_CASE
+}
+
+#ifdef DRS_SP_TIMELINE
+__device__ unsigned long long drs_sp_tl[48];
+#define SP_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl[i] += t_ - tl_last; tl_last = t_; } while (0)
+#else
+#define SP_STAMP(i) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(1))) void* sp_gptr;
+typedef __attribute__((address_space(3))) void* sp_lptr;
+typedef __attribute__((address_space(3))) unsigned* sp_flag_ptr;
+
+// spin until the LDS counter *f reaches `target`.  A protocol error must never leave waves spinning on the GPU: after
+// ~2^22 polls (about a second) the wave traps and the launch fails loudly.
+__device__ __forceinline__ void sp_poll(sp_flag_ptr f, unsigned target) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1u << 22)) __builtin_trap();
+  }
+}
+__device__ __forceinline__ void sp_bump(sp_flag_ptr f) {
+  __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// consumer release of a ring slot + instruction priority for what follows.  The two consumer waves of a SIMD share its
+// matrix pipe and the hardware arbitrates "oldest first": left alone, the older wave runs a column at full speed while the
+// younger one crawls, then blocks one step ahead at the ring and idles while the younger one runs ALONE (LDS latencies
+// exposed: 63 % pipe occupancy measured).  The counter value returned by the release tells how many of the 8 consumers
+// were here before this wave: the second half to arrive (the waves that are behind) raise their priority, the first half
+// lower it, so the partners stay within a column of each other and one multiplies while the other waits for fragments.
+__device__ __forceinline__ void sp_bump_prio(sp_flag_ptr f, unsigned step_base, int lane) {
+  unsigned old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned rank = (unsigned)__builtin_amdgcn_readfirstlane((int)old) - step_base;
+  if (rank >= 4) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
+template <int BNB_>
+struct SpGeom {
+  static constexpr int IW = 18, NPIX = 18 * 18;
+  static constexpr int NBLK = (NPIX + 7) / 8;      // pixel blocks of 8 = 1 KB DMA pieces per window
+  static constexpr int WBUF = NBLK * 1024;         // bytes of one window buffer
+  static constexpr int BNB = BNB_;
+  static constexpr int W_IMAGE = 9 * 4 * BNB * 16;  // one operand image (hi or lo) of a chunk's weights
+  static constexpr int LDS = 2 * WBUF + 2 * W_IMAGE + 64;
+};
+
+template <bool HAS2, int BNB_, bool FUSE, bool DUAL>
+__global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using P = PolicyBF16X3;
+  using G = SpGeom<BNB_>;
+  constexpr int KC = 32, IW = G::IW, NBLK = G::NBLK, WBUF = G::WBUF, W_IMAGE = G::W_IMAGE, BNB = G::BNB;
+  constexpr int NT = DUAL ? 4 : 2, BN = 32, TH = 16, TW = 16;
+  constexpr int NRW = DUAL ? 8 : 8 * BN / BNB;  // row-waves per channel group: 4 (64 channels per block) or 8 (32, dual)
+  constexpr int RPW = TH / NRW;                  // patch rows per consumer wave: 4 or 2
+  char* sWin = smem;                             // [buffer 2][window pixel][rotated operand slot 8] x 16 bytes
+  char* sW = smem + 2 * WBUF;                    // [image][kx(3)][ky(3)][k-group(4)][BNB] operand slots
+  // ten monotonic counters, no barrier inside the step loop (the waves of a SIMD drift to complementary phases: one
+  // multiplies while its partner waits for fragments or writes its tile out):
+  sp_flag_ptr sCR = (sp_flag_ptr)(sW + 2 * W_IMAGE);  // CR[3]: consumer waves that hold weight column j of their step in registers
+  sp_flag_ptr sCL = sCR + 3;                          // CL[3]: mover waves whose part of weight column j has landed
+  sp_flag_ptr sWL = sCR + 6;                          // WL[2]: mover waves whose part of window buffer b has landed
+  sp_flag_ptr sWR = sCR + 8;                          // WR[2]: consumer waves that have finished reading window buffer b
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 consumers, 8..11 movers
+  const bool mover = wid >= 8;
+  const int lr = lane & 15, kg = lane >> 4;
+
+  // persistent blocks, XCD-aware item order (see tapconv_mfma_kernel)
+  const int ngroups = DUAL ? 1 : d.Cout / BNB;
+  const int wcout = DUAL ? 2 * d.Cout : d.Cout;  // channels of the packed weight image
+  const int nitems = d.N * g.tiles_y * g.tiles_x * ngroups;
+  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+  const int per = (nitems + 7) >> 3;
+  const int lo_item = xcd * per, hi_item = min(nitems, lo_item + per);
+  const int span = hi_item - lo_item - j8;
+  const int my_items = span > 0 ? (span + nb8 - 1) / nb8 : 0;
+  const int nck = g.nchunks + (HAS2 ? g.nchunks2 : 0);
+  const int S = my_items * nck;
+  if (S == 0) return;
+  auto item_of = [&](int ordinal, int& n_, int& ty0_, int& tx0_, int& n0_) __attribute__((always_inline)) {
+    int it = lo_item + ordinal * nb8 + j8;
+    n0_ = (it % ngroups) * BNB;
+    it /= ngroups;
+    tx0_ = (it % g.tiles_x) * TW;
+    it /= g.tiles_x;
+    ty0_ = (it % g.tiles_y) * TH;
+    n_ = it / g.tiles_y;
+  };
+
+#ifdef DRS_SP_TIMELINE
+  unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long tl_begin = tl_last;
+#endif
+  if (tid < 10) __hip_atomic_store(sCR + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  sp_wait_lds();
+  sp_barrier();
+  int c = -1, ord = -1, n = 0, ty0 = 0, tx0 = 0, n0 = 0;  // current step: chunk, item ordinal, item coordinates
+
+  if (mover) {
+    // ===================== movers =====================
+    // Everything goes global -> REGISTERS -> LDS.  Measured on this kernel: one wave sustains about one 1 KB LDS-DMA
+    // instruction per 300 cycles (each seems to wait for the previous one to land), 3.4 bytes per cycle and wave, whatever
+    // else the CU or the chip is doing, so four movers cannot bring in the 113 KB a step needs (41 KB window + 72 KB
+    // weights) next to 6.9 k cycles of MFMA.  Plain global loads issue ~3x faster and need no LDS slot while in flight:
+    // the operands of step k+1 are prefetched into the movers' registers a whole step ahead and written into the window
+    // buffer / a weight ring slot the moment the consumers have released it (~100 cycles instead of a memory round trip).
+    // Protocol (step k = one K-chunk of one patch; window buffer k & 1; weight ring slot j = kernel column j), mover M(k)
+    // fills step k:   loads: column 0, window, column 1 (in the order the stores need them; column 2 follows the store
+    //                 of column 0 into the same registers)
+    //                 wait CR0 (every consumer holds column 0 of step k-1 in registers) -> store column 0 -> CL0
+    //                 wait WR[k&1] (the consumers left the buffer in step k-2)           -> store window   -> WL[k&1]
+    //                 wait CR1 -> store column 1 -> CL1;  wait CR2 -> store column 2 -> CL2
+    //   consumer(k):  wait WL[k&1], CL0 -> read column 0 -> CR0 -> MFMA | wait CL1 -> read -> CR1 -> MFMA | wait CL2 ->
+    //                 read -> CR2 -> MFMA -> WR[k&1] -> epilogue of the item
+    // Every wait is for an event whose own prerequisites lie strictly earlier in this order: no cycle.  Counters are
+    // bumped with release semantics after the ds_writes have completed (lgkmcnt(0)).
+    const int pw = wid - 8;
+    const char* wg = reinterpret_cast<const char*>(d.w);
+    const size_t w_chunk = (size_t)9 * 4 * wcout * 16;
+    const size_t w_gimage = DUAL ? 2 * (size_t)g.w_gimage : (size_t)g.w_gimage;  // (the geometry was sized for d.Cout channels)
+    const char* zero = reinterpret_cast<const char*>(d.zero_line) + (lane & 15) * 16;
+    // this lane's role inside a window piece (8 pixels x 128 bytes): lanes 8*px .. 8*px + 7 fetch the 8 operand slots of
+    // pixel px = ONE 128-byte line (coalesced), rotated by px: LDS slot s of the pixel holds operand slot (s - px) & 7
+    const int l_px = lane >> 3, l_c = ((lane & 7) - l_px) & 7, l_img = l_c >> 2, l_kg = l_c & 3;
+    const int half1 = drs_sp_group_bytes(d.in_cs), half2 = HAS2 ? drs_sp_group_bytes(d.in2_cs) : 0;
+    const int l_off1 = l_img * half1 + l_kg * 16, l_off2 = l_img * half2 + l_kg * 16;
+    constexpr int NPW = (NBLK + 3) / 4;  // window pieces per mover wave (at most): blocks pw + 4*i
+    static_assert(NBLK == 4 * (NPW - 1) + 1, "piece distribution: the last round holds block NBLK - 1 only, owned by mover 0");
+    // per-lane byte offsets of this wave's window pixels relative to the window origin, computed ONCE (32 bits: a tensor
+    // spans less than 2 GB): the per-step work of the fast path is one scalar base pointer + one load per piece
+    int off1[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int p = (pw + 4 * i) * 8 + l_px;
+      const int py = (p * 3641) >> 16, px = p - py * IW;  // p / 18 (exact for p < 1024)
+      off1[i] = ((py * d.W + px) * d.in_cs) * 4 + l_off1;
+    }
+    const bool tail_ok = (NBLK - 1) * 8 + l_px < G::NPIX;  // the last block is half empty
+    constexpr int WPC = BNB == 64 ? 6 : 3;  // weight pieces (1 KB) per mover wave and kernel column
+    u32x4 wr[2][WPC], ww[NPW];  // column registers: column 2 re-uses column 0's once that one is stored
+    // weight piece i of column col: source address and LDS destination of this lane's 16 bytes
+    auto piece = [&](int col, bool second, int cc, int n0_, int i, const char*& src, char*& dst) __attribute__((always_inline)) {
+      if constexpr (BNB == 64) {  // piece = one (image, ky, k-group) row of 64 channels; second input: (image, k-group)
+        const int idx = pw * (second ? 2 : WPC) + i;
+        const int im = second ? idx >> 2 : idx / 12, ky = second ? 0 : (idx % 12) >> 2, kq = idx & 3;
+        src = second ? reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage + ((size_t)(cc * 4 + kq) * wcout + n0_ + lane) * 16
+                     : wg + (size_t)im * w_gimage + (size_t)cc * w_chunk + ((size_t)((ky * 3 + col) * 4 + kq) * wcout + n0_ + lane) * 16;
+        dst = sW + (size_t)im * W_IMAGE + (size_t)(((second ? 0 : col) * 3 + ky) * 4 + kq) * BNB * 16 + lane * 16;
+      } else {  // piece = two consecutive k-group rows of 32 channels
+        const int prow = lane >> 5, pco = lane & 31;
+        const int row0 = (pw * (second ? 1 : WPC) + i) * 2;
+        const int im = second ? row0 >> 2 : row0 / 12, ky = second ? 0 : (row0 % 12) >> 2, kq0 = row0 & 3;
+        src = second ? reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage + ((size_t)(cc * 4 + kq0 + prow) * d.Cout + n0_ + pco) * 16
+                     : wg + (size_t)im * w_gimage + (size_t)cc * w_chunk + ((size_t)((ky * 3 + col) * 4 + kq0 + prow) * d.Cout + n0_ + pco) * 16;
+        dst = sW + (size_t)im * W_IMAGE + (size_t)(((second ? 0 : col) * 3 + ky) * 4 + kq0) * BNB * 16 + lane * 16;
+      }
+    };
+    const int nwin = pw == 0 ? NPW : NPW - 1;  // window pieces of this wave
+    for (int k = 0; k < S; ++k) {
+      if (++c == nck) c = 0;
+      if (c == 0) item_of(++ord, n, ty0, tx0, n0);
+      const bool second = HAS2 && c >= g.nchunks;
+      const int cc = second ? c - g.nchunks : c;
+      // pieces per column (the second input has one tap: column 0 only)
+      int np[3];
+#pragma unroll
+      for (int col = 0; col < 3; ++col) {
+        np[col] = second ? (col == 0 ? (BNB == 64 ? 2 : 1) : 0) : WPC;
+#ifdef DRS_SP_TIMELINE
+        if (g.debug & 2) np[col] = 0;
+#endif
+      }
+      auto load_col = [&](int col) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WPC; ++i)
+          if (i < np[col]) {
+            const char* src; char* dst;
+            piece(col, second, cc, n0, i, src, dst);
+            wr[col & 1][i] = *reinterpret_cast<const u32x4*>(src);
+          }
+      };
+      auto store_col = [&](int col) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WPC; ++i)
+          if (i < np[col]) {
+            const char* src; char* dst;
+            piece(col, second, cc, n0, i, src, dst);
+            *reinterpret_cast<u32x4*>(dst) = wr[col & 1][i];
+          }
+        sp_wait_lds();
+        if (lane == 0) sp_bump(sCL + col);
+      };
+      SP_STAMP(7);
+      load_col(0);
+      // ---- window loads ----
+#ifdef DRS_SP_TIMELINE
+      const bool skip_win = (g.debug & 1) != 0;
+#else
+      const bool skip_win = false;
+#endif
+      if (skip_win) {
+      } else if (!second && ty0 >= 1 && ty0 + TH + 1 <= d.H && tx0 >= 1 && tx0 + TW + 1 <= d.W && cc * KC + KC <= d.Cin) {
+        // fast path: every window pixel inside the image, every k-group inside the channel count
+        const char* base = reinterpret_cast<const char*>(d.in) +
+                           ((((long long)n * d.H + (ty0 - 1)) * d.W + (tx0 - 1)) * d.in_cs + d.in_co) * 4 + cc * 128;
+#pragma unroll
+        for (int i = 0; i < NPW - 1; ++i) ww[i] = *reinterpret_cast<const u32x4*>(base + (unsigned)off1[i]);
+        if (pw == 0) ww[NPW - 1] = *reinterpret_cast<const u32x4*>(tail_ok ? base + (unsigned)off1[NPW - 1] : zero);
+      } else {
+        // border patches, partial K-chunks, the second input: per-lane validity; anything invalid reads the zero line
+        const bool ch_ok = cc * KC + l_kg * 8 < (second ? d.Cin2 : d.Cin);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          if (i < nwin) {
+            const int p = (pw + 4 * i) * 8 + l_px;
+            const int py = (p * 3641) >> 16, px = p - py * IW;
+            const char* src;
+            bool ok;
+            if (!second) {
+              const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+              ok = ch_ok && p < G::NPIX && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+              src = reinterpret_cast<const char*>(d.in) +
+                    ((((long long)n * d.H + iy) * d.W + ix) * d.in_cs + d.in_co) * 4 + cc * 128 + l_off1;
+            } else {
+              const int iy = ty0 + py, ix = tx0 + px;
+              ok = ch_ok && py < TH && px < TW && iy < d.H2 && ix < d.W2;
+              src = reinterpret_cast<const char*>(d.in2) +
+                    ((((long long)n * d.H2 + iy) * d.W2 + ix) * d.in2_cs + d.in2_co) * 4 + cc * 128 + l_off2;
+            }
+            ww[i] = *reinterpret_cast<const u32x4*>(ok ? src : zero);
+          }
+      }
+      load_col(1);
+      SP_STAMP(0);
+      // ---- stores, each as soon as its destination is free and its loads have landed (in-order vector-memory counter) ----
+      if (k >= 1) sp_poll(sCR, 8u * (unsigned)k);
+      SP_STAMP(1);
+      sp_wait_vm(nwin + np[1]);
+      store_col(0);
+      load_col(2);  // into column 0's registers; needed two thirds of a step from now
+      SP_STAMP(2);
+      if (k >= 2) sp_poll(sWR + (k & 1), 8u * (unsigned)(k >> 1));
+      sp_wait_vm(np[1] + np[2]);
+      {
+        char* buf = sWin + (k & 1) * WBUF + lane * 16;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          if (i < nwin && !skip_win) *reinterpret_cast<u32x4*>(buf + (pw + 4 * i) * 1024) = ww[i];
+        sp_wait_lds();
+        if (lane == 0) sp_bump(sWL + (k & 1));
+      }
+      SP_STAMP(3);
+      if (k >= 1) sp_poll(sCR + 1, 8u * (unsigned)k);
+      SP_STAMP(4);
+      sp_wait_vm(np[2]);
+      store_col(1);
+      if (k >= 1) sp_poll(sCR + 2, 8u * (unsigned)k);
+      SP_STAMP(5);
+      sp_wait_vm(0);
+      store_col(2);
+      SP_STAMP(6);
+    }
+  } else {
+    // ===================== consumers =====================
+    const int rw = (BNB == 64 && !DUAL) ? (wid & 3) : (wid & 7);  // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
+    const int ng = (BNB == 64 && !DUAL) ? ((wid >> 2) & 1) : 0;   // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
+    // fragment addresses: window pixel p = B + q + lr with B = rw*RPW*18 (per wave) and q = wr*18 + kx (compile time);
+    // slot address = p * 128 + ((c + p) & 7) * 16, c = image * 4 + k-group.  The rotation depends on q only through q & 7:
+    // one lane table per residue (hi and lo image), the rest (q * 128) is an immediate.
+    const int B = rw * RPW * IW;
+    int tab_hi[8], tab_lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int rot = (kg + B + j + lr) & 7;
+      tab_hi[j] = (B + lr) * 128 + rot * 16;
+      tab_lo[j] = (B + lr) * 128 + (rot ^ 4) * 16;
+    }
+    const char* wbase = sW + ((size_t)kg * BNB + ng * NT * 16 + lr) * 16;  // this lane's weight origin
+    f32x4 acc[RPW][NT];
+    typename P::Frag wf[3][NT];
+    auto read_wf = [&](int col) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          wf[ky][t] = P::load(wbase, W_IMAGE, (size_t)(((col * 3 + ky) * 4 * BNB) + t * 16) * 16);
+    };
+    auto win_frag = [&](const char* buf, int q) __attribute__((always_inline)) {  // q: compile-time window offset
+      return typename P::Frag{*reinterpret_cast<const bf16x8*>(buf + tab_hi[q & 7] + q * 128),
+                              *reinterpret_cast<const bf16x8*>(buf + tab_lo[q & 7] + q * 128)};
+    };
+    auto mma_col = [&](const char* buf, int col) __attribute__((always_inline)) {
+#pragma unroll
+      for (int wr = 0; wr < RPW + 2; ++wr) {
+        const typename P::Frag af = win_frag(buf, wr * IW + col);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int r = wr - ky;
+          if (r >= 0 && r < RPW) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[ky][t], af, acc[r][t]);
+          }
+        }
+      }
+    };
+    auto mma_col_dbg = [&](const char* buf, int col) __attribute__((always_inline)) {
+#ifdef DRS_SP_TIMELINE
+      if (g.debug & 4) return;
+#endif
+      mma_col(buf, col);
+    };
+
+    for (int k = 0; k < S; ++k) {
+      if (++c == nck) c = 0;
+      if (c == 0) {
+        item_of(++ord, n, ty0, tx0, n0);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const bool second = HAS2 && c >= g.nchunks;
+      const char* buf = sWin + (k & 1) * WBUF;
+      const unsigned ltarget = 4u * (unsigned)(k + 1);  // four movers per column and step
+      SP_STAMP(7);
+      sp_poll(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1));  // window k is in its buffer
+      sp_poll(sCL, ltarget);                                   // ... and weight column 0 of k
+      SP_STAMP(0);
+      read_wf(0);
+      sp_wait_lds();
+      sp_bump_prio(sCR, 8u * (unsigned)k, lane);  // column 0 is in registers: its ring slot may be refilled
+      SP_STAMP(1);
+      if (second) {  // second input: one tap, window origin; columns 1 and 2 are empty
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const typename P::Frag af = win_frag(buf, r * IW);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[0][t], af, acc[r][t]);
+        }
+        sp_wait_lds();
+        if (lane == 0) {
+          sp_bump(sCR + 1);
+          sp_bump(sCR + 2);
+          sp_bump(sWR + (k & 1));
+        }
+      } else {
+        mma_col_dbg(buf, 0);
+        SP_STAMP(2);
+        sp_poll(sCL + 1, ltarget);
+        read_wf(1);
+        sp_wait_lds();
+        sp_bump_prio(sCR + 1, 8u * (unsigned)k, lane);
+        SP_STAMP(3);
+        mma_col_dbg(buf, 1);
+        SP_STAMP(4);
+        sp_poll(sCL + 2, ltarget);
+        read_wf(2);
+        sp_wait_lds();
+        sp_bump_prio(sCR + 2, 8u * (unsigned)k, lane);
+        SP_STAMP(5);
+        mma_col_dbg(buf, 2);
+        sp_wait_lds();  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
+        if (lane == 0) sp_bump(sWR + (k & 1));
+        SP_STAMP(6);
+      }
+      if (c == nck - 1) {
+        // opaque copies of the lane coordinates: everything the epilogue derives from them is computed here, not hoisted
+        // out of the step loop (where it would be spilled and reloaded between the stores)
+        int lr_e = lr, kg_e = kg;
+        asm volatile("" : "+v"(lr_e), "+v"(kg_e));
+        if constexpr (DUAL) {
+          // out = relu(main + b_main) + post_add + (skip + b_skip): tiles t (main) and t + 2 (skip) of the same lane;
+          // channel of (tile t, register j) in SP order: kg*8 + t*4 + j
+          f32x4 comb[RPW][2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float4 b1 = *reinterpret_cast<const float4*>(d.bias + kg_e * 8 + t * 4);
+            const float4 b2 = *reinterpret_cast<const float4*>(d.bias + d.Cout + kg_e * 8 + t * 4);
+            const float bm[4] = {b1.x, b1.y, b1.z, b1.w}, bs[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) comb[r][t][j] = fmaxf(acc[r][t][j] + bm[j], 0.f) + (acc[r][t + 2][j] + bs[j]);
+          }
+          TapConv de = d;
+          de.bias = nullptr; de.bias2 = nullptr; de.relu_pre = 0;
+          tile_epilogue_sp<RPW, 2, false>(de, comb, n, 0, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
+        } else if constexpr (FUSE)
+          fuse_epilogue<RPW, NT>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e);
+        else
+          tile_epilogue_sp<RPW, NT, true>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
+      }
+    }
+  }
+#ifdef DRS_SP_TIMELINE
+  if (blockIdx.x == 0 && (wid == 0 || wid == 4 || wid == 8) && lane == 0) {
+    for (int i = 0; i < 8; ++i) drs_sp_tl[(wid == 0 ? 0 : (wid == 4 ? 32 : 16)) + i] = tl[i];
+    drs_sp_tl[wid == 0 ? 8 : (wid == 4 ? 40 : 24)] = S;
+    if (wid == 0) drs_sp_tl[9] = __builtin_amdgcn_s_memtime() - tl_begin;
+  }
+
+#endif
+}
+
+bool sp_std3x3(const TapConv& d) {
+  if (d.mode != 0 || d.ntaps != 9 || d.wtaps_total != 9 || d.in_stride != 1 || d.out_scale != 1) return false;
+  for (int i = 0; i < 9; ++i)
+    if (d.dy[i] != i / 3 - 1 || d.dx[i] != i % 3 - 1 || d.wtap[i] != i) return false;
+  return true;
+}
+
+template <bool HAS2, int BNB, bool FUSE = false, bool DUAL = false>
+int sp_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
+  auto kern = tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL>;
+  constexpr size_t kLds = SpGeom<BNB>::LDS;
+  static_assert(kLds <= 160 * 1024, "LDS budget");
+  int num_cu = 0;
+  {
+    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
+    if (rc) return rc;
+  }
+  const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (DUAL ? 1 : d.Cout / BNB);
+  long long blocks = num_cu;  // one 12-wave block per CU
+#ifdef DRS_SP_TIMELINE
+  if (getenv("DRS_SP_MAXBLOCKS")) blocks = atoi(getenv("DRS_SP_MAXBLOCKS"));  // experiment: fewer CUs
+#endif
+  if (blocks > nitems) blocks = nitems;
+  blocks = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);
+  DRS_CHECK_HIP(hipGetLastError());
+#ifdef DRS_SP_TIMELINE
+  {
+    unsigned long long h[48];
+    hipEvent_t e0, e1;
+    float ms = 0.f;
+    DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
+    DRS_CHECK_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);  // timed repeat (same result)
+    DRS_CHECK_HIP(hipEventRecord(e1, s));
+    DRS_CHECK_HIP(hipStreamSynchronize(s));
+    DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    DRS_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(drs_sp_tl), sizeof(h)));
+    const double sc = h[8] ? 1.0 / (double)h[8] : 0.0;
+    fprintf(stderr, "sp kernel Cin=%d Cout=%d TH=%d in2=%d BNB=%d fuse=%d dual=%d: %.1f us, %llu steps/block, wave0 alive %llu ticks = %.2f GHz, %.0f ticks/step\n",
+            d.Cin, d.Cout, d.TH, d.in2 ? d.Cin2 : 0, BNB, (int)FUSE, (int)DUAL, ms * 1e3, h[8], h[9], h[9] / (ms * 1e6), h[9] * sc);
+    fprintf(stderr, "   C0: epi>Y %.0f Y %.0f rd0 %.0f col0 %.0f L1+rd1 %.0f col1 %.0f L2+rd2 %.0f col2 %.0f\n", h[7] * sc, h[0] * sc, h[1] * sc,
+            h[2] * sc, h[3] * sc, h[4] * sc, h[5] * sc, h[6] * sc);
+    fprintf(stderr, "   C4: epi>Y %.0f Y %.0f rd0 %.0f col0 %.0f L1+rd1 %.0f col1 %.0f L2+rd2 %.0f col2 %.0f\n", h[39] * sc, h[32] * sc, h[33] * sc,
+            h[34] * sc, h[35] * sc, h[36] * sc, h[37] * sc, h[38] * sc);
+    fprintf(stderr, "   M : loads %.0f CR0poll %.0f col0 %.0f WR+win %.0f CR1poll %.0f col1+CR2poll %.0f col2 %.0f\n", (h[23] + h[16]) * sc,
+            h[17] * sc, h[18] * sc, h[19] * sc, h[20] * sc, h[21] * sc, h[22] * sc);
+  }
+#endif
+  return DRS_OK;
+}
+
+}  // namespace
+
+// Eligibility: 3x3 stride 1 on 16-row patches, SP-format input(s), SP-format output (or the fused fp32 projection).
+// DRS_SPK=0 sends these layers to the lock-step kernel (tapconv_mfma_kernel<.., SP>).
+bool drs_tapconv_sp_supported(const TapConv& d, int impl) {
+  static const int env = getenv("DRS_SPK") ? atoi(getenv("DRS_SPK")) : 1;
+  if (!env || impl != DRS_IMPL_MFMA_BF16X3) return false;
+  if (!d.in || !d.in_sp || !sp_std3x3(d) || !d.zero_line) return false;
+  if (d.gate || d.in_add || d.res || d.sigmoid || d.out_nchw || d.TH <= 8) return false;
+  if ((d.in_co & 31) || !(d.in_cs == 16 || (d.in_cs & 31) == 0)) return false;
+  if (!(d.Cin % 32 == 0 || (d.Cin == 16 && d.in_cs == 16))) return false;
+  if (d.dual)
+    return d.Cout == 32 && !d.in2 && !d.fuse_out && !d.out2 && d.bias && d.out && d.out_sp && !(d.out_co & 31) && !(d.out_cs & 31);
+  if (d.Cout % 32 != 0) return false;
+  if (d.in2 && (!d.in2_sp || !d.w2 || (d.in2_co & 31) || !(d.in2_cs == 16 || (d.in2_cs & 31) == 0) ||
+                !(d.Cin2 % 32 == 0 || (d.Cin2 == 16 && d.in2_cs == 16)) || d.H2 != d.TH || d.W2 != d.TW))
+    return false;
+  if (d.fuse_out) return d.Cout == 32 && !d.in2 && !d.out2 && !d.out_sp && d.fuse_dim <= 4 && !d.post_add && !d.relu_pre && !d.relu_post;
+  if (!d.out || !d.out_sp || (d.out_co & 31) || (d.out_cs & 31)) return false;
+  if (d.out2 && (!d.post2 || (d.out2_co & 31) || (d.out2_cs & 31) || (d.post2_cs & 3))) return false;
+  if (d.post_add && (d.post_cs & 3)) return false;
+  return true;
+}
+
+int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
+  DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_sp: geometry");
+  if (d.dual) return sp_launch<false, 64, false, true>(d, g, s);
+  if (d.fuse_out) return sp_launch<false, 32, true>(d, g, s);
+  if (d.Cout % 64 == 0) return d.in2 ? sp_launch<true, 64>(d, g, s) : sp_launch<false, 64>(d, g, s);
+  return d.in2 ? sp_launch<true, 32>(d, g, s) : sp_launch<false, 32>(d, g, s);
+}

@@ -560,6 +560,3 @@ int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStre
   if (impl == DRS_IMPL_MFMA_F32) return ws_dispatch<PolicyF32>(d, g, s);
   return ws_dispatch<PolicyBF16X3>(d, g, s);
 }
-
-// (placeholder until conv_mfma_sp.hip lands)
-bool drs_tapconv_sp_supported(const TapConv&, int) { return false; }

@@ -82,3 +82,5 @@ struct MfmaGeom {
 // wave-specialised 3x3 kernel (conv_mfma_ws.hip); `g` is the CONV3X3 / 512-thread geometry of conv_mfma.hip
 bool drs_tapconv_ws_supported(const TapConv& d, int impl);
 int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStream_t s);
+// wave-specialised 3x3 kernel over SP-format activations (conv_mfma_sp.hip); eligibility: drs_tapconv_sp_supported (drs_common.h)
+int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s);

@@ -899,7 +899,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       d.relu_pre = 1;
       d.in_sp = d.out_sp = sp; d.zero_line = zero_line;
       d.post_add = temb + rb.mlp.temb_off; d.post_cs = plan->temb_total;
-      if (drs_tapconv_ws_supported(d, c.impl)) {
+      if (drs_tapconv_ws_supported(d, c.impl) || drs_tapconv_sp_supported(d, c.impl)) {
         const std::string& wn = plan->params[rb.conv1.w].name;
         prof_begin(plan, wn.substr(0, wn.size() - 7) + "+skip", 2.0 * conv_flops(d), conv_bytes(d), s);
         rc = drs_launch_tapconv_mfma(d, c.impl, s);
