@@ -1,0 +1,204 @@
+// Fused additive attention gate of one decoder stage (reference AttentionBlock.forward + gating_signal.forward,
+// UNet_model_superres.py:89-108, 222-225) over SP-format activations, ONE launch instead of five:
+//   g   = relu(BN(conv1x1(x)))                          gating signal, Cc -> Ch channels at the low resolution
+//   g1  = w_g(g)                                        1x1, Ch -> Ch
+//   p   = relu(g1 + w_x(x_res))                         2x2 stride 2 over the skip tensor (Ch channels, double resolution)
+//   psi = sigmoid(conv1x1(p) -> 1 channel)
+//   att = BN(conv1x1(nearest2x(psi) * x_res)) = nearest2x(psi) * (W' x_res) + b'     -> channel slice of the concat buffer
+// The five ops are HBM-bound with next to no arithmetic; run one by one they move x, g, g1, p, psi and x_res (twice)
+// through HBM.  Here a wave owns 16 low-resolution pixels and chains the GEMMs IN REGISTERS: with the output-channel
+// permutation of the SP format (drs_sp_cout_perm: a lane's accumulators of a tile pair are 8 consecutive channels of its
+// pixel) the bias + ReLU'd accumulator of one GEMM, split into bf16 hi | lo, IS the B operand of the next one.  The four
+// x_res pixels under a low-resolution pixel are loaded once and serve both w_x and the gated result convolution.
+// HBM traffic per stage: x + x_res in, att out - half of the unfused sequence; no intermediate ever leaves the CU.
+// Weights of all four matrices stay in LDS for the lifetime of the (persistent) block; activations go global ->
+// registers in MFMA operand layout (an SP slot = 8 channels of a pixel = one operand register group), no LDS staging,
+// no barrier after the weight load.
+#include "conv_epilogue.h"
+#include "mfma_policy.h"
+
+namespace {
+
+template <int NT>  // Ch = 16 * NT output channels everywhere: NT = 2 (Ch = 32), 4 (Ch = 64)
+__global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using P = PolicyBF16X3;
+  constexpr int Ch = 16 * NT, NC = NT / 2;  // NC: 32-channel chunks of a Ch-channel tensor
+  const int ncx = d.Cc / 32;                // chunks of the stage input
+  // LDS images: gate [ncx][4][Ch], wg [NC][4][Ch], wx [NC][4 taps][4][Ch], res [NC][4][Ch] slots of 16 bytes, hi then lo
+  const int gate_img = ncx * 4 * Ch * 16, wg_img = NC * 4 * Ch * 16, wx_img = NC * 16 * Ch * 16;
+  char* sGate = smem;
+  char* sWg = sGate + 2 * gate_img;
+  char* sWx = sWg + 2 * wg_img;
+  char* sRes = sWx + 2 * wx_img;
+  {
+    const int tid = threadIdx.x;
+    auto copy = [&](char* dst, const void* src, int bytes) {
+      for (int o = tid * 16; o < bytes; o += 512 * 16)
+        *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src) + o);
+    };
+    copy(sGate, d.w_gate, 2 * gate_img);
+    copy(sWg, d.w_wg, 2 * wg_img);
+    copy(sWx, d.w_wx, 2 * wx_img);
+    copy(sRes, d.w_res, 2 * wg_img);
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  auto wfrag = [&](const char* base, int img, int slot) {  // slot = ((chunk * taps + tap) * 4 + kg) * Ch + tile * 16 + lr
+    return P::load(base, (size_t)img, (size_t)slot * 16);
+  };
+  // channel of (tile tt, register j) of this lane in SP order: (tt >> 1) * 32 + kg * 8 + (tt & 1) * 4 + j
+  const int bw = (d.LW + 15) / 16;
+  const long long nitems = (long long)d.N * d.LH * bw;
+  const int OW = 2 * d.LW, OH = 2 * d.LH;
+  for (long long it = (long long)blockIdx.x * 8 + wave; it < nitems; it += (long long)gridDim.x * 8) {
+    const int xb = (int)(it % bw), y = (int)((it / bw) % d.LH), n = (int)(it / ((long long)bw * d.LH));
+    const int px_raw = xb * 16 + lr;
+    const bool valid = px_raw < d.LW;
+    const int px = valid ? px_raw : d.LW - 1;
+    // ---- skip-tensor fragments of the 4 pixels under this low-resolution pixel (issued first: the longest latency) ----
+    typename P::Frag xr[4][NC];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const size_t pix = ((size_t)n * OH + 2 * y + (t >> 1)) * OW + 2 * px + (t & 1);
+      const char* g = reinterpret_cast<const char*>(d.xres) + (pix * d.r_cs + d.r_co) * 4 + kg * 16;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+        xr[t][cc] = typename P::Frag{*reinterpret_cast<const bf16x8*>(g + cc * 128), *reinterpret_cast<const bf16x8*>(g + cc * 128 + 64)};
+    }
+    // ---- gating signal: g = relu(Wg x + bg), K = Cc from global memory ----
+    f32x4 acc[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      const char* g = reinterpret_cast<const char*>(d.x) + ((((size_t)n * d.LH + y) * d.LW + px) * d.x_cs + d.x_co) * 4 + kg * 16;
+      for (int c = 0; c < ncx; c += 2) {  // two chunks in flight (Cc is a multiple of 64 on these stages)
+        const typename P::Frag a0{*reinterpret_cast<const bf16x8*>(g + c * 128), *reinterpret_cast<const bf16x8*>(g + c * 128 + 64)};
+        const typename P::Frag a1{*reinterpret_cast<const bf16x8*>(g + c * 128 + 128), *reinterpret_cast<const bf16x8*>(g + c * 128 + 192)};
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = P::mma(wfrag(sGate, gate_img, (c * 4 + kg) * Ch + tt * 16 + lr), a0, acc[tt]);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = P::mma(wfrag(sGate, gate_img, ((c + 1) * 4 + kg) * Ch + tt * 16 + lr), a1, acc[tt]);
+      }
+    }
+    // bias + ReLU, split: the accumulators of tile pair cc are this lane's operand slot of chunk cc of the next GEMM
+    typename P::Frag gfr[NC];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      const float4 b0 = *reinterpret_cast<const float4*>(d.b_gate + cc * 32 + kg * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(d.b_gate + cc * 32 + kg * 8 + 4);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = fmaxf(acc[2 * cc][j] + bb[j], 0.f);
+        v[4 + j] = fmaxf(acc[2 * cc + 1][j] + bb[4 + j], 0.f);
+      }
+      u32x4 h, l;
+      drs_sp_split8(v, h, l);
+      gfr[cc] = typename P::Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+    }
+    // ---- p = relu(w_g(g) + w_x(x_res) + biases) ----
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) acc[tt] = P::mma(wfrag(sWg, wg_img, (cc * 4 + kg) * Ch + tt * 16 + lr), gfr[cc], acc[tt]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          acc[tt] = P::mma(wfrag(sWx, wx_img, ((cc * 4 + t) * 4 + kg) * Ch + tt * 16 + lr), xr[t][cc], acc[tt]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the weight-fragment reads of the next tap behind these MFMAs (registers)
+    }
+    // ---- psi = sigmoid(w_psi . p + b_psi): in-lane partial over this lane's channels, then the 4 k-group lanes of the pixel ----
+    float dot = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int ch = (tt >> 1) * 32 + kg * 8 + (tt & 1) * 4;
+      const float4 bg = *reinterpret_cast<const float4*>(d.b_wg + ch), bx = *reinterpret_cast<const float4*>(d.b_wx + ch);
+      const float4 wp = *reinterpret_cast<const float4*>(d.w_psi + ch);
+      dot += fmaxf(acc[tt][0] + bg.x + bx.x, 0.f) * wp.x + fmaxf(acc[tt][1] + bg.y + bx.y, 0.f) * wp.y +
+             fmaxf(acc[tt][2] + bg.z + bx.z, 0.f) * wp.z + fmaxf(acc[tt][3] + bg.w + bx.w, 0.f) * wp.w;
+    }
+    dot += __shfl_xor(dot, 16);
+    dot += __shfl_xor(dot, 32);
+    const float psi = 1.f / (1.f + expf(-(dot + d.b_psi[0])));
+    if (d.psi_out && valid && kg == 0) d.psi_out[((size_t)n * d.LH + y) * d.LW + px] = psi;
+    // ---- att = psi * (W' x_res) + b' for the 4 pixels, stored as SP halves into the concat slice ----
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = P::mma(wfrag(sRes, wg_img, (cc * 4 + kg) * Ch + tt * 16 + lr), xr[t][cc], acc[tt]);
+      __builtin_amdgcn_sched_barrier(0);
+      const size_t pix = ((size_t)n * OH + 2 * y + (t >> 1)) * OW + 2 * px + (t & 1);
+      char* o = reinterpret_cast<char*>(d.out) + (pix * d.out_cs + d.out_co) * 4 + kg * 16;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        const float4 b0 = *reinterpret_cast<const float4*>(d.b_res + cc * 32 + kg * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(d.b_res + cc * 32 + kg * 8 + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = psi * acc[2 * cc][j] + bb[j];
+          v[4 + j] = psi * acc[2 * cc + 1][j] + bb[4 + j];
+        }
+        u32x4 h, l;
+        drs_sp_split8(v, h, l);
+        if (valid) {
+          *reinterpret_cast<u32x4*>(o + cc * 128) = h;
+          *reinterpret_cast<u32x4*>(o + cc * 128 + 64) = l;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
+  auto kern = attn_gate_sp_kernel<NT>;
+  int num_cu = 0;
+  {
+    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
+    if (rc) return rc;
+  }
+  const long long nitems = (long long)d.N * d.LH * ((d.LW + 15) / 16);
+  long long blocks = num_cu;  // one 8-wave block per CU, persistent over the pixel blocks
+  if (blocks * 8 > nitems) blocks = (nitems + 7) / 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, d);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+}  // namespace
+
+size_t drs_attn_gate_lds_bytes(int Cc, int Ch) {
+  // gate Ch x Cc, w_g Ch x Ch, w_x 4 x Ch x Ch, result Ch x Ch, two bf16 images each
+  return (size_t)4 * Ch * ((size_t)Cc + 6 * (size_t)Ch);
+}
+
+bool drs_attn_gate_supported(int Cc, int Ch) {
+  static const bool env = !(getenv("DRS_FUSE_GATE") && atoi(getenv("DRS_FUSE_GATE")) == 0);
+  return env && (Ch == 32 || Ch == 64) && Cc % 64 == 0 && drs_attn_gate_lds_bytes(Cc, Ch) <= 160 * 1024;
+}
+
+int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
+  DRS_REQUIRE(drs_attn_gate_supported(d.Cc, d.Ch), DRS_ERR_SHAPE, "attn_gate: Cc=%d Ch=%d", d.Cc, d.Ch);
+  DRS_REQUIRE(d.x && d.xres && d.out && d.w_gate && d.w_wg && d.w_wx && d.w_res && d.w_psi, DRS_ERR_ARG, "attn_gate: null pointer");
+  DRS_REQUIRE(!(d.x_cs & 31) && !(d.x_co & 31) && !(d.r_cs & 31) && !(d.r_co & 31) && !(d.out_cs & 31) && !(d.out_co & 31),
+              DRS_ERR_SHAPE, "attn_gate: channel strides / offsets must be multiples of 32");
+  if ((long long)d.N * d.LH * d.LW == 0) return DRS_OK;
+  const size_t lds = drs_attn_gate_lds_bytes(d.Cc, d.Ch);
+  return d.Ch == 32 ? attn_launch<2>(d, lds, s) : attn_launch<4>(d, lds, s);
+}

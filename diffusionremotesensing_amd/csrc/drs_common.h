@@ -140,6 +140,24 @@ int drs_launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, i
 
 int drs_launch_sp_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int src_cs, int src_co, hipStream_t s);
 
+// fused attention gate of a decoder stage over SP-format activations (attn_gate_sp.hip)
+struct AttnGateDesc {
+  const float* x;    int x_cs, x_co;      // stage input (SP), Cc channels, N x LH x LW
+  const float* xres; int r_cs, r_co;      // skip tensor (SP), Ch channels, N x 2LH x 2LW
+  float* out;        int out_cs, out_co;  // concat buffer (SP): channels [out_co, out_co + Ch) at N x 2LH x 2LW
+  float* psi_out;                         // optional (N, LH, LW) fp32 copy of psi, or null
+  int N, LH, LW, Cc, Ch;
+  // packed operand images (conv_mfma.hip: [chunk][tap][k-group][Ch][8 x bf16], hi image then lo image, output rows in SP
+  // permutation), biases in logical channel order
+  const void* w_gate; const float* b_gate;
+  const void* w_wg;   const float* b_wg;
+  const void* w_wx;   const float* b_wx;   // 4 taps (ky*2 + kx)
+  const float* w_psi; const float* b_psi;  // Ch floats + 1
+  const void* w_res;  const float* b_res;
+};
+bool drs_attn_gate_supported(int Cc, int Ch);
+int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s);
+
 int drs_launch_sp_add_rowvec(const float* src, float* dst, const float* vec, int vec_stride, int N, long long pix_per_image,
                              int C, hipStream_t s);
 bool drs_tapconv_sp_supported(const TapConv& d, int impl);  // wave-specialised SP-format 3x3 kernel (conv_mfma_sp.hip) takes this op

@@ -253,7 +253,12 @@ struct ResBlock {
   bool dual = false;
   size_t dual_w_off = 0, dual_b_off = 0;
 };
-struct DecStage { ConvLayer gate, wg, wx, psi, result, conv, transform, upconv; Mlp mlp; };
+struct DecStage {
+  ConvLayer gate, wg, wx, psi, result, conv, transform, upconv; Mlp mlp;
+  // fused attention gate (attn_gate_sp.hip): w_g and w_x once more with the SP output-row permutation
+  bool fused_gate = false;
+  size_t fz_wg_off = 0, fz_wx_off = 0;
+};
 
 }  // namespace
 
@@ -497,6 +502,14 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
       rb.dual_b_off = cur; cur += align_up((size_t)64 * 4);
     }
   }
+  for (int i = 0; i < 3; ++i) {
+    DecStage& d = p->dec[i];
+    d.fused_gate = p->sp && drs_attn_gate_supported(kUp[i], kUp[i + 1]);
+    if (d.fused_gate) {
+      d.fz_wg_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(d.wg.Cout, d.wg.Cin, 1, DRS_IMPL_MFMA_BF16X3));
+      d.fz_wx_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(d.wx.Cout, d.wx.Cin, 4, DRS_IMPL_MFMA_BF16X3));
+    }
+  }
   for (PlanarConv* L : p->planars) {
     L->w_off = cur; cur += align_up((size_t)L->Cout * L->Cin * 9 * 4);
     L->b_off = cur; cur += align_up((size_t)L->Cout * 4);
@@ -683,6 +696,17 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
                                         plan->sp ? 1 : 0)))
       return rc;
   }
+  for (int i = 0; i < 3; ++i) {
+    const DecStage& d = plan->dec[i];
+    if (!d.fused_gate) continue;
+    // (the pack kernel also writes the bias vector: the layers' own bias slots receive the same values again)
+    if ((rc = drs_launch_pack_conv_mfma(F(d.wg.w), F(d.wg.b), nullptr, nullptr, nullptr, nullptr, 0.f, base + d.fz_wg_off,
+                                        (float*)(base + d.wg.b_off), d.wg.Cout, d.wg.Cin, 1, 0, impl, s, 0, 0, 0, 0, 1)))
+      return rc;
+    if ((rc = drs_launch_pack_conv_mfma(F(d.wx.w), F(d.wx.b), nullptr, nullptr, nullptr, nullptr, 0.f, base + d.fz_wx_off,
+                                        (float*)(base + d.wx.b_off), d.wx.Cout, d.wx.Cin, 4, 0, impl, s, 0, 0, 0, 0, 1)))
+      return rc;
+  }
   for (PlanarConv* L : plan->planars) {
     DRS_CHECK_HIP(hipMemcpyAsync(base + L->w_off, F(L->w), (size_t)L->Cout * L->Cin * 9 * 4, hipMemcpyDeviceToDevice, s));
     DRS_CHECK_HIP(hipMemcpyAsync(base + L->b_off, F(L->b), (size_t)L->Cout * 4, hipMemcpyDeviceToDevice, s));
@@ -809,8 +833,12 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
 #define RUN(expr) do { if ((rc = (expr))) return rc; } while (0)
 
   // --- second stream (eval plans): see the decoder section ---
-  static const bool concurrent_env = !(getenv("DRS_CONCURRENT") && atoi(getenv("DRS_CONCURRENT")) == 0);
-  const bool concurrent = concurrent_env && !train && !plan->profiling && c.impl != DRS_IMPL_DIRECT;
+  // DRS_CONCURRENT: 1 / 0 force the two-stream decoder stages on / off.  Default: on for the fp32-activation plans (their
+  // kernels run two blocks per CU and leave room for a partner); off for SP plans, whose wave-specialised kernels own a
+  // whole CU (154 KB of LDS, 12 waves) and whose attention gate is one fused launch: measured 498 vs 469 steps/s.
+  static const int concurrent_env = getenv("DRS_CONCURRENT") ? atoi(getenv("DRS_CONCURRENT")) : -1;
+  const bool concurrent = (concurrent_env < 0 ? !plan->sp : concurrent_env != 0) && !train && !plan->profiling &&
+                          c.impl != DRS_IMPL_DIRECT;
   if (concurrent && !plan->side) {
     DRS_CHECK_HIP(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
     DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
@@ -978,6 +1006,28 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       if (concurrent) d.shared_cu = 1;
       return plan_conv(plan, L, d, sa);
     };
+    const bool fuse_gate = st.fused_gate && !(c.flags & DRS_PLAN_KEEP_ALL);
+    if (fuse_gate) {
+      // gating signal + attention gate in ONE launch (attn_gate_sp.hip): g, g1, p and psi never reach HBM
+      AttnGateDesc a = {};
+      a.x = xcur; a.x_cs = Cc; a.x_co = 0;
+      a.xres = xres; a.r_cs = Ch; a.r_co = 0;
+      a.out = cat; a.out_cs = Cc + Ch; a.out_co = Cc;
+      a.psi_out = nullptr;
+      a.N = B; a.LH = lh; a.LW = lw; a.Cc = Cc; a.Ch = Ch;
+      a.w_gate = PW(st.gate); a.b_gate = PB(st.gate);
+      a.w_wg = pk + st.fz_wg_off; a.b_wg = PB(st.wg);
+      a.w_wx = pk + st.fz_wx_off; a.b_wx = PB(st.wx);
+      a.w_psi = PW(st.psi); a.b_psi = PB(st.psi);
+      a.w_res = PW(st.result); a.b_res = PB(st.result);
+      const double px = (double)B * lh * lw;
+      prof_begin(plan, "attention_gate." + std::to_string(i), 2.0 * px * Ch * (Cc + 10.0 * Ch),
+                 4.0 * px * (Cc + 8.0 * Ch), sa);
+      rc = drs_launch_attn_gate(a, sa);
+      prof_end(plan, sa);
+      if (rc) return rc;
+      if (concurrent) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, sa));
+    } else {
     {  // gating = relu(BN(conv1x1(x)))   (:222-225)
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.gate), PB(st.gate), TP(plan->t_G[i]), Ch, Ch, 0, 1, 1, 1,
                             0);
@@ -1017,6 +1067,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       RUN(att_conv(st.result, d));
       if (concurrent) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, sa));
     }
+    }  // !fuse_gate
     {  // UpConvBlock: relu(BN(conv(x + relu(time_mlp(t)))))   (:199-205)
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.conv), PB(st.conv), TP(plan->t_U[i]), Cc, Cc, 0, 3, 3, 1,
                             1);
