@@ -172,6 +172,9 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
     // Every wait is for an event whose own prerequisites lie strictly earlier in this order: no cycle.  Counters are
     // bumped with release semantics after the ds_writes have completed (lgkmcnt(0)).
     const int pw = wid - 8;
+    // The movers issue few instructions, each of which gates thousands of MFMA cycles: top priority on their SIMDs (they
+    // are the youngest waves there and would otherwise only get the issue slots the two MFMA streams leave over).
+    __builtin_amdgcn_s_setprio(3);
     const char* wg = reinterpret_cast<const char*>(d.w);
     const size_t w_chunk = (size_t)9 * 4 * wcout * 16;
     const size_t w_gimage = DUAL ? 2 * (size_t)g.w_gimage : (size_t)g.w_gimage;  // (the geometry was sized for d.Cout channels)
@@ -196,21 +199,25 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
     constexpr int WPC = BNB == 64 ? 6 : 3;  // weight pieces (1 KB) per mover wave and kernel column
     u32x4 wr[2][WPC], ww[NPW];  // column registers: column 2 re-uses column 0's once that one is stored
     // weight piece i of column col: source address and LDS destination of this lane's 16 bytes
+    // Address of a weight piece = scalar base of the step (chunk, channel group) + scalar offset of the piece (operand
+    // image, kernel row / column, k-group: 32 bits) + this lane's constant byte offset: no per-lane 64-bit arithmetic
+    // inside the step loop.
+    const unsigned lane_w = BNB == 64 ? (unsigned)lane * 16u : (unsigned)(((lane >> 5) * d.Cout + (lane & 31)) * 16);
     auto piece = [&](int col, bool second, int cc, int n0_, int i, const char*& src, char*& dst) __attribute__((always_inline)) {
+      int im, ky, kq;  // operand image, kernel row, (first) k-group of the piece: wave-uniform
       if constexpr (BNB == 64) {  // piece = one (image, ky, k-group) row of 64 channels; second input: (image, k-group)
         const int idx = pw * (second ? 2 : WPC) + i;
-        const int im = second ? idx >> 2 : idx / 12, ky = second ? 0 : (idx % 12) >> 2, kq = idx & 3;
-        src = second ? reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage + ((size_t)(cc * 4 + kq) * wcout + n0_ + lane) * 16
-                     : wg + (size_t)im * w_gimage + (size_t)cc * w_chunk + ((size_t)((ky * 3 + col) * 4 + kq) * wcout + n0_ + lane) * 16;
-        dst = sW + (size_t)im * W_IMAGE + (size_t)(((second ? 0 : col) * 3 + ky) * 4 + kq) * BNB * 16 + lane * 16;
+        im = second ? idx >> 2 : idx / 12; ky = second ? 0 : (idx % 12) >> 2; kq = idx & 3;
       } else {  // piece = two consecutive k-group rows of 32 channels
-        const int prow = lane >> 5, pco = lane & 31;
         const int row0 = (pw * (second ? 1 : WPC) + i) * 2;
-        const int im = second ? row0 >> 2 : row0 / 12, ky = second ? 0 : (row0 % 12) >> 2, kq0 = row0 & 3;
-        src = second ? reinterpret_cast<const char*>(d.w2) + (size_t)im * g.w2_gimage + ((size_t)(cc * 4 + kq0 + prow) * d.Cout + n0_ + pco) * 16
-                     : wg + (size_t)im * w_gimage + (size_t)cc * w_chunk + ((size_t)((ky * 3 + col) * 4 + kq0 + prow) * d.Cout + n0_ + pco) * 16;
-        dst = sW + (size_t)im * W_IMAGE + (size_t)(((second ? 0 : col) * 3 + ky) * 4 + kq0) * BNB * 16 + lane * 16;
+        im = second ? row0 >> 2 : row0 / 12; ky = second ? 0 : (row0 % 12) >> 2; kq = row0 & 3;
       }
+      const char* base = second ? reinterpret_cast<const char*>(d.w2) + (size_t)cc * 4 * wcout * 16 + (size_t)n0_ * 16
+                                : wg + (size_t)cc * w_chunk + (size_t)n0_ * 16;
+      const unsigned soff = second ? (unsigned)im * (unsigned)g.w2_gimage + (unsigned)(kq * wcout * 16)
+                                   : (unsigned)im * (unsigned)w_gimage + (unsigned)(((ky * 3 + col) * 4 + kq) * wcout * 16);
+      src = base + soff + lane_w;
+      dst = sW + im * W_IMAGE + (((second ? 0 : col) * 3 + ky) * 4 + kq) * BNB * 16 + lane * 16;
     };
     const int nwin = pw == 0 ? NPW : NPW - 1;  // window pieces of this wave
     for (int k = 0; k < S; ++k) {
@@ -346,7 +353,10 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
       return typename P::Frag{*reinterpret_cast<const bf16x8*>(buf + tab_hi[q & 7] + q * 128),
                               *reinterpret_cast<const bf16x8*>(buf + tab_lo[q & 7] + q * 128)};
     };
-    auto mma_col = [&](const char* buf, int col) __attribute__((always_inline)) {
+    // MFMAs of kernel column `col`.  PRE: the weight fragments of column col + 1 are read into wf[ky] as soon as the last
+    // window row that needs the old wf[ky] has been issued (row ky + RPW - 1), behind a poll of that column's "landed"
+    // counter: the fragment-read latency of the next column hides under the tail of this one.
+    auto mma_col = [&](const char* buf, int col, bool pre, unsigned ltarget) __attribute__((always_inline)) {
 #pragma unroll
       for (int wr = 0; wr < RPW + 2; ++wr) {
         const typename P::Frag af = win_frag(buf, wr * IW + col);
@@ -354,19 +364,25 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
         for (int ky = 0; ky < 3; ++ky) {
           const int r = wr - ky;
           if (r >= 0 && r < RPW) {
+#ifdef DRS_SP_TIMELINE
+            if (g.debug & 4) continue;
+#endif
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[ky][t], af, acc[r][t]);
           }
         }
+        if (pre) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+            if (wr == ky + RPW - 1) {
+              if (ky == 0) sp_poll(sCL + col + 1, ltarget);
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                wf[ky][t] = P::load(wbase, W_IMAGE, (size_t)((((col + 1) * 3 + ky) * 4 * BNB) + t * 16) * 16);
+            }
+        }
       }
     };
-    auto mma_col_dbg = [&](const char* buf, int col) __attribute__((always_inline)) {
-#ifdef DRS_SP_TIMELINE
-      if (g.debug & 4) return;
-#endif
-      mma_col(buf, col);
-    };
-
     for (int k = 0; k < S; ++k) {
       if (++c == nck) c = 0;
       if (c == 0) {
@@ -401,21 +417,17 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
           sp_bump(sWR + (k & 1));
         }
       } else {
-        mma_col_dbg(buf, 0);
+        mma_col(buf, 0, true, ltarget);  // ... and the fragments of column 1 under its tail
         SP_STAMP(2);
-        sp_poll(sCL + 1, ltarget);
-        read_wf(1);
         sp_wait_lds();
         sp_bump_prio(sCR + 1, 8u * (unsigned)k, lane);
         SP_STAMP(3);
-        mma_col_dbg(buf, 1);
+        mma_col(buf, 1, true, ltarget);  // ... and of column 2
         SP_STAMP(4);
-        sp_poll(sCL + 2, ltarget);
-        read_wf(2);
         sp_wait_lds();
         sp_bump_prio(sCR + 2, 8u * (unsigned)k, lane);
         SP_STAMP(5);
-        mma_col_dbg(buf, 2);
+        mma_col(buf, 2, false, 0u);
         sp_wait_lds();  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
         if (lane == 0) sp_bump(sWR + (k & 1));
         SP_STAMP(6);
