@@ -302,13 +302,14 @@ def main():
         with torch.no_grad():
             x.copy_(x_cpu)
             ops = engine.profile_forward(x, t.fill_(750), lr, MAG, iters=5)
-        # dominant kernel = the 3x3 stride-1 implicit-GEMM family (tapconv_ws_kernel / tapconv_mfma_kernel<.., CONV3X3>):
-        # every conv1 / conv2 / skip conv of the residual blocks (block 0: conv1 + skip fused into one launch), ups.*.conv
-        # and up_convs.0/1 (up_convs.2 is the fused-projection instantiation and is listed separately).  achieved = algorithmic FLOPs of those launches
-        # (2*MACs) / their HIP-event durations, i.e. FLOPs per launch / average launch duration.
+        # dominant kernel = the 3x3 stride-1 implicit-GEMM convolution: on the default (split-bf16, SP-format) plan every
+        # such layer is ONE kernel template, tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL> (conv_mfma_sp.hip): conv1 / conv2 of
+        # the residual blocks (block 0: conv1 + skip fused into one launch), ups.*.conv and up_convs.* (up_convs.2 with the
+        # fused output projection) = 14 launches per forward.  achieved = algorithmic FLOPs of those launches (2*MACs,
+        # SURVEY.md 8(d)) / their HIP-event durations, i.e. FLOPs per launch / average launch duration.
         def is_dom(name):
             return (name.endswith((".conv1.0", ".conv2.0", ".conv_upsampled_lr_img", ".conv1.0+skip")) or
-                    (name.startswith("ups.") and name.endswith(".conv")) or name in ("up_convs.0", "up_convs.1"))
+                    (name.startswith("ups.") and name.endswith(".conv")) or name.startswith("up_convs."))
         conv = [o for o in ops if o[2] > 0 and o[0] not in ("lr_branch", "conv0")]
         dom = [o for o in conv if is_dom(o[0])] if args.impl != "direct" else conv
         conv_ms = sum(o[1] for o in conv)
@@ -319,37 +320,51 @@ def main():
         top = sorted(ops, key=lambda o: -o[1])[:6]
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.impl]
+        # HBM traffic from the PMC passes (they cannot run inside this process): profiles/r02_pmc_traffic.json, per op of
+        # one forward (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes, gfx950 correction of MI355X_MICROARCH.md)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if args.impl == "mfma_bf16x3" and os.path.exists(tpath):  # PMC passes cannot run inside this process
-            # the dominant family = every 3x3 stride-1 instantiation (wave-specialised kernel for the wide layers, the
-            # CONV3X3 schedule of tapconv_mfma_kernel for the rest): launch-weighted mean of their measured HBM bytes
-            tot_b = tot_n = 0.0
-            for kname, e in json.load(open(tpath))["kernels"].items():
-                # tapconv_ws_kernel<P, HAS2, BNB, FUSE, DUAL>: FUSE = up_convs.2, listed on its own, not in `dom`
-                fused_projection = re.search(r"tapconv_ws_kernel<[^,]+, (true|false), \d+, true", kname) is not None
-                if (("PolicyBF16X3, 32, 4, 1," in kname or ("tapconv_ws_kernel<PolicyBF16X3" in kname and not fused_projection))
-                        and "hbm_bytes_per_launch" in e):
-                    tot_b += e["hbm_bytes_per_launch"] * e["launches_per_forward"]
-                    tot_n += e["launches_per_forward"]
-            if tot_n:
-                traffic = round(tot_b / tot_n)
+        level256 = None
+        fwd_traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if args.impl == "mfma_bf16x3" and os.path.exists(tpath):
+            per_op = json.load(open(tpath)).get("per_op_last_forward") or []
+            by_name = {e["op"]: e["hbm_read_bytes"] + e["hbm_write_bytes"] for e in per_op}
+            dom_t = [by_name[o[0]] for o in dom if o[0] in by_name]
+            if dom_t and len(dom_t) == len(dom):
+                traffic = round(sum(dom_t) / len(dom_t))
+            # the 256x256 level: conv0, conv_blocks.0, downs.0, decoder stage 2 (gate, ups.2.conv reads 128x128 but writes
+            # for it, transform, up_convs.2): counter bytes / HIP-event time of the same ops in this run / 8 TB/s
+            lvl = [o for o in ops if o[0] in by_name and (o[0] == "conv0" or o[0].startswith("conv_blocks.0.") or
+                                                          o[0] in ("downs.0", "attention_gate.2", "ups.2.transform", "up_convs.2") or
+                                                          o[0].startswith(("gating_signals.2", "attention_blocks.2")))]
+            if lvl:
+                lb = sum(by_name[o[0]] for o in lvl)
+                lms = sum(o[1] for o in lvl)
+                level256 = {"ops": [o[0] for o in lvl], "pmc_bytes": round(lb), "ms": round(lms, 4),
+                            "GBs": round(lb / 1e9 / (lms * 1e-3), 1), "frac": round(lb / 1e9 / (lms * 1e-3) / HBM_PEAK_GBS, 4)}
+            if per_op:
+                fb = sum(by_name.values())
+                fwd_traffic = {"pmc_bytes": round(fb), "GBs": round(fb / 1e9 / (all_ms * 1e-3), 1),
+                               "frac": round(fb / 1e9 / (all_ms * 1e-3) / HBM_PEAK_GBS, 4)}
         mfma_per_product = 3 if args.impl == "mfma_bf16x3" else 1
         roofline = {"bound": "mfma",
-                    "kernel": ("3x3 stride-1 family: tapconv_ws_kernel<%s, *> (wave-specialised, Cout %% 64 == 0) + "
-                               "tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *>" % (args.impl, args.impl)) if args.impl != "direct"
-                    else "tapconv_direct_kernel",
+                    "kernel": ("3x3 stride-1 convolution: tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL> (conv_mfma_sp.hip; 8 MFMA + 4 "
+                               "mover waves per CU, SP-format operands)" if args.impl == "mfma_bf16x3" else
+                               "3x3 stride-1 family: tapconv_ws_kernel / tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *>" % args.impl)
+                    if args.impl != "direct" else "tapconv_direct_kernel",
                     "launches_per_forward": len(dom),
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
                     "flops_per_launch": round(dom_fl / len(dom)), "avg_launch_us": round(1e3 * dom_ms / len(dom), 2),
                     "algorithmic_bytes_per_launch": round(dom_by / len(dom)),
-                    "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
-                    if traffic else None,
+                    "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                    "per op of one forward)" if traffic else None,
                     "mfma_instructions_per_product": mfma_per_product,
                     "mfma_pipe_frac": round(mfma_per_product * achieved / peak, 5),
                     "forward_ms_sum_of_ops": round(all_ms, 4), "conv_ms": round(conv_ms, 4),
                     "forward_hbm_GBs_algorithmic": round(MB_PER_FWD / 1e3 / (all_ms * 1e-3), 1),
                     "forward_hbm_frac_of_8TBs": round(MB_PER_FWD / 1e3 / (all_ms * 1e-3) / HBM_PEAK_GBS, 5),
+                    "forward_hbm_counter_based": fwd_traffic,
+                    "hbm_frac_256_level": level256["frac"] if level256 else None, "level_256": level256,
                     "top_ops_ms": {n: round(ms, 4) for n, ms, _, _ in top}}
         result = {
             "metric": "unet_denoise_steps_per_s", "value": round(value, 4), "unit": "batch16_steps/s",

@@ -578,17 +578,23 @@ def test_full_length_chain_is_deterministic(dev, model):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ws", ["0", "1"])
-def test_conv_kernel_variants_in_subprocess(ws):
-    """The 3x3 kernel family is chosen once per process (DRS_WS: 0 = lock-step kernel only, 1 = wave-specialised for
-    the 64-channel-group layers only, 5 = default: + the 32-channel flavour).  The default is what every other test
-    runs; the others must reproduce the same goldens.  Own process, because the switch is read once."""
+@pytest.mark.parametrize("env", [{"DRS_SP": "0"}, {"DRS_SP": "0", "DRS_WS": "0"}, {"DRS_SPK": "0"}, {"DRS_FUSE_GATE": "0"},
+                                 {"DRS_CONCURRENT": "1"}],
+                         ids=["fp32-activations+ws", "fp32-activations+lockstep", "sp+lockstep", "sp-unfused-gate", "sp-two-streams"])
+def test_conv_kernel_variants_in_subprocess(env):
+    """The kernel families of the eval split-bf16 plan are chosen once per process.  Default = SP-format activations with
+    the wave-specialised SP kernel and the fused attention gate, serial stages; the switches select the older paths that
+    the training / fp32 plans and small shapes still use: DRS_SP=0 fp32 channels-last activations (wave-specialised
+    fp32-input kernel, DRS_WS=0: lock-step kernel only), DRS_SPK=0 SP format on the lock-step kernel, DRS_FUSE_GATE=0 the
+    five-launch attention gate, DRS_CONCURRENT=1 two-stream decoder stages.  All must reproduce the same goldens.  Own
+    process, because the switches are read once."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DRS_WS=ws)
+    env = dict(os.environ, **env)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-m", "gpu", "-k",
-           "test_unet_blocks_golden or test_unet_forward_config1_vs_oracle or (test_conv2d_flavours and mfma_bf16x3)"]
+           "test_unet_blocks_golden or test_unet_forward_config1_vs_oracle or test_unet_forward_golden or "
+           "(test_conv2d_flavours and mfma_bf16x3)"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

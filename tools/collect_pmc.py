@@ -11,7 +11,9 @@ import re
 import sys
 from collections import defaultdict
 
-out, steps, dirs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
+args = [a for a in sys.argv[1:] if not a.startswith("--ops=")]
+ops_file = next((a[6:] for a in sys.argv[1:] if a.startswith("--ops=")), None)
+out, steps, dirs = args[0], int(args[1]), args[2:]
 acc = defaultdict(lambda: defaultdict(float))
 launches = defaultdict(int)
 for d in dirs:
@@ -24,6 +26,24 @@ for d in dirs:
             if row["Counter_Name"] in ("FETCH_SIZE", "SQ_WAVE_CYCLES") and key not in seen:
                 seen.add(key)
                 launches[(k, row["Counter_Name"])] += 1
+# per-dispatch HBM bytes of the LAST forward, in launch order, labelled with the plan's op names (bench.py writes them
+# with DRS_BENCH_OPS): the kernels of the library are launched one per op, in schedule order
+per_op = None
+if ops_file and os.path.exists(ops_file):
+    names = [ln.split()[0] for ln in open(ops_file) if ln.strip() and not ln.startswith("lr_branch")]
+    disp = defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "kernel": ""})
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    e = disp[int(row["Dispatch_Id"])]
+                    e[row["Counter_Name"]] += float(row["Counter_Value"])
+                    e["kernel"] = re.sub(r"\(.*", "", row["Kernel_Name"].replace("(anonymous namespace)::", ""))[:120]
+    mine = [v for _, v in sorted(disp.items()) if re.search(r"tapconv|stem_kernel|time_mlp|attn_gate", v["kernel"])]
+    if len(mine) >= len(names):
+        last = mine[-len(names):]  # the last forward re-uses the cached conditioning branch: exactly the listed ops
+        per_op = [{"op": n, "kernel": v["kernel"], "hbm_read_bytes": 2 * v["FETCH_SIZE"] * 1024,
+                   "hbm_write_bytes": v["WRITE_SIZE"] * 1024} for n, v in zip(names, last)]
 res = {}
 for k, c in acc.items():
     n = max(launches.get((k, "FETCH_SIZE"), 0), launches.get((k, "SQ_WAVE_CYCLES"), 0), 1)
@@ -41,6 +61,7 @@ json.dump({"command": "rocprofv3 --pmc <COUNTERS> --output-format csv -d DIR -- 
                       "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*), MI355X, bf16x3, BASELINE configs[1]" % steps,
            "note": "FETCH_SIZE/WRITE_SIZE are KB; hbm_read = 2 * FETCH_SIZE * 1024 (gfx950 correction of MI355X_MICROARCH.md); "
                    "values per UNet forward unless named per_launch",
+           "per_op_last_forward": per_op,
            "kernels": dict(sorted(res.items(), key=lambda kv: -kv[1].get("hbm_read_bytes_per_forward", 0)))},
           open(out, "w"), indent=1)
 print("wrote", out, len(res), "kernels")
