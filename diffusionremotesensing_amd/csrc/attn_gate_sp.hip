@@ -165,6 +165,201 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
   }
 }
 
+// ---- wide variant (Ch = 128: the first decoder stage, whose weights, 524 KB as bf16 hi | lo, cannot live in LDS) ----------
+// A block (8 waves) owns 64 low-resolution pixels = 4 MFMA pixel blocks; wave w computes output channels
+// [32 * (w & 3), + 32) of pixel blocks {2 * (w >> 2), + 1}.  Weight fragments come straight from global memory (every CU reads the
+// same 0.5 MB: L2-resident; the two waves of a channel group share them through L1), activations as above; the gating
+// signal crosses the channel groups through a 32 KB LDS image in operand-slot order, the psi partial sums through 1 KB.
+__global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) {
+  using P = PolicyBF16X3;
+  constexpr int Ch = 128, NG = 4;
+  __shared__ __attribute__((aligned(16))) char sG[4 * NG * 2 * 4 * 16 * 16];  // [pixel block 4][chunk 4][hi | lo][k-group 4][pixel 16]
+  __shared__ float sPsi[NG][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int cg = wave & 3, pb2 = wave >> 2;
+  const int ncx = d.Cc / 32;
+  const size_t gate_img = (size_t)ncx * 4 * Ch * 16, wg_img = (size_t)NG * 4 * Ch * 16, wx_img = (size_t)NG * 16 * Ch * 16;
+  const int bw = (d.LW + 15) / 16;
+  const long long nblk16 = (long long)d.N * d.LH * bw;
+  const long long nitems = (nblk16 + 3) / 4;
+  const int OW = 2 * d.LW, OH = 2 * d.LH;
+  auto wfrag = [&](const void* base, size_t img, int slot) {  // slot = ((chunk * taps + tap) * 4 + kg) * Ch + channel
+    const char* g = reinterpret_cast<const char*>(base) + (size_t)slot * 16;
+    return typename P::Frag{*reinterpret_cast<const bf16x8*>(g), *reinterpret_cast<const bf16x8*>(g + img)};
+  };
+  auto gslot = [&](int pbl, int cc, int img) { return sG + ((((pbl * NG + cc) * 2 + img) * 4 + kg) * 16 + lr) * 16; };
+  for (long long it = blockIdx.x; it < nitems; it += gridDim.x) {
+    int nn[2], yy[2], px[2];
+    bool valid[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const long long q = it * 4 + pb2 * 2 + b;
+      const long long qc = q < nblk16 ? q : nblk16 - 1;
+      const int xb = (int)(qc % bw);
+      yy[b] = (int)((qc / bw) % d.LH);
+      nn[b] = (int)(qc / ((long long)bw * d.LH));
+      const int pr = xb * 16 + lr;
+      valid[b] = q < nblk16 && pr < d.LW;
+      px[b] = pr < d.LW ? pr : d.LW - 1;
+    }
+    auto xres_frag = [&](int b, int t, int cc) {
+      const size_t pix = ((size_t)nn[b] * OH + 2 * yy[b] + (t >> 1)) * OW + 2 * px[b] + (t & 1);
+      const char* g = reinterpret_cast<const char*>(d.xres) + (pix * d.r_cs + d.r_co) * 4 + cc * 128 + kg * 16;
+      return typename P::Frag{*reinterpret_cast<const bf16x8*>(g), *reinterpret_cast<const bf16x8*>(g + 64)};
+    };
+    // ---- gating signal: this wave's 32 channels of g = relu(Wg x + bg) for its two pixel blocks ----
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      const char* xg[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        xg[b] = reinterpret_cast<const char*>(d.x) + ((((size_t)nn[b] * d.LH + yy[b]) * d.LW + px[b]) * d.x_cs + d.x_co) * 4 + kg * 16;
+      for (int c = 0; c < ncx; ++c) {
+        typename P::Frag wa[2], xa[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wa[t] = wfrag(d.w_gate, gate_img, (c * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          xa[b] = typename P::Frag{*reinterpret_cast<const bf16x8*>(xg[b] + c * 128), *reinterpret_cast<const bf16x8*>(xg[b] + c * 128 + 64)};
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[t], xa[b], acc[b][t]);
+      }
+    }
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(d.b_gate + cg * 32 + kg * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(d.b_gate + cg * 32 + kg * 8 + 4);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = fmaxf(acc[b][0][j] + bb[j], 0.f);
+          v[4 + j] = fmaxf(acc[b][1][j] + bb[4 + j], 0.f);
+        }
+        u32x4 h, l;
+        drs_sp_split8(v, h, l);
+        *reinterpret_cast<u32x4*>(gslot(pb2 * 2 + b, cg, 0)) = h;
+        *reinterpret_cast<u32x4*>(gslot(pb2 * 2 + b, cg, 1)) = l;
+      }
+    }
+    __syncthreads();
+    // ---- p = relu(w_g(g) + w_x(x_res) + biases), this wave's 32 channels ----
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NG; ++cc) {
+      typename P::Frag wa[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wa[t] = wfrag(d.w_wg, wg_img, (cc * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const typename P::Frag gf{*reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, cc, 0)),
+                                  *reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, cc, 1))};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[t], gf, acc[b][t]);
+      }
+    }
+    for (int t4 = 0; t4 < 4; ++t4) {
+#pragma unroll
+      for (int cc = 0; cc < NG; ++cc) {
+        typename P::Frag wa[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wa[t] = wfrag(d.w_wx, wx_img, ((cc * 4 + t4) * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const typename P::Frag xf = xres_frag(b, t4, cc);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[t], xf, acc[b][t]);
+        }
+      }
+    }
+    {
+      const int ch = cg * 32 + kg * 8;
+      float wp[8], bsum[8];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(d.w_psi + ch), a1 = *reinterpret_cast<const float4*>(d.w_psi + ch + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(d.b_wg + ch), g1 = *reinterpret_cast<const float4*>(d.b_wg + ch + 4);
+        const float4 x0 = *reinterpret_cast<const float4*>(d.b_wx + ch), x1 = *reinterpret_cast<const float4*>(d.b_wx + ch + 4);
+        wp[0] = a0.x; wp[1] = a0.y; wp[2] = a0.z; wp[3] = a0.w; wp[4] = a1.x; wp[5] = a1.y; wp[6] = a1.z; wp[7] = a1.w;
+        bsum[0] = g0.x + x0.x; bsum[1] = g0.y + x0.y; bsum[2] = g0.z + x0.z; bsum[3] = g0.w + x0.w;
+        bsum[4] = g1.x + x1.x; bsum[5] = g1.y + x1.y; bsum[6] = g1.z + x1.z; bsum[7] = g1.w + x1.w;
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dot += fmaxf(acc[b][0][j] + bsum[j], 0.f) * wp[j];
+          dot += fmaxf(acc[b][1][j] + bsum[4 + j], 0.f) * wp[4 + j];
+        }
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+        if (kg == 0) sPsi[cg][(pb2 * 2 + b) * 16 + lr] = dot;
+      }
+    }
+    __syncthreads();
+    float psi[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int i = (pb2 * 2 + b) * 16 + lr;
+      psi[b] = 1.f / (1.f + expf(-(sPsi[0][i] + sPsi[1][i] + sPsi[2][i] + sPsi[3][i] + d.b_psi[0])));
+      if (d.psi_out && valid[b] && kg == 0 && cg == 0) d.psi_out[((size_t)nn[b] * d.LH + yy[b]) * d.LW + px[b]] = psi[b];
+    }
+    // ---- att = psi * (W' x_res) + b' for the 4 pixels under each low-resolution pixel ----
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(d.b_res + cg * 32 + kg * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(d.b_res + cg * 32 + kg * 8 + 4);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      for (int t4 = 0; t4 < 4; ++t4) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < NG; ++cc) {
+          typename P::Frag wa[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) wa[t] = wfrag(d.w_res, wg_img, (cc * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const typename P::Frag xf = xres_frag(b, t4, cc);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[t], xf, acc[b][t]);
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = psi[b] * acc[b][0][j] + bb[j];
+            v[4 + j] = psi[b] * acc[b][1][j] + bb[4 + j];
+          }
+          u32x4 h, l;
+          drs_sp_split8(v, h, l);
+          if (valid[b]) {
+            const size_t pix = ((size_t)nn[b] * OH + 2 * yy[b] + (t4 >> 1)) * OW + 2 * px[b] + (t4 & 1);
+            char* o = reinterpret_cast<char*>(d.out) + (pix * d.out_cs + d.out_co + cg * 32) * 4 + kg * 16;
+            *reinterpret_cast<u32x4*>(o) = h;
+            *reinterpret_cast<u32x4*>(o + 64) = l;
+          }
+        }
+      }
+    }
+    __syncthreads();  // sG / sPsi are rewritten by the next item
+  }
+}
+
 template <int NT>
 int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
   auto kern = attn_gate_sp_kernel<NT>;
@@ -190,7 +385,9 @@ size_t drs_attn_gate_lds_bytes(int Cc, int Ch) {
 
 bool drs_attn_gate_supported(int Cc, int Ch) {
   static const bool env = !(getenv("DRS_FUSE_GATE") && atoi(getenv("DRS_FUSE_GATE")) == 0);
-  return env && (Ch == 32 || Ch == 64) && Cc % 64 == 0 && drs_attn_gate_lds_bytes(Cc, Ch) <= 160 * 1024;
+  if (!env) return false;
+  if (Ch == 128) return Cc % 32 == 0;  // wide variant: weights streamed from L2
+  return (Ch == 32 || Ch == 64) && Cc % 64 == 0 && drs_attn_gate_lds_bytes(Cc, Ch) <= 160 * 1024;
 }
 
 int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
@@ -199,6 +396,16 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
   DRS_REQUIRE(!(d.x_cs & 31) && !(d.x_co & 31) && !(d.r_cs & 31) && !(d.r_co & 31) && !(d.out_cs & 31) && !(d.out_co & 31),
               DRS_ERR_SHAPE, "attn_gate: channel strides / offsets must be multiples of 32");
   if ((long long)d.N * d.LH * d.LW == 0) return DRS_OK;
+  if (d.Ch == 128) {
+    int num_cu = 0;
+    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(attn_gate_wide_kernel), 0, &num_cu);
+    if (rc) return rc;
+    const long long nitems = ((long long)d.N * d.LH * ((d.LW + 15) / 16) + 3) / 4;
+    const long long blocks = nitems < 4LL * num_cu ? nitems : 4LL * num_cu;
+    hipLaunchKernelGGL(attn_gate_wide_kernel, dim3((unsigned)blocks), dim3(512), 0, s, d);
+    DRS_CHECK_HIP(hipGetLastError());
+    return DRS_OK;
+  }
   const size_t lds = drs_attn_gate_lds_bytes(d.Cc, d.Ch);
   return d.Ch == 32 ? attn_launch<2>(d, lds, s) : attn_launch<4>(d, lds, s);
 }
