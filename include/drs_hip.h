@@ -44,7 +44,11 @@ enum {
   DRS_IMPL_MFMA_F16 = 3  /* implicit GEMM, fp16 operands, fp32 accumulate */
 };
 
-/* Human-readable message for the last non-zero status returned on this thread. */
+/* Threading: a drs_plan (and the buffers bound to it) is used by ONE host thread at a time - its launches, events and side
+ * streams are not locked.  Different plans may be driven from different threads and on different devices; the plan-less
+ * entry points (noise_images, sampler steps, adam / ema, downblur, aggregate) are re-entrant.  The library's only
+ * process-wide state is a mutex-guarded per-device cache of kernel attributes.
+ * Human-readable message for the last non-zero status returned on this thread. */
 const char* drs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int drs_abi_version(void);

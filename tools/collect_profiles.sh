@@ -8,7 +8,7 @@ mkdir -p $O && cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt /tmp/f /tmp/w /tmp/sq
 cp $R/bench.py $R/tools/profile_forward.py /tmp/ 2>/dev/null
 cd $R
-DRS_BENCH_OPS=$O/bench_ops.txt rocprofv3 --kernel-trace --stats -d /tmp/kt -o b -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.log || exit 1
+DRS_BENCH_OPS=$O/bench_ops.txt rocprofv3 --kernel-trace --stats -d /tmp/kt -o b -- python3 bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.log || exit 1
 python3 tools/rocpd_sequence.py $(find /tmp/kt -name "b_results.db" | head -1) 40 > $O/step_kernel_sequence.txt || exit 1
 python3 tools/rocpd_stats.py $(find /tmp/kt -name "b_results.db" | head -1) 40 --csv > $O/bench_kernel_stats.csv || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/f -- python3 tools/profile_forward.py --steps 3 > $O/f.log 2>&1 || exit 1
@@ -19,5 +19,6 @@ python3 tools/collect_pmc.py $O/pmc_traffic.json 3 /tmp/f /tmp/w /tmp/sq --ops=$
 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o t -- python3 bench.py --workload train --steps 8 --warmup 2 > $O/train_under_rocprof.json 2> $O/kt2.log || exit 1
 python3 tools/rocpd_stats.py $(find /tmp/kt2 -name "t_results.db" | head -1) 40 --csv > $O/train_kernel_stats.csv || exit 1
 python3 bench.py --workload train --steps 10 --warmup 2 > $O/bench_train.json 2>> $O/kt2.log
+python3 tools/latency_regime.py --steps 50 --json $O/latency_regime.json > $O/latency_regime.txt 2>&1 || exit 1
 python3 bench.py > $O/bench_final.json 2> $O/bench_final.log
 tail -c 600 $O/bench_final.json

@@ -4,7 +4,8 @@
 train_diffusion_superres.py:422-424, Aggregation_Sampling.py:94-97) and BASELINE configs[4] (class-conditional CFG
 sampling, 64x64, batch 64: generate_new_imgs/train_diffusion_generation.py:236-249).  Prints ms per step (wall, K steps
 between two synchronisations) next to the sum of the per-op HIP-event times and the launch count of one step.
-Usage: latency_regime.py [--steps 50]"""
+`--json FILE` also writes the numbers and the per-launch sequence (op name, microseconds) of each workload's step.
+Usage: latency_regime.py [--steps 50] [--json FILE]"""
 import argparse
 import os
 import sys
@@ -19,6 +20,7 @@ from diffusionremotesensing_amd.train_diffusion_superres import Diffusion  # noq
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--json", default=None)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 
@@ -56,7 +58,7 @@ def superres(batch, image):
         ms = run("superres", step, a.steps)
         ops = eng.profile_forward(x, t.fill_(700), lr, 2, iters=5)
     ops = [o for o in ops if o[0] != "lr_branch"]
-    return ms, sum(o[1] for o in ops), len(ops) + 2  # + randn + sampler update
+    return ms, sum(o[1] for o in ops), len(ops) + 2, ops  # + randn + sampler update
 
 
 def generation():
@@ -81,13 +83,20 @@ def generation():
     with torch.no_grad():
         ms = run("generation", step, a.steps)
         ops = eng.profile_forward(x.repeat(2, 1, 1, 1), t2.fill_(500), None, 1, iters=5, labels=labels2)
-    return ms, sum(o[1] for o in ops), len(ops) + 3
+    return ms, sum(o[1] for o in ops), len(ops) + 3, ops
 
 
+report = []
 print(f"{'workload':44s} {'ms/step':>8s} {'sum of op ms':>13s} {'launches':>9s} {'gap share':>10s}")
 for name, fn in (("superres sample(n=1) 256x256", lambda: superres(1, 256)),
                  ("superres sample(n=4) 128x128 (configs[0])", lambda: superres(4, 128)),
                  ("superres step B=16 256x256 (configs[1])", lambda: superres(16, 256)),
                  ("generation CFG step B=64 64x64 (configs[4])", generation)):
-    ms, opsum, n = fn()
+    ms, opsum, n, ops = fn()
+    report.append({"workload": name, "ms_per_step": round(ms, 4), "sum_of_op_ms": round(opsum, 4), "launches": n,
+                   "sequence_us": [[o[0], round(1e3 * o[1], 1)] for o in ops]})
     print(f"{name:44s} {ms:8.3f} {opsum:13.3f} {n:9d} {max(0.0, 1 - opsum / ms):10.1%}")
+if a.json:
+    import json
+    with open(a.json, "w") as f:
+        json.dump({"steps": a.steps, "workloads": report}, f, indent=1)
