@@ -205,6 +205,14 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
       for (int j = 0; j < 8; ++j) bias8[j] += b2[j];
     }
     if (!LEAN && d.post_add) load8(d.post_add + (size_t)n * d.post_cs + c8, post8);
+    // (loaded before the first store: gfx9 counts loads and stores in ONE counter, a load issued after a store is only
+    // complete once that store has reached memory)
+    float post2_8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) post2_8[j] = 0.f;
+    if constexpr (OUT2) {
+      if (d.out2) load8(d.post2 + (size_t)n * d.post2_cs + c8, post2_8);
+    }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       const int ty = ty0 + wave * RPW + r;
@@ -249,9 +257,8 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
       if constexpr (OUT2) {
         if (d.out2) {
           float p2[8];
-          load8(d.post2 + (size_t)n * d.post2_cs + c8, p2);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) p2[j] += v[j];
+          for (int j = 0; j < 8; ++j) p2[j] = post2_8[j] + v[j];
           store_sp(d.out2, d.out2_cs, d.out2_co + cg, p2, ty, oy);
         }
       }
@@ -304,3 +311,61 @@ __device__ __forceinline__ void fuse_epilogue(const TapConv& d, f32x4 (&acc)[RPW
   }
 }
 
+
+// The same projection on the matrix pipe (split-bf16 kernels): y = W (acc + bias) is one more 16x16x32 GEMM per row of 16
+// pixels.  A lane's eight accumulators of the two channel tiles (channels kg*4 + j and 16 + kg*4 + j) are its eight
+// K-elements of the B operand once split into bf16 hi | lo; the A operand holds fuse_w in the same K order (rows >=
+// fuse_dim are zero), and the result rows 0..3 land in the lanes of k-group 0: no cross-lane reduction, no LDS round trips
+// (the shuffle form costs 8 ds_bpermute per row and was 35 us of up_convs.2's 220).  Same 2^-16 operand rounding as every
+// other product of the split-bf16 path.
+template <int RPW>
+__device__ __forceinline__ void fuse_epilogue_mfma(const TapConv& d, f32x4 (&acc)[RPW][2], int n, int n0, int ty0, int tx0,
+                                                   int wave, int lr, int kg) {
+  using P = PolicyBF16X3;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (d.bias) {
+    b0 = *reinterpret_cast<const float4*>(d.bias + n0 + kg * 4);
+    b1 = *reinterpret_cast<const float4*>(d.bias + n0 + 16 + kg * 4);
+  }
+  typename P::Frag wfr;
+  {
+    float w8[8];
+    const int m = min(lr, d.fuse_dim - 1);
+    const float4 w0 = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)m * d.Cout + n0 + kg * 4);
+    const float4 w1 = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)m * d.Cout + n0 + 16 + kg * 4);
+    const float keep = lr < d.fuse_dim ? 1.f : 0.f;
+    w8[0] = w0.x * keep; w8[1] = w0.y * keep; w8[2] = w0.z * keep; w8[3] = w0.w * keep;
+    w8[4] = w1.x * keep; w8[5] = w1.y * keep; w8[6] = w1.z * keep; w8[7] = w1.w * keep;
+    u32x4 h, l;
+    drs_sp_split8(w8, h, l);
+    wfr = typename P::Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+  }
+  float fb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb[j] = d.fuse_b[min(j, d.fuse_dim - 1)];
+  const size_t plane = (size_t)d.OH * d.OW;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int ty = ty0 + wave * RPW + r, tx = tx0 + lr;
+    const bool valid = ty < d.TH && tx < d.TW;
+    const int oy = min(ty, d.TH - 1) * d.out_scale + d.out_oy, ox = min(tx, d.TW - 1) * d.out_scale + d.out_ox;
+    float v[8];
+    v[0] = acc[r][0][0] + b0.x; v[1] = acc[r][0][1] + b0.y; v[2] = acc[r][0][2] + b0.z; v[3] = acc[r][0][3] + b0.w;
+    v[4] = acc[r][1][0] + b1.x; v[5] = acc[r][1][1] + b1.y; v[6] = acc[r][1][2] + b1.z; v[7] = acc[r][1][3] + b1.w;
+    if (d.out && valid) {  // parity taps only: production runs never store the 32-channel tensor
+      float* o = d.out + (((size_t)n * d.OH + oy) * d.OW + ox) * d.out_cs + d.out_co + n0 + kg * 4;
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(o + 16) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    u32x4 h, l;
+    drs_sp_split8(v, h, l);
+    const typename P::Frag vf{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+    const f32x4 y = P::mma(wfr, vf, f32x4{0.f, 0.f, 0.f, 0.f});  // lanes of k-group 0: outputs 0..3 of pixel lr
+    if (valid && kg == 0) {
+      float* o = d.fuse_out + (size_t)n * d.fuse_dim * plane + (size_t)oy * d.OW + ox;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < d.fuse_dim) o[(size_t)j * plane] = y[j] + fb[j];
+    }
+  }
+}

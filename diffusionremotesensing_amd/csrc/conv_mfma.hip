@@ -526,8 +526,11 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((size_t)d.N * d.TH * d.TW == 0) return DRS_OK;
   MfmaGeom g; int bn, rpw, mode; size_t lds;
   geom(d, impl, &g, &bn, &rpw, &mode, &lds);
-  if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_sp_supported(d, impl))
-    return drs_launch_tapconv_sp(d, g, s);
+  if (mode == MODE_GENERIC && drs_conv_s2_sp_supported(d, impl)) return drs_launch_conv_s2_sp(d, s);
+  if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_sp_supported(d, impl)) {
+    static const int spk = getenv("DRS_SPK") ? atoi(getenv("DRS_SPK")) : 1;
+    return (spk == 2 && !d.dual) ? drs_launch_tapconv_sp1(d, g, s) : drs_launch_tapconv_sp(d, g, s);
+  }
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_ws_supported(d, impl))
     return drs_launch_tapconv_ws(d, g, impl, s);
   DRS_REQUIRE(!d.dual, DRS_ERR_SHAPE, "tapconv_mfma: the fused conv1 + skip op needs the wave-specialised kernel");

@@ -1,29 +1,20 @@
-// Wave-specialised 3x3 stride-1 tap-convolution over SP-format activations (split bf16 hi | lo, drs_common.h): the
-// default kernel of every wide 3x3 layer of the eval split-bf16 plan (conv1 / conv2 (+ fused 1x1 shortcut) of the residual
-// blocks, ups.*.conv, up_convs.*; reference UNet_model_superres.py:153-172,197-207,377).
+// Wave-specialised 3x3 stride-1 tap-convolution over SP-format activations, ONE consumer wave per SIMD: the successor of
+// tapconv_sp_kernel (conv_mfma_sp.hip; same LDS images, same movers, same counter protocol, same epilogues).
 //
-// Same GEMM view, MFMA schedule and weight ring as tapconv_ws_kernel (conv_mfma_ws.hip); what is gone is every
-// conversion: the producers stored the operand halves, so the mover waves LDS-DMA the input window STRAIGHT INTO THE
-// OPERAND IMAGE (global_load_lds_dwordx4, whole 128-byte lines: 8 pixels x [4 hi slots | 4 lo slots] per instruction), and
-// the consumer waves only read fragments and issue MFMAs.  Zero padding costs nothing either: a lane whose window pixel
-// lies outside the image (or whose channels lie beyond Cin) takes a line of zeros as its source address.
-//   block = 12 waves on one CU: 8 consumer waves (2 per SIMD) + 4 mover waves (1 per SIMD, no vector registers to speak of)
-//   LDS   = 2 window buffers x 41 KB (double-buffered: window k+1 lands while window k is multiplied)
-//           + weight ring of the 3 kernel columns (72 KB at 64 output channels per block) + 5 counters = 154 KB
-//   step k (one 32-channel K-chunk of one 16x16 patch): NO block-wide barrier, ten monotonic LDS counters ("landed" /
-//   "released" per window buffer and per weight ring slot; protocol at the mover loop).  Waves drift apart by up to a
-//   step: while one wave of a SIMD waits for fragments or writes its tile out, its partner's MFMAs keep the pipe busy
-//   (with a barrier per step both waves of a SIMD stalled and multiplied at the same times: 65 % pipe occupancy).
-// Window image in LDS: like memory, 128 bytes per window pixel (18 x 18 window, row-major) = the pixel's 8 operand slots
-// [hi k-groups 0-3 | lo k-groups 0-3], ROTATED by the pixel index: slot c of pixel p sits at position (c + p) & 7.  The
-// DMA reads whole lines (8 consecutive lanes = one pixel's 128 bytes: full coalescing; without the rotation a fragment
-// read would hit 4-way bank conflicts, with a pixel-minor layout every lane of a DMA would touch a different line and the
-// instruction takes 320 instead of 140 cycles to issue).  A fragment read (16 consecutive pixels of one k-group) touches
-// 16 different 16-byte bank groups in each of the hardware's ds_read_b128 lane groups (MI355X_MICROARCH.md): conflict-free.
-// Lane addresses come from 2 x 8 per-wave tables (one per residue of the window offset mod 8) plus immediates.
-// Flavours (template arguments): BNB = 64 (2 channel groups x 4 row-waves) / 32 (1 x 8 row-waves); HAS2 = the block's 1x1
-// shortcut input as extra one-tap K-chunks; FUSE = up_convs.2 with the fused `output` projection (fp32 NCHW result);
-// DUAL = conv1 + skip convolution of the first residual block from one 64-channel operand image.
+// What the phase timeline of that kernel showed (tools/build_tl.sh): inside a kernel column its two consumer waves per SIMD
+// keep the matrix pipe 96 % busy, but everything BETWEEN columns - draining the LDS queue, the release with its returned
+// rank, the poll of the next column's counter, the first fragment reads - is exposed, because both waves of a SIMD reach
+// those points together: 2.4 k of 11 k ticks per step (6.9 k = the MFMAs back to back).  tools/micro/cons_loop.hip: the
+// fragment reads + MFMAs alone run at 92 % of the MFMA rate in either structure.  So here a SIMD has one consumer wave
+// with twice the register tile (8 rows x 32 channels; 4 rows for the 32-channel / dual flavours) and nothing is ever
+// waited for where it is issued:
+//   * window fragments run PF rows ahead of their MFMAs through a register ring, across column and step boundaries;
+//   * the weight fragments of column j + 1 replace those of column j row by row under its tail (as before);
+//   * a counter is PEEKED two row groups before it is needed (plain LDS load, no wait) and only checked then;
+//   * releases are relaxed LDS atomics without return: the LDS executes a wave's operations in order, so an add issued
+//     after the fragment reads is performed after them - no lgkmcnt(0) drain anywhere in the steady state.
+// Fragment reads per MFMA drop from 0.33 to 0.22 on the way (8-row tile).  Block = 4 consumer + 4 mover waves (512 threads,
+// 256 registers per lane).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -31,6 +22,7 @@
 #include "mfma_policy.h"
 
 namespace {
+
 
 __device__ __forceinline__ void sp_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void sp_barrier() {
@@ -53,7 +45,7 @@ __device__ __forceinline__ void sp_wait_vm(int n) {
 }
 
 #ifdef DRS_SP_TIMELINE
-__device__ unsigned long long drs_sp_tl[48];
+__device__ unsigned long long drs_sp1_tl[48];
 #define SP_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl[i] += t_ - tl_last; tl_last = t_; } while (0)
 #else
 #define SP_STAMP(i) do { } while (0)
@@ -75,18 +67,24 @@ __device__ __forceinline__ void sp_poll(sp_flag_ptr f, unsigned target) {
 __device__ __forceinline__ void sp_bump(sp_flag_ptr f) {
   __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// consumer release of a ring slot + instruction priority for what follows.  The two consumer waves of a SIMD share its
-// matrix pipe and the hardware arbitrates "oldest first": left alone, the older wave runs a column at full speed while the
-// younger one crawls, then blocks one step ahead at the ring and idles while the younger one runs ALONE (LDS latencies
-// exposed: 63 % pipe occupancy measured).  The counter value returned by the release tells how many of the 8 consumers
-// were here before this wave: the second half to arrive (the waves that are behind) raise their priority, the first half
-// lower it, so the partners stay within a column of each other and one multiplies while the other waits for fragments.
-__device__ __forceinline__ void sp_bump_prio(sp_flag_ptr f, unsigned step_base, int lane) {
-  unsigned old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  const unsigned rank = (unsigned)__builtin_amdgcn_readfirstlane((int)old) - step_base;
-  if (rank >= 4) __builtin_amdgcn_s_setprio(2);
-  else __builtin_amdgcn_s_setprio(0);
+// relaxed forms for the consumers (see the header): peek = issue the counter load, no wait; release = add without return
+#ifdef DRS_SP_TIMELINE
+#define SP_FREE sp_free_run    // timing experiments (DRS_DEBUG_FLAGS & 16): counters ignored, results wrong
+#define SP_MUTE sp_mute        // ... & 32: the consumers do not even touch the counters
+#else
+#define SP_FREE false
+#define SP_MUTE false
+#endif
+__device__ __forceinline__ unsigned sp_peek(sp_flag_ptr f) {
+  return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void sp_check(sp_flag_ptr f, unsigned peeked, unsigned target) {
+  if ((unsigned)__builtin_amdgcn_readfirstlane((int)peeked) < target) sp_poll(f, target);
+  asm volatile("" ::: "memory");  // the fragment reads it guards stay behind it
+}
+__device__ __forceinline__ void sp_release(sp_flag_ptr f, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <int BNB_>
@@ -100,14 +98,15 @@ struct SpGeom {
 };
 
 template <bool HAS2, int BNB_, bool FUSE, bool DUAL>
-__global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom g) {
+__global__ __launch_bounds__(512, 1) void tapconv_sp1_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   using G = SpGeom<BNB_>;
   constexpr int KC = 32, IW = G::IW, NBLK = G::NBLK, WBUF = G::WBUF, W_IMAGE = G::W_IMAGE, BNB = G::BNB;
   constexpr int NT = DUAL ? 4 : 2, BN = 32, TH = 16, TW = 16;
-  constexpr int NRW = DUAL ? 8 : 8 * BN / BNB;  // row-waves per channel group: 4 (64 channels per block) or 8 (32, dual)
-  constexpr int RPW = TH / NRW;                  // patch rows per consumer wave: 4 or 2
+  constexpr int NCONS = 4;                                // consumer waves (one per SIMD); waves 4..7 are the movers
+  constexpr int NRW = (BNB == 64 && !DUAL) ? 2 : 4;       // row-waves per channel group
+  constexpr int RPW = TH / NRW;                            // patch rows per consumer wave: 8 or 4
   char* sWin = smem;                             // [buffer 2][window pixel][rotated operand slot 8] x 16 bytes
   char* sW = smem + 2 * WBUF;                    // [image][kx(3)][ky(3)][k-group(4)][BNB] operand slots
   // ten monotonic counters, no barrier inside the step loop (the waves of a SIMD drift to complementary phases: one
@@ -117,9 +116,12 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
   sp_flag_ptr sWL = sCR + 6;                          // WL[2]: mover waves whose part of window buffer b has landed
   sp_flag_ptr sWR = sCR + 8;                          // WR[2]: consumer waves that have finished reading window buffer b
 
+#ifdef DRS_SP_TIMELINE
+  const bool sp_free_run = (g.debug & 16) != 0, sp_mute = (g.debug & 32) != 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 consumers, 8..11 movers
-  const bool mover = wid >= 8;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3 consumers, 4..7 movers
+  const bool mover = wid >= NCONS;
   const int lr = lane & 15, kg = lane >> 4;
 
   // persistent blocks, XCD-aware item order (see tapconv_mfma_kernel)
@@ -171,10 +173,12 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
     //                 read -> CR2 -> MFMA -> WR[k&1] -> epilogue of the item
     // Every wait is for an event whose own prerequisites lie strictly earlier in this order: no cycle.  Counters are
     // bumped with release semantics after the ds_writes have completed (lgkmcnt(0)).
-    const int pw = wid - 8;
-    // The movers issue few instructions, each of which gates thousands of MFMA cycles: top priority on their SIMDs (they
-    // are the youngest waves there and would otherwise only get the issue slots the two MFMA streams leave over).
-    __builtin_amdgcn_s_setprio(3);
+    const int pw = wid - NCONS;
+    // Default priority: with one consumer wave per SIMD the movers get the issue slots they need between two MFMAs; raised
+    // priority (what the two-consumer kernel needs) costs the consumer 0.9 k ticks per step here.
+#ifdef DRS_SP_TIMELINE
+    if (g.debug & 8) __builtin_amdgcn_s_setprio(3);
+#endif
     const char* wg = reinterpret_cast<const char*>(d.w);
     const size_t w_chunk = (size_t)9 * 4 * wcout * 16;
     const size_t w_gimage = DUAL ? 2 * (size_t)g.w_gimage : (size_t)g.w_gimage;  // (the geometry was sized for d.Cout channels)
@@ -297,13 +301,13 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
       load_col(1);
       SP_STAMP(0);
       // ---- stores, each as soon as its destination is free and its loads have landed (in-order vector-memory counter) ----
-      if (k >= 1) sp_poll(sCR, 8u * (unsigned)k);
+      if (k >= 1) if (!SP_FREE) sp_poll(sCR, (unsigned)NCONS * (unsigned)k);
       SP_STAMP(1);
       sp_wait_vm(nwin + np[1]);
       store_col(0);
       load_col(2);  // into column 0's registers; needed two thirds of a step from now
       SP_STAMP(2);
-      if (k >= 2) sp_poll(sWR + (k & 1), 8u * (unsigned)(k >> 1));
+      if (k >= 2) if (!SP_FREE) sp_poll(sWR + (k & 1), (unsigned)NCONS * (unsigned)(k >> 1));
       sp_wait_vm(np[1] + np[2]);
       {
         char* buf = sWin + (k & 1) * WBUF + lane * 16;
@@ -314,11 +318,11 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
         if (lane == 0) sp_bump(sWL + (k & 1));
       }
       SP_STAMP(3);
-      if (k >= 1) sp_poll(sCR + 1, 8u * (unsigned)k);
+      if (k >= 1) if (!SP_FREE) sp_poll(sCR + 1, (unsigned)NCONS * (unsigned)k);
       SP_STAMP(4);
       sp_wait_vm(np[2]);
       store_col(1);
-      if (k >= 1) sp_poll(sCR + 2, 8u * (unsigned)k);
+      if (k >= 1) if (!SP_FREE) sp_poll(sCR + 2, (unsigned)NCONS * (unsigned)k);
       SP_STAMP(5);
       sp_wait_vm(0);
       store_col(2);
@@ -326,8 +330,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
     }
   } else {
     // ===================== consumers =====================
-    const int rw = (BNB == 64 && !DUAL) ? (wid & 3) : (wid & 7);  // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
-    const int ng = (BNB == 64 && !DUAL) ? ((wid >> 2) & 1) : 0;   // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
+    const int rw = NRW == 2 ? (wid & 1) : (wid & 3);  // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
+    const int ng = NRW == 2 ? (wid >> 1) : 0;         // channel group: channels [ng*BN, ng*BN + BN) of the block's BNB
     // fragment addresses: window pixel p = B + q + lr with B = rw*RPW*18 (per wave) and q = wr*18 + kx (compile time);
     // slot address = p * 128 + ((c + p) & 7) * 16, c = image * 4 + k-group.  The rotation depends on q only through q & 7:
     // one lane table per residue (hi and lo image), the rest (q * 128) is an immediate.
@@ -340,49 +344,20 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
       tab_lo[j] = (B + lr) * 128 + (rot ^ 4) * 16;
     }
     const char* wbase = sW + ((size_t)kg * BNB + ng * NT * 16 + lr) * 16;  // this lane's weight origin
+    constexpr int NWR = RPW + 2;             // window rows of a column
+    constexpr int NB = RPW == 8 ? 5 : 3;     // fragment ring (NWR % NB == 0: the ring phase is the same in every column)
+    constexpr int PF = RPW == 8 ? 3 : 2;     // rows the window fragments run ahead of their MFMAs
+    static_assert(NWR % NB == 0 && PF < NB && PF + 2 <= NWR - 1, "ring geometry");
     f32x4 acc[RPW][NT];
-    typename P::Frag wf[3][NT];
-    auto read_wf = [&](int col) __attribute__((always_inline)) {
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-          wf[ky][t] = P::load(wbase, W_IMAGE, (size_t)(((col * 3 + ky) * 4 * BNB) + t * 16) * 16);
+    typename P::Frag wf[3][NT], af[NB];
+    auto w_frag = [&](int col, int ky, int t) __attribute__((always_inline)) {
+      return P::load(wbase, W_IMAGE, (size_t)(((col * 3 + ky) * 4 * BNB) + t * 16) * 16);
     };
     auto win_frag = [&](const char* buf, int q) __attribute__((always_inline)) {  // q: compile-time window offset
       return typename P::Frag{*reinterpret_cast<const bf16x8*>(buf + tab_hi[q & 7] + q * 128),
                               *reinterpret_cast<const bf16x8*>(buf + tab_lo[q & 7] + q * 128)};
     };
-    // MFMAs of kernel column `col`.  PRE: the weight fragments of column col + 1 are read into wf[ky] as soon as the last
-    // window row that needs the old wf[ky] has been issued (row ky + RPW - 1), behind a poll of that column's "landed"
-    // counter: the fragment-read latency of the next column hides under the tail of this one.
-    auto mma_col = [&](const char* buf, int col, bool pre, unsigned ltarget) __attribute__((always_inline)) {
-#pragma unroll
-      for (int wr = 0; wr < RPW + 2; ++wr) {
-        const typename P::Frag af = win_frag(buf, wr * IW + col);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int r = wr - ky;
-          if (r >= 0 && r < RPW) {
-#ifdef DRS_SP_TIMELINE
-            if (g.debug & 4) continue;
-#endif
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[ky][t], af, acc[r][t]);
-          }
-        }
-        if (pre) {
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
-            if (wr == ky + RPW - 1) {
-              if (ky == 0) sp_poll(sCL + col + 1, ltarget);
-#pragma unroll
-              for (int t = 0; t < NT; ++t)
-                wf[ky][t] = P::load(wbase, W_IMAGE, (size_t)((((col + 1) * 3 + ky) * 4 * BNB) + t * 16) * 16);
-            }
-        }
-      }
-    };
+    bool primed = false;  // column 0's weight fragments and the first PF window rows of this step are already in registers
     for (int k = 0; k < S; ++k) {
       if (++c == nck) c = 0;
       if (c == 0) {
@@ -394,47 +369,104 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
       }
       const bool second = HAS2 && c >= g.nchunks;
       const char* buf = sWin + (k & 1) * WBUF;
+      const char* nbuf = sWin + ((k + 1) & 1) * WBUF;
       const unsigned ltarget = 4u * (unsigned)(k + 1);  // four movers per column and step
       SP_STAMP(7);
-      sp_poll(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1));  // window k is in its buffer
-      sp_poll(sCL, ltarget);                                   // ... and weight column 0 of k
-      SP_STAMP(0);
-      read_wf(0);
-      sp_wait_lds();
-      sp_bump_prio(sCR, 8u * (unsigned)k, lane);  // column 0 is in registers: its ring slot may be refilled
-      SP_STAMP(1);
-      if (second) {  // second input: one tap, window origin; columns 1 and 2 are empty
+      if (second) {
+        // second input (1x1 shortcut): one tap at the window origin, columns 1 and 2 are empty.  Short and rare: not pipelined.
+        if (!SP_FREE) sp_poll(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1));
+        if (!SP_FREE) sp_poll(sCL, ltarget);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wf[0][t] = w_frag(0, 0, t);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-          const typename P::Frag af = win_frag(buf, r * IW);
+          const typename P::Frag a = win_frag(buf, r * IW);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[0][t], af, acc[r][t]);
+          for (int t = 0; t < NT; ++t) acc[r][t] = P::mma(wf[0][t], a, acc[r][t]);
         }
-        sp_wait_lds();
-        if (lane == 0) {
-          sp_bump(sCR + 1);
-          sp_bump(sCR + 2);
-          sp_bump(sWR + (k & 1));
-        }
+        if (!SP_MUTE) sp_release(sCR, lane);
+        if (!SP_MUTE) sp_release(sCR + 1, lane);
+        if (!SP_MUTE) sp_release(sCR + 2, lane);
+        if (!SP_MUTE) sp_release(sWR + (k & 1), lane);
+        primed = false;
       } else {
-        mma_col(buf, 0, true, ltarget);  // ... and the fragments of column 1 under its tail
-        SP_STAMP(2);
-        sp_wait_lds();
-        sp_bump_prio(sCR + 1, 8u * (unsigned)k, lane);
-        SP_STAMP(3);
-        mma_col(buf, 1, true, ltarget);  // ... and of column 2
-        SP_STAMP(4);
-        sp_wait_lds();
-        sp_bump_prio(sCR + 2, 8u * (unsigned)k, lane);
-        SP_STAMP(5);
-        mma_col(buf, 2, false, 0u);
-        sp_wait_lds();  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
-        if (lane == 0) sp_bump(sWR + (k & 1));
-        SP_STAMP(6);
-      }
+        // is step k + 1 one this step can prime (a 3x3 step of this block)?
+        const int c1 = c + 1 == nck ? 0 : c + 1;
+        const bool nreg = k + 1 < S && !(HAS2 && c1 >= g.nchunks);
+        if (!primed) {
+          if (!SP_FREE) sp_poll(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1));  // window k is in its buffer
+          if (!SP_FREE) sp_poll(sCL, ltarget);                                   // ... and weight column 0 of k
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[ky][t] = w_frag(0, ky, t);
+#pragma unroll
+          for (int i = 0; i < PF; ++i) af[i] = win_frag(buf, i * IW);
+        }
+        SP_STAMP(0);
+        unsigned peek_w = 0, peek_c = 0;
+#pragma unroll
+        for (int col = 0; col < 3; ++col) {
+#pragma unroll
+          for (int wr = 0; wr < NWR; ++wr) {
+            // ---- (a) window row PF groups ahead: this column, the next one, or column 0 of the next step ----
+            {
+              const int pr = wr + PF;
+              if (pr < NWR) {
+                af[pr % NB] = win_frag(buf, pr * IW + col);
+              } else if (col < 2) {
+                af[pr % NB] = win_frag(buf, (pr - NWR) * IW + col + 1);
+              } else if (nreg) {
+                if (pr == NWR) if (!SP_FREE) sp_check(sWL + ((k + 1) & 1), peek_w, 4u * (unsigned)(((k + 1) >> 1) + 1));
+                af[pr % NB] = win_frag(nbuf, (pr - NWR) * IW);
+              }
+              // the last fragment read of this window buffer has been issued: the buffer may be refilled (for step k + 2)
+              if (col == 2 && pr == NWR - 1) if (!SP_MUTE) sp_release(sWR + (k & 1), lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- (b) MFMAs of this window row: term-major over its (up to) 3 * NT accumulators ----
+            {
+              const typename P::Frag a = af[wr % NB];
 #ifdef DRS_SP_TIMELINE
-      if (c == nck - 1 && (g.debug & 64)) continue;  // timing experiment: no epilogue
+              if (!(g.debug & 4))
 #endif
+#pragma unroll
+              for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                  const int r = wr - ky;
+                  if (r >= 0 && r < RPW) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                      acc[r][t] = term == 0   ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][t].lo, a.hi, acc[r][t], 0, 0, 0)
+                                  : term == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][t].hi, a.lo, acc[r][t], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][t].hi, a.hi, acc[r][t], 0, 0, 0);
+                  }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- (c) counters and the next column's weight fragments ----
+            // all three kernel rows of this column are in registers once row 2 has used wf[2]: release its ring slot
+            if (wr == 2) if (!SP_MUTE) sp_release(sCR + col, lane);
+            if (col < 2 || nreg) {
+              sp_flag_ptr ncl = sCL + (col == 2 ? 0 : col + 1);
+              const unsigned ntarget = col == 2 ? ltarget + 4u : ltarget;
+              if (wr == RPW - 3) peek_c = SP_MUTE ? 0u : sp_peek(ncl);
+              if (wr == RPW - 1) if (!SP_FREE) sp_check(ncl, peek_c, ntarget);
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky)
+                if (wr == ky + RPW - 1) {  // row ky + RPW - 1 was the last user of wf[ky]
+#pragma unroll
+                  for (int t = 0; t < NT; ++t) wf[ky][t] = w_frag(col == 2 ? 0 : col + 1, ky, t);
+                }
+            }
+            if (col == 2 && nreg && wr == NWR - PF - 2) peek_w = SP_MUTE ? 0u : sp_peek(sWL + ((k + 1) & 1));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        primed = nreg;
+        SP_STAMP(1);
+      }
       if (c == nck - 1) {
         // opaque copies of the lane coordinates: everything the epilogue derives from them is computed here, not hoisted
         // out of the step loop (where it would be spilled and reloaded between the stores)
@@ -461,29 +493,22 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
           fuse_epilogue_mfma<RPW>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e);
         else
           tile_epilogue_sp<RPW, NT, true>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
+        SP_STAMP(2);
       }
     }
   }
 #ifdef DRS_SP_TIMELINE
-  if (blockIdx.x == 0 && (wid == 0 || wid == 4 || wid == 8) && lane == 0) {
-    for (int i = 0; i < 8; ++i) drs_sp_tl[(wid == 0 ? 0 : (wid == 4 ? 32 : 16)) + i] = tl[i];
-    drs_sp_tl[wid == 0 ? 8 : (wid == 4 ? 40 : 24)] = S;
-    if (wid == 0) drs_sp_tl[9] = __builtin_amdgcn_s_memtime() - tl_begin;
+  if (blockIdx.x == 0 && (wid == 0 || wid == NCONS) && lane == 0) {
+    for (int i = 0; i < 8; ++i) drs_sp1_tl[(wid == 0 ? 0 : 16) + i] = tl[i];
+    drs_sp1_tl[wid == 0 ? 8 : 24] = S;
+    if (wid == 0) drs_sp1_tl[9] = __builtin_amdgcn_s_memtime() - tl_begin;
   }
-
 #endif
 }
 
-bool sp_std3x3(const TapConv& d) {
-  if (d.mode != 0 || d.ntaps != 9 || d.wtaps_total != 9 || d.in_stride != 1 || d.out_scale != 1) return false;
-  for (int i = 0; i < 9; ++i)
-    if (d.dy[i] != i / 3 - 1 || d.dx[i] != i % 3 - 1 || d.wtap[i] != i) return false;
-  return true;
-}
-
 template <bool HAS2, int BNB, bool FUSE = false, bool DUAL = false>
-int sp_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
-  auto kern = tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL>;
+int sp1_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
+  auto kern = tapconv_sp1_kernel<HAS2, BNB, FUSE, DUAL>;
   constexpr size_t kLds = SpGeom<BNB>::LDS;
   static_assert(kLds <= 160 * 1024, "LDS budget");
   int num_cu = 0;
@@ -492,13 +517,10 @@ int sp_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
     if (rc) return rc;
   }
   const long long nitems = (long long)d.N * g.tiles_x * g.tiles_y * (DUAL ? 1 : d.Cout / BNB);
-  long long blocks = num_cu;  // one 12-wave block per CU
-#ifdef DRS_SP_TIMELINE
-  if (getenv("DRS_SP_MAXBLOCKS")) blocks = atoi(getenv("DRS_SP_MAXBLOCKS"));  // experiment: fewer CUs
-#endif
+  long long blocks = num_cu;  // one 8-wave block per CU
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), kLds, s, d, g);
   DRS_CHECK_HIP(hipGetLastError());
 #ifdef DRS_SP_TIMELINE
   {
@@ -507,19 +529,16 @@ int sp_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
     float ms = 0.f;
     DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
     DRS_CHECK_HIP(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);  // timed repeat (same result)
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), kLds, s, d, g);  // timed repeat (same result)
     DRS_CHECK_HIP(hipEventRecord(e1, s));
     DRS_CHECK_HIP(hipStreamSynchronize(s));
     DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    DRS_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(drs_sp_tl), sizeof(h)));
+    DRS_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(drs_sp1_tl), sizeof(h)));
     const double sc = h[8] ? 1.0 / (double)h[8] : 0.0;
-    fprintf(stderr, "sp kernel Cin=%d Cout=%d TH=%d in2=%d BNB=%d fuse=%d dual=%d: %.1f us, %llu steps/block, wave0 alive %llu ticks = %.2f GHz, %.0f ticks/step\n",
+    fprintf(stderr, "sp1 kernel Cin=%d Cout=%d TH=%d in2=%d BNB=%d fuse=%d dual=%d: %.1f us, %llu steps/block, wave0 alive %llu ticks = %.2f GHz, %.0f ticks/step\n",
             d.Cin, d.Cout, d.TH, d.in2 ? d.Cin2 : 0, BNB, (int)FUSE, (int)DUAL, ms * 1e3, h[8], h[9], h[9] / (ms * 1e6), h[9] * sc);
-    fprintf(stderr, "   C0: epi>Y %.0f Y %.0f rd0 %.0f col0 %.0f L1+rd1 %.0f col1 %.0f L2+rd2 %.0f col2 %.0f\n", h[7] * sc, h[0] * sc, h[1] * sc,
-            h[2] * sc, h[3] * sc, h[4] * sc, h[5] * sc, h[6] * sc);
-    fprintf(stderr, "   C4: epi>Y %.0f Y %.0f rd0 %.0f col0 %.0f L1+rd1 %.0f col1 %.0f L2+rd2 %.0f col2 %.0f\n", h[39] * sc, h[32] * sc, h[33] * sc,
-            h[34] * sc, h[35] * sc, h[36] * sc, h[37] * sc, h[38] * sc);
+    fprintf(stderr, "   C : top %.0f prime %.0f columns %.0f epilogue %.0f\n", h[7] * sc, h[0] * sc, h[1] * sc, h[2] * sc);
     fprintf(stderr, "   M : loads %.0f CR0poll %.0f col0 %.0f WR+win %.0f CR1poll %.0f col1+CR2poll %.0f col2 %.0f\n", (h[23] + h[16]) * sc,
             h[17] * sc, h[18] * sc, h[19] * sc, h[20] * sc, h[21] * sc, h[22] * sc);
   }
@@ -529,32 +548,11 @@ int sp_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 
 }  // namespace
 
-// Eligibility: 3x3 stride 1 on 16-row patches, SP-format input(s), SP-format output (or the fused fp32 projection).
-// DRS_SPK=0 sends these layers to the lock-step kernel (tapconv_mfma_kernel<.., SP>).
-bool drs_tapconv_sp_supported(const TapConv& d, int impl) {
-  static const int env = getenv("DRS_SPK") ? atoi(getenv("DRS_SPK")) : 1;
-  if (!env || impl != DRS_IMPL_MFMA_BF16X3) return false;
-  if (!d.in || !d.in_sp || !sp_std3x3(d) || !d.zero_line) return false;
-  if (d.gate || d.in_add || d.res || d.sigmoid || d.out_nchw || d.TH <= 8) return false;
-  if ((d.in_co & 31) || !(d.in_cs == 16 || (d.in_cs & 31) == 0)) return false;
-  if (!(d.Cin % 32 == 0 || (d.Cin == 16 && d.in_cs == 16))) return false;
-  if (d.dual)
-    return d.Cout == 32 && !d.in2 && !d.fuse_out && !d.out2 && d.bias && d.out && d.out_sp && !(d.out_co & 31) && !(d.out_cs & 31);
-  if (d.Cout % 32 != 0) return false;
-  if (d.in2 && (!d.in2_sp || !d.w2 || (d.in2_co & 31) || !(d.in2_cs == 16 || (d.in2_cs & 31) == 0) ||
-                !(d.Cin2 % 32 == 0 || (d.Cin2 == 16 && d.in2_cs == 16)) || d.H2 != d.TH || d.W2 != d.TW))
-    return false;
-  if (d.fuse_out) return d.Cout == 32 && !d.in2 && !d.out2 && !d.out_sp && d.fuse_dim <= 4 && !d.post_add && !d.relu_pre && !d.relu_post;
-  if (!d.out || !d.out_sp || (d.out_co & 31) || (d.out_cs & 31)) return false;
-  if (d.out2 && (!d.post2 || (d.out2_co & 31) || (d.out2_cs & 31) || (d.post2_cs & 3))) return false;
-  if (d.post_add && (d.post_cs & 3)) return false;
-  return true;
-}
-
-int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
-  DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_sp: geometry");
-  if (d.dual) return sp_launch<false, 64, false, true>(d, g, s);
-  if (d.fuse_out) return sp_launch<false, 32, true>(d, g, s);
-  if (d.Cout % 64 == 0) return d.in2 ? sp_launch<true, 64>(d, g, s) : sp_launch<false, 64>(d, g, s);
-  return d.in2 ? sp_launch<true, 32>(d, g, s) : sp_launch<false, 32>(d, g, s);
+// Same eligibility as tapconv_sp_kernel (drs_tapconv_sp_supported, conv_mfma_sp.hip).
+int drs_launch_tapconv_sp1(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
+  DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_sp1: geometry");
+  DRS_REQUIRE(!d.dual, DRS_ERR_SHAPE, "tapconv_sp1: the dual flavour stays on tapconv_sp_kernel (registers)");
+  if (d.fuse_out) return sp1_launch<false, 32, true>(d, g, s);
+  if (d.Cout % 64 == 0) return d.in2 ? sp1_launch<true, 64>(d, g, s) : sp1_launch<false, 64>(d, g, s);
+  return d.in2 ? sp1_launch<true, 32>(d, g, s) : sp1_launch<false, 32>(d, g, s);
 }

@@ -839,7 +839,9 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   static const int concurrent_env = getenv("DRS_CONCURRENT") ? atoi(getenv("DRS_CONCURRENT")) : -1;
   const bool concurrent = (concurrent_env < 0 ? !plan->sp : concurrent_env != 0) && !train && !plan->profiling &&
                           c.impl != DRS_IMPL_DIRECT;
-  if (concurrent && !plan->side) {
+  // the time MLPs (one small latency-bound launch) run next to conv0 in every eval plan unless DRS_CONCURRENT=0
+  const bool mlp_side = concurrent_env != 0 && !train && !plan->profiling && c.impl != DRS_IMPL_DIRECT;
+  if ((concurrent || mlp_side) && !plan->side) {
     DRS_CHECK_HIP(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
     DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
     DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
@@ -850,7 +852,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   const float* inv_freq = (const float*)(pk + plan->o_inv_freq);
   // (eval: on the side stream, next to the conditioning branch / conv0; the first consumer is block 0's conv1)
   hipStream_t st_mlp = s;
-  if (concurrent) {
+  if (mlp_side) {
     st_mlp = plan->side;
     DRS_CHECK_HIP(hipEventRecord(plan->ev_fork, s));  // t / labels were produced on the caller's stream
     DRS_CHECK_HIP(hipStreamWaitEvent(st_mlp, plan->ev_fork, 0));
@@ -860,7 +862,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                                 temb, plan->temb_total, B, 100, labels ? (const float*)(pk + plan->o_label) : nullptr,
                                 (const long long*)labels, label_batch, plan->cfg.num_classes, st_mlp));
   prof_end(plan, s);
-  if (concurrent) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, st_mlp));
+  if (mlp_side) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, st_mlp));
 
   // --- LR conditioning branch: RRDB -> bicubic -> conv (reference :345-353), constant per sampling chain ---
   if (has_cond && !reuse_cond) {
@@ -903,7 +905,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                       has_cond ? TP(plan->t_cond) : nullptr, Bl, TP(plan->t_x0), B, C, kDown[0], H, W, s, plan->sp ? 1 : 0));
   prof_end(plan, s);
 
-  if (concurrent) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));  // time embeddings are ready
+  if (mlp_side) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));  // time embeddings are ready
 
   // --- encoder + bottleneck: ResConvBlock (reference :153-172), downs (:366) ---
   const float* xin = TP(plan->t_x0);
@@ -971,7 +973,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     if (i < 3) {
       TapConv d = conv_desc(TP(plan->t_R[i]), B, hh, ww, co, co, 0, PW(plan->downs[i]), PB(plan->downs[i]),
                             TP(plan->t_D[i]), co, co, 0, 3, 3, 2, 1);
-      d.in_sp = d.out_sp = sp;
+      d.in_sp = d.out_sp = sp; d.zero_line = zero_line;
       RUN(plan_conv(plan, plan->downs[i], d, s));
       xin = TP(plan->t_D[i]);
     }

@@ -1,0 +1,196 @@
+// Micro-benchmark: the CONSUMER side of the SP 3x3 kernel in isolation (no movers, no counters, static LDS contents):
+// fragment reads + split-bf16 MFMAs of one 16x16-pixel x 64-channel patch per block and 32-channel step, LDS images laid
+// out exactly like conv_mfma_sp.hip (rotated pixel-major window, [image][col][ky][k-group][64 channels] weights).
+//   V0: 8 waves (2 per SIMD), 4 rows x 32 channels each: the structure of the shipped kernel (compiler-scheduled)
+//   V1: 4 waves (1 per SIMD), 8 rows x 32 channels each, window fragments prefetched PF rows ahead through a 5-slot
+//       register ring, weight fragments of the next column under the tail of the current one, order pinned by
+//       sched_barrier
+// Prints ticks per step (6912 = the 432 MFMAs of a SIMD back to back).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct Frag { bf16x8 hi, lo; };
+constexpr int IW = 18, WBUF = 41 * 1024, W_IMAGE = 9 * 4 * 64 * 16, BNB = 64;
+
+__device__ __forceinline__ f32x4 mm(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+template <int VARIANT, int PF>
+__global__ __launch_bounds__(VARIANT == 0 ? 512 : 256, 1) void cons(float* out, int steps, unsigned long long* ticks, int data) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sWin = smem;
+  char* sW = smem + 2 * WBUF;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kg = lane >> 4;
+  for (int i = tid; i < (2 * WBUF + 2 * W_IMAGE) / 4; i += blockDim.x)
+  {
+    // bf16 pairs: DATA = 0: nearly constant bit patterns; DATA = 1: random sign / mantissa, exponents 2^-4 .. 2^3 (what real
+    // activations look like to the multipliers: switching activity sets the power, power sets clock AND issue throttling)
+    unsigned h = (unsigned)i * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const unsigned rnd = (h & 0x807f807fu) | ((0x7bu + ((h >> 8) & 7u)) << 7) | ((0x7bu + ((h >> 24) & 7u)) << 23);
+    reinterpret_cast<unsigned*>(smem)[i] = data ? rnd : 0x3c003c00u + ((i * 2654435761u) >> 20 & 0x00ff00ffu);
+  }
+  __syncthreads();
+  constexpr int RPW = VARIANT == 0 ? 4 : 8;
+  const int rw = VARIANT == 0 ? (wid & 3) : (wid & 1);
+  const int ng = VARIANT == 0 ? (wid >> 2) : (wid >> 1);
+  const int B = rw * RPW * IW;
+  int tab_hi[8], tab_lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int rot = (kg + B + j + lr) & 7;
+    tab_hi[j] = (B + lr) * 128 + rot * 16;
+    tab_lo[j] = (B + lr) * 128 + (rot ^ 4) * 16;
+  }
+  const char* wbase = sW + ((size_t)kg * BNB + ng * 32 + lr) * 16;
+  f32x4 acc[RPW][2];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto win_frag = [&](const char* buf, int q) __attribute__((always_inline)) {
+    return Frag{*reinterpret_cast<const bf16x8*>(buf + tab_hi[q & 7] + q * 128),
+                *reinterpret_cast<const bf16x8*>(buf + tab_lo[q & 7] + q * 128)};
+  };
+  auto w_frag = [&](int col, int ky, int t) __attribute__((always_inline)) {
+    const size_t off = (size_t)(((col * 3 + ky) * 4 * BNB) + t * 16) * 16;
+    return Frag{*reinterpret_cast<const bf16x8*>(wbase + off), *reinterpret_cast<const bf16x8*>(wbase + W_IMAGE + off)};
+  };
+  Frag wf[3][2];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if constexpr (VARIANT == 0) {
+    for (int k = 0; k < steps; ++k) {
+      const char* buf = sWin + (k & 1) * WBUF;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wf[ky][t] = w_frag(0, ky, t);
+#pragma unroll
+      for (int col = 0; col < 3; ++col) {
+#pragma unroll
+        for (int wr = 0; wr < RPW + 2; ++wr) {
+          const Frag af = win_frag(buf, wr * IW + col);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int r = wr - ky;
+            if (r >= 0 && r < RPW) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                acc[r][t] = mm(wf[ky][t].lo, af.hi, acc[r][t]);
+                acc[r][t] = mm(wf[ky][t].hi, af.lo, acc[r][t]);
+                acc[r][t] = mm(wf[ky][t].hi, af.hi, acc[r][t]);
+              }
+            }
+          }
+          if (col < 2) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+              if (wr == ky + RPW - 1) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wf[ky][t] = w_frag(col + 1, ky, t);
+              }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (stands for the release of the ring slot)
+      }
+    }
+  } else {
+    // software pipeline over the 30 (column, window row) groups of a step; the ring and the weight registers carry over
+    // from one step to the next
+    Frag af[5];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wf[ky][t] = w_frag(0, ky, t);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) af[i] = win_frag(sWin, i * IW);
+    for (int k = 0; k < steps; ++k) {
+      const char* buf = sWin + (k & 1) * WBUF;
+      const char* nbuf = sWin + ((k + 1) & 1) * WBUF;
+#pragma unroll
+      for (int col = 0; col < 3; ++col) {
+#pragma unroll
+        for (int wr = 0; wr < 10; ++wr) {
+          // prefetch the window row PF groups ahead
+          {
+            const int pr = wr + PF;
+            if (pr < 10) af[pr % 5] = win_frag(buf, pr * IW + col);
+            else if (col < 2) af[pr % 5] = win_frag(buf, (pr - 10) * IW + col + 1);
+            else af[pr % 5] = win_frag(nbuf, (pr - 10) * IW);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const Frag a = af[wr % 5];
+          // term-major over the (up to) six accumulators of this window row: no back-to-back dependent MFMAs
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              const int r = wr - ky;
+              if (r >= 0 && r < 8) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                  acc[r][t] = term == 0 ? mm(wf[ky][t].lo, a.hi, acc[r][t])
+                            : term == 1 ? mm(wf[ky][t].hi, a.lo, acc[r][t]) : mm(wf[ky][t].hi, a.hi, acc[r][t]);
+              }
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          // weight fragments of the next column as soon as row ky + 7 (the last user of wf[ky]) has been issued
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+            if (wr == ky + 7) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t) wf[ky][t] = w_frag(col == 2 ? 0 : col + 1, ky, t);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) s += acc[r][t];
+  out[(size_t)blockIdx.x * blockDim.x + tid] = s[0] + s[1] + s[2] + s[3];
+  if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
+template <int V, int PF>
+void run(const char* name, int blocks, int steps, float* out, unsigned long long* ticks, int data) {
+  auto kern = cons<V, PF>;
+  const size_t lds = 2 * WBUF + 2 * W_IMAGE;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(V == 0 ? 512 : 256), lds, 0, out, steps, ticks, data);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  unsigned long long h[256];
+  hipMemcpy(h, ticks, 8 * blocks, hipMemcpyDeviceToHost);
+  double avg = 0;
+  for (int i = 0; i < blocks; ++i) avg += h[i];
+  avg /= blocks;
+  printf("%-28s blocks %3d: %7.0f ticks/step (%.0f %% of the MFMA rate), %.1f us, %.2f GHz, %s\n", name, blocks, avg / steps,
+         100.0 * 6912 * steps / avg, ms * 1e3, avg / (ms * 1e6), hipGetErrorString(hipGetLastError()));
+}
+
+int main() {
+  float* out; unsigned long long* ticks;
+  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&ticks, 8 * 256);
+  const int steps = 64;
+  for (int data : {0, 1})
+    for (int blocks : {8, 256}) {
+      printf("data %d\n", data);
+      run<0, 0>("V0 2 waves/SIMD 4 rows", blocks, steps, out, ticks, data);
+      run<1, 3>("V1 1 wave/SIMD 8 rows PF=3", blocks, steps, out, ticks, data);
+    }
+  return 0;
+}

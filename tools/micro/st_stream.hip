@@ -2,6 +2,7 @@
 // pattern (8 lines of 128 bytes at a pixel stride), as a function of the number of waves storing.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ __launch_bounds__(1024) void st(char* __restrict__ buf, size_t per_wave_bytes, int iters, int stride,
@@ -18,9 +19,9 @@ __global__ __launch_bounds__(1024) void st(char* __restrict__ buf, size_t per_wa
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
-int main() {
-  const int iters = 256;
-  const size_t per_wave = (size_t)iters * 8 * 512;  // room for MODE 1 at stride 512
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 256;  // 16 = the burst of one epilogue (16 KB per wave)
+  const size_t per_wave = (size_t)256 * 8 * 512;  // room for MODE 1 at stride 512
   char* buf; unsigned long long* ticks;
   hipMalloc(&buf, per_wave * 256 * 16); hipMalloc(&ticks, 8 * 1024);
   for (int blocks : {8, 256})
