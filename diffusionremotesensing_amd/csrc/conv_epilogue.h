@@ -266,6 +266,60 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
   }
 }
 
+// The SP wave-specialised kernel's form: the per-item constants (bias, per-image adds) arrive in registers (its mover
+// waves stage them in LDS: a global load at this point would expose a full memory round trip per item on every SIMD),
+// row addresses are advanced instead of recomputed, no gate / residual (that kernel does not take such layers).
+struct SpEpiConst { float bias[8], post[8], post2[8]; };  // this lane's 8 channels: bias (+ bias2), post_add, post2 (zeros if absent)
+template <int RPW, bool OUT2>
+__device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&acc)[RPW][2], const SpEpiConst& k, int n, int cg,
+                                                     int ty0, int tx0, int wave, int lr, int kg) {
+  const bool lo = lr < 8;
+  const int pl = lr & 7;
+  const bool relu_pre = d.relu_pre != 0, relu_post = d.relu_post != 0;
+  const int tyb = ty0 + wave * RPW;
+  const size_t pix0 = ((size_t)n * d.OH + tyb) * d.OW + tx0 + pl;  // (out_scale 1, no phase offset: 3x3 stride 1)
+  const int lane_b = (lo ? 0 : 64) + kg * 16;
+  char* o1 = d.out ? reinterpret_cast<char*>(d.out) + (pix0 * d.out_cs + d.out_co + cg) * 4 + lane_b : nullptr;
+  char* o2 = (OUT2 && d.out2) ? reinterpret_cast<char*>(d.out2) + (pix0 * d.out2_cs + d.out2_co + cg) * 4 + lane_b : nullptr;
+  const size_t row1 = (size_t)d.OW * d.out_cs * 4, row2 = OUT2 ? (size_t)d.OW * d.out2_cs * 4 : 0;
+  const int h1 = 8 * d.out_cs * 4, h2 = OUT2 ? 8 * d.out2_cs * 4 : 0;
+  const bool ok0 = tx0 + pl < d.TW, ok1 = tx0 + pl + 8 < d.TW;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    if (tyb + r < d.TH) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = acc[r][0][j] + k.bias[j]; v[4 + j] = acc[r][1][j] + k.bias[4 + j]; }
+      if (relu_pre) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += k.post[j];
+      if (relu_post) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      auto put = [&](char* g, int hb, const float (&w8)[8]) __attribute__((always_inline)) {
+        u32x4 H, L;
+        drs_sp_split8(w8, H, L);
+        const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo
+        if (ok0) *reinterpret_cast<u32x4*>(g) = lo ? H : got;
+        if (ok1) *reinterpret_cast<u32x4*>(g + hb) = lo ? got : L;
+      };
+      if (o1) put(o1 + r * row1, h1, v);
+      if constexpr (OUT2) {
+        if (o2) {
+          float p2[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p2[j] = v[j] + k.post2[j];
+          put(o2 + r * row2, h2, p2);
+        }
+      }
+    }
+  }
+}
+
 // ---- fused 1x1 projection epilogue (the UNet's `output` conv riding on up_convs.2) ------------------------------
 // Works in MFMA layout: lane (lr, kg) holds channels t*16 + kg*4 .. +3 of pixel lr.  y[j] = fuse_b[j] + sum over the 32
 // channels of (acc + bias) * fuse_w[j][co]: 8 in-lane products, then 2 cross-lane steps over the 4 k-group lanes.
@@ -318,31 +372,21 @@ __device__ __forceinline__ void fuse_epilogue(const TapConv& d, f32x4 (&acc)[RPW
 // fuse_dim are zero), and the result rows 0..3 land in the lanes of k-group 0: no cross-lane reduction, no LDS round trips
 // (the shuffle form costs 8 ds_bpermute per row and was 35 us of up_convs.2's 220).  Same 2^-16 operand rounding as every
 // other product of the split-bf16 path.
+struct FuseEpiConst { float4 b0, b1; float w8[8]; float fb[4]; };  // bias of this lane's 8 channels, fuse_w row lr (same 8), fuse_b
 template <int RPW>
-__device__ __forceinline__ void fuse_epilogue_mfma(const TapConv& d, f32x4 (&acc)[RPW][2], int n, int n0, int ty0, int tx0,
-                                                   int wave, int lr, int kg) {
+__device__ __forceinline__ void fuse_epilogue_mfma_pre(const TapConv& d, f32x4 (&acc)[RPW][2], const FuseEpiConst& k, int n, int n0,
+                                                       int ty0, int tx0, int wave, int lr, int kg) {
   using P = PolicyBF16X3;
-  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-  if (d.bias) {
-    b0 = *reinterpret_cast<const float4*>(d.bias + n0 + kg * 4);
-    b1 = *reinterpret_cast<const float4*>(d.bias + n0 + 16 + kg * 4);
-  }
   typename P::Frag wfr;
   {
     float w8[8];
-    const int m = min(lr, d.fuse_dim - 1);
-    const float4 w0 = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)m * d.Cout + n0 + kg * 4);
-    const float4 w1 = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)m * d.Cout + n0 + 16 + kg * 4);
     const float keep = lr < d.fuse_dim ? 1.f : 0.f;
-    w8[0] = w0.x * keep; w8[1] = w0.y * keep; w8[2] = w0.z * keep; w8[3] = w0.w * keep;
-    w8[4] = w1.x * keep; w8[5] = w1.y * keep; w8[6] = w1.z * keep; w8[7] = w1.w * keep;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w8[j] = k.w8[j] * keep;
     u32x4 h, l;
     drs_sp_split8(w8, h, l);
     wfr = typename P::Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
   }
-  float fb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) fb[j] = d.fuse_b[min(j, d.fuse_dim - 1)];
   const size_t plane = (size_t)d.OH * d.OW;
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
@@ -350,8 +394,8 @@ __device__ __forceinline__ void fuse_epilogue_mfma(const TapConv& d, f32x4 (&acc
     const bool valid = ty < d.TH && tx < d.TW;
     const int oy = min(ty, d.TH - 1) * d.out_scale + d.out_oy, ox = min(tx, d.TW - 1) * d.out_scale + d.out_ox;
     float v[8];
-    v[0] = acc[r][0][0] + b0.x; v[1] = acc[r][0][1] + b0.y; v[2] = acc[r][0][2] + b0.z; v[3] = acc[r][0][3] + b0.w;
-    v[4] = acc[r][1][0] + b1.x; v[5] = acc[r][1][1] + b1.y; v[6] = acc[r][1][2] + b1.z; v[7] = acc[r][1][3] + b1.w;
+    v[0] = acc[r][0][0] + k.b0.x; v[1] = acc[r][0][1] + k.b0.y; v[2] = acc[r][0][2] + k.b0.z; v[3] = acc[r][0][3] + k.b0.w;
+    v[4] = acc[r][1][0] + k.b1.x; v[5] = acc[r][1][1] + k.b1.y; v[6] = acc[r][1][2] + k.b1.z; v[7] = acc[r][1][3] + k.b1.w;
     if (d.out && valid) {  // parity taps only: production runs never store the 32-channel tensor
       float* o = d.out + (((size_t)n * d.OH + oy) * d.OW + ox) * d.out_cs + d.out_co + n0 + kg * 4;
       *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -365,7 +409,24 @@ __device__ __forceinline__ void fuse_epilogue_mfma(const TapConv& d, f32x4 (&acc
       float* o = d.fuse_out + (size_t)n * d.fuse_dim * plane + (size_t)oy * d.OW + ox;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < d.fuse_dim) o[(size_t)j * plane] = y[j] + fb[j];
+        if (j < d.fuse_dim) o[(size_t)j * plane] = y[j] + k.fb[j];
     }
   }
+}
+template <int RPW>
+__device__ __forceinline__ void fuse_epilogue_mfma(const TapConv& d, f32x4 (&acc)[RPW][2], int n, int n0, int ty0, int tx0,
+                                                   int wave, int lr, int kg) {
+  FuseEpiConst k;
+  k.b0 = k.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d.bias) {
+    k.b0 = *reinterpret_cast<const float4*>(d.bias + n0 + kg * 4);
+    k.b1 = *reinterpret_cast<const float4*>(d.bias + n0 + 16 + kg * 4);
+  }
+  const int m = min(lr, d.fuse_dim - 1);
+  const float4 w0 = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)m * d.Cout + n0 + kg * 4);
+  const float4 w1 = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)m * d.Cout + n0 + 16 + kg * 4);
+  k.w8[0] = w0.x; k.w8[1] = w0.y; k.w8[2] = w0.z; k.w8[3] = w0.w; k.w8[4] = w1.x; k.w8[5] = w1.y; k.w8[6] = w1.z; k.w8[7] = w1.w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) k.fb[j] = d.fuse_b[min(j, d.fuse_dim - 1)];
+  fuse_epilogue_mfma_pre<RPW>(d, acc, k, n, n0, ty0, tx0, wave, lr, kg);
 }

@@ -96,7 +96,8 @@ struct SpGeom {
   static constexpr int WBUF = NBLK * 1024;         // bytes of one window buffer
   static constexpr int BNB = BNB_;
   static constexpr int W_IMAGE = 9 * 4 * BNB * 16;  // one operand image (hi or lo) of a chunk's weights
-  static constexpr int LDS = 2 * WBUF + 2 * W_IMAGE + 64;
+  static constexpr int EPI = 768;                   // bytes of one slot of per-item epilogue constants (two slots)
+  static constexpr int LDS = 2 * WBUF + 2 * W_IMAGE + 64 + 2 * EPI;
 };
 
 template <bool HAS2, int BNB_, bool FUSE, bool DUAL>
@@ -116,6 +117,11 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
   sp_flag_ptr sCL = sCR + 3;                          // CL[3]: mover waves whose part of weight column j has landed
   sp_flag_ptr sWL = sCR + 6;                          // WL[2]: mover waves whose part of window buffer b has landed
   sp_flag_ptr sWR = sCR + 8;                          // WR[2]: consumer waves that have finished reading window buffer b
+  // per-item epilogue constants, staged by one mover wave with the item's first step (slot = item ordinal & 1): bias (+ bias2) |
+  // post_add | post2 of the block's channels (fused projection: bias | fuse_w rows | fuse_b).  A global load in the
+  // consumers' epilogue would expose a memory round trip per item on every SIMD.
+  float* sEpi = reinterpret_cast<float*>(sW + 2 * W_IMAGE + 64);
+  constexpr int EC = DUAL ? 64 : BNB;                 // floats per constant vector
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 consumers, 8..11 movers
@@ -255,6 +261,30 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
         if (lane == 0) sp_bump(sCL + col);
       };
       SP_STAMP(7);
+      // epilogue constants of a new item (one mover wave; issued before every other load of the step: the oldest)
+      const bool epi_step = c == 0 && pw == 3;  // (mover 0 carries one window piece more than the others)
+      u32x4 ev = {0u, 0u, 0u, 0u};
+      if (epi_step) {
+        const float* src = nullptr;
+        const float* src2 = nullptr;
+        if constexpr (FUSE) {
+          const int fd1 = d.fuse_dim - 1;
+          if (lane < 8) src = d.bias ? d.bias + n0 + lane * 4 : nullptr;
+          else if (lane < 40) src = d.fuse_w + (size_t)min((lane - 8) >> 3, fd1) * d.Cout + n0 + ((lane - 8) & 7) * 4;
+          else if (lane < 44) ev[0] = __float_as_uint(d.fuse_b[min(lane - 40, fd1)]);
+        } else {
+          const int which = lane / (EC / 4), o = (lane % (EC / 4)) * 4;
+          if (which == 0) { src = d.bias ? d.bias + n0 + o : nullptr; src2 = (HAS2 && d.bias2) ? d.bias2 + n0 + o : nullptr; }
+          else if (which == 1) src = (d.post_add && o < d.Cout) ? d.post_add + (size_t)n * d.post_cs + n0 + o : nullptr;
+          else if (which == 2) src = (d.out2 && !DUAL) ? d.post2 + (size_t)n * d.post2_cs + n0 + o : nullptr;
+        }
+        if (src) {
+          const float4 a = *reinterpret_cast<const float4*>(src);
+          float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (src2) b = *reinterpret_cast<const float4*>(src2);
+          ev = u32x4{__float_as_uint(a.x + b.x), __float_as_uint(a.y + b.y), __float_as_uint(a.z + b.z), __float_as_uint(a.w + b.w)};
+        }
+      }
       load_col(0);
       // ---- window loads ----
 #ifdef DRS_SP_TIMELINE
@@ -300,6 +330,14 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
       if (k >= 1) sp_poll(sCR, 8u * (unsigned)k);
       SP_STAMP(1);
       sp_wait_vm(nwin + np[1]);
+      if (epi_step) {  // (every consumer is past the epilogue of the item that used this slot: it holds column 0 of step k - 1)
+        float* slot = sEpi + (ord & 1) * (G::EPI / 4);
+        if (FUSE && lane >= 40) {
+          if (lane < 44) slot[160 + lane - 40] = __uint_as_float(ev[0]);
+        } else if (lane < 3 * (EC / 4) || FUSE) {
+          if (!FUSE || lane < 40) *reinterpret_cast<u32x4*>(slot + lane * 4) = ev;
+        }
+      }
       store_col(0);
       load_col(2);  // into column 0's registers; needed two thirds of a step from now
       SP_STAMP(2);
@@ -440,27 +478,52 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
         // out of the step loop (where it would be spilled and reloaded between the stores)
         int lr_e = lr, kg_e = kg;
         asm volatile("" : "+v"(lr_e), "+v"(kg_e));
+        const float* ek = sEpi + (ord & 1) * (G::EPI / 4);
+        auto lds8 = [&](const float* p, float (&v)[8]) __attribute__((always_inline)) {
+          const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        };
         if constexpr (DUAL) {
           // out = relu(main + b_main) + post_add + (skip + b_skip): tiles t (main) and t + 2 (skip) of the same lane;
           // channel of (tile t, register j) in SP order: kg*8 + t*4 + j
+          float bm[8], bs[8];
+          lds8(ek + kg_e * 8, bm);
+          lds8(ek + 32 + kg_e * 8, bs);
           f32x4 comb[RPW][2];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const float4 b1 = *reinterpret_cast<const float4*>(d.bias + kg_e * 8 + t * 4);
-            const float4 b2 = *reinterpret_cast<const float4*>(d.bias + d.Cout + kg_e * 8 + t * 4);
-            const float bm[4] = {b1.x, b1.y, b1.z, b1.w}, bs[4] = {b2.x, b2.y, b2.z, b2.w};
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < RPW; ++r)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) comb[r][t][j] = fmaxf(acc[r][t][j] + bm[j], 0.f) + (acc[r][t + 2][j] + bs[j]);
-          }
+              for (int j = 0; j < 4; ++j)
+                comb[r][t][j] = fmaxf(acc[r][t][j] + bm[t * 4 + j], 0.f) + (acc[r][t + 2][j] + bs[t * 4 + j]);
+          SpEpiConst kc;
+          lds8(ek + EC + kg_e * 8, kc.post);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { kc.bias[j] = 0.f; kc.post2[j] = 0.f; }
           TapConv de = d;
-          de.bias = nullptr; de.bias2 = nullptr; de.relu_pre = 0;
-          tile_epilogue_sp<RPW, 2, false>(de, comb, n, 0, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
-        } else if constexpr (FUSE)
-          fuse_epilogue_mfma<RPW>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e);
-        else
-          tile_epilogue_sp<RPW, NT, true>(d, acc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e, d.out_oy, d.out_ox);
+          de.relu_pre = 0;
+          tile_epilogue_sp_pre<RPW, false>(de, comb, kc, n, 0, ty0, tx0, rw, lr_e, kg_e);
+        } else if constexpr (FUSE) {
+          FuseEpiConst kc;
+          kc.b0 = *reinterpret_cast<const float4*>(ek + kg_e * 4);
+          kc.b1 = *reinterpret_cast<const float4*>(ek + 16 + kg_e * 4);
+          const int m = min(lr_e, 3);
+          const float4 w0 = *reinterpret_cast<const float4*>(ek + 32 + m * 32 + kg_e * 4);
+          const float4 w1 = *reinterpret_cast<const float4*>(ek + 32 + m * 32 + 16 + kg_e * 4);
+          kc.w8[0] = w0.x; kc.w8[1] = w0.y; kc.w8[2] = w0.z; kc.w8[3] = w0.w;
+          kc.w8[4] = w1.x; kc.w8[5] = w1.y; kc.w8[6] = w1.z; kc.w8[7] = w1.w;
+          const float4 fb = *reinterpret_cast<const float4*>(ek + 160);
+          kc.fb[0] = fb.x; kc.fb[1] = fb.y; kc.fb[2] = fb.z; kc.fb[3] = fb.w;
+          fuse_epilogue_mfma_pre<RPW>(d, acc, kc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e);
+        } else {
+          SpEpiConst kc;
+          const float* e0 = ek + ng * BN + kg_e * 8;
+          lds8(e0, kc.bias);
+          lds8(e0 + EC, kc.post);
+          lds8(e0 + 2 * EC, kc.post2);
+          tile_epilogue_sp_pre<RPW, true>(d, acc, kc, n, n0 + ng * BN, ty0, tx0, rw, lr_e, kg_e);
+        }
       }
     }
   }
