@@ -33,9 +33,20 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
   char* sRes = sWx + 2 * wx_img;
   {
     const int tid = threadIdx.x;
-    auto copy = [&](char* dst, const void* src, int bytes) {
-      for (int o = tid * 16; o < bytes; o += 512 * 16)
-        *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src) + o);
+    auto copy = [&](char* dst, const void* src, int bytes) {  // 8 loads in flight per thread (not a round trip per 8 KB)
+      for (int o0 = tid * 16; o0 < bytes; o0 += 8 * 512 * 16) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int o = o0 + u * 512 * 16;
+          if (o < bytes) v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src) + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int o = o0 + u * 512 * 16;
+          if (o < bytes) *reinterpret_cast<u32x4*>(dst + o) = v[u];
+        }
+      }
     };
     copy(sGate, d.w_gate, 2 * gate_img);
     copy(sWg, d.w_wg, 2 * wg_img);
@@ -219,17 +230,28 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
 #pragma unroll
       for (int b = 0; b < 2; ++b)
         xg[b] = reinterpret_cast<const char*>(d.x) + ((((size_t)nn[b] * d.LH + yy[b]) * d.LW + px[b]) * d.x_cs + d.x_co) * 4 + kg * 16;
-      for (int c = 0; c < ncx; ++c) {
-        typename P::Frag wa[2], xa[2];
+      // Every operand of this kernel comes straight from L2 / HBM and a wave has 12 MFMAs of work per 4 KB: what counts is
+      // how many loads are in flight.  Operands are fetched in groups of 2 chunks (8 fragments, 64 registers) issued
+      // back to back; the MFMAs then consume them in issue order (counted waits).
+      for (int c0 = 0; c0 < ncx; c0 += 2) {
+        typename P::Frag wa[2][2], xa[2][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) wa[t] = wfrag(d.w_gate, gate_img, (c * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-          xa[b] = typename P::Frag{*reinterpret_cast<const bf16x8*>(xg[b] + c * 128), *reinterpret_cast<const bf16x8*>(xg[b] + c * 128 + 64)};
+          for (int t = 0; t < 2; ++t) wa[i][t] = wfrag(d.w_gate, gate_img, ((c0 + i) * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < 2; ++b)
+            xa[i][b] = typename P::Frag{*reinterpret_cast<const bf16x8*>(xg[b] + (c0 + i) * 128),
+                                        *reinterpret_cast<const bf16x8*>(xg[b] + (c0 + i) * 128 + 64)};
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[t], xa[b], acc[b][t]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[i][t], xa[i][b], acc[b][t]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     {
@@ -256,33 +278,43 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      typename P::Frag wa[NG][2];
 #pragma unroll
-    for (int cc = 0; cc < NG; ++cc) {
-      typename P::Frag wa[2];
+      for (int cc = 0; cc < NG; ++cc)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) wa[t] = wfrag(d.w_wg, wg_img, (cc * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+        for (int t = 0; t < 2; ++t) wa[cc][t] = wfrag(d.w_wg, wg_img, (cc * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const typename P::Frag gf{*reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, cc, 0)),
-                                  *reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, cc, 1))};
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[t], gf, acc[b][t]);
-      }
-    }
-    for (int t4 = 0; t4 < 4; ++t4) {
-#pragma unroll
-      for (int cc = 0; cc < NG; ++cc) {
-        typename P::Frag wa[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) wa[t] = wfrag(d.w_wx, wx_img, ((cc * 4 + t4) * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+      for (int cc = 0; cc < NG; ++cc)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const typename P::Frag xf = xres_frag(b, t4, cc);
+          const typename P::Frag gf{*reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, cc, 0)),
+                                    *reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, cc, 1))};
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[t], xf, acc[b][t]);
+          for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[cc][t], gf, acc[b][t]);
         }
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    for (int t4 = 0; t4 < 4; ++t4)
+      for (int c0 = 0; c0 < NG; c0 += 2) {
+        typename P::Frag wa[2][2], xf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) wa[i][t] = wfrag(d.w_wx, wx_img, (((c0 + i) * 4 + t4) * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) xf[i][b] = xres_frag(b, t4, c0 + i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[i][t], xf[i][b], acc[b][t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     {
       const int ch = cg * 32 + kg * 8;
       float wp[8], bsum[8];
@@ -320,22 +352,31 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
       const float4 b0 = *reinterpret_cast<const float4*>(d.b_res + cg * 32 + kg * 8);
       const float4 b1 = *reinterpret_cast<const float4*>(d.b_res + cg * 32 + kg * 8 + 4);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      typename P::Frag wr[NG][2];  // the result weights of this wave's channels: the same for all four pixels
+#pragma unroll
+      for (int cc = 0; cc < NG; ++cc)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wr[cc][t] = wfrag(d.w_res, wg_img, (cc * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
       for (int t4 = 0; t4 < 4; ++t4) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int cc = 0; cc < NG; ++cc) {
-          typename P::Frag wa[2];
+        for (int c0 = 0; c0 < NG; c0 += 2) {
+          typename P::Frag xf[2][2];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) wa[t] = wfrag(d.w_res, wg_img, (cc * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const typename P::Frag xf = xres_frag(b, t4, cc);
+            for (int b = 0; b < 2; ++b) xf[i][b] = xres_frag(b, t4, c0 + i);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[t], xf, acc[b][t]);
-          }
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wr[c0 + i][t], xf[i][b], acc[b][t]);
+          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {

@@ -19,6 +19,30 @@
 
 namespace {
 
+// the block's weights -> LDS: [operand image][chunk][tap][k-group][GC] slots; 8 loads in flight per thread (a dependent
+// load -> store chain per slot would cost a memory round trip per 8 KB of the up to 147 KB)
+__device__ __forceinline__ void copy_weights(char* smem, const TapConv& d, int nck, int GC, int n0, unsigned w_gimage, int tid) {
+  const int slots = nck * 36 * GC;  // per operand image; a multiple of 512
+  const char* wsrc = reinterpret_cast<const char*>(d.w);
+  for (int i0 = tid; i0 < 2 * slots; i0 += 512 * 8) {
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 512;
+      if (i < 2 * slots) {
+        const int im = i >= slots, idx = im ? i - slots : i;
+        const int r = idx / GC, j = idx - r * GC;
+        v[u] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)im * w_gimage + ((size_t)r * d.Cout + n0 + j) * 16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 512;
+      if (i < 2 * slots) *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = v[u];
+    }
+  }
+}
+
 template <int NT>  // 16 * NT output channels per block
 __global__ __launch_bounds__(512, 1) void conv_s2_sp_kernel(TapConv d, int nck, unsigned w_gimage) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -31,29 +55,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_sp_kernel(TapConv d, int nck, 
   const int grp = j8 % ngroups, member = j8 / ngroups, members = nb8 / ngroups;  // (the launcher makes nb8 a multiple of ngroups)
   const int n0 = grp * GC;
   const int img = nck * 36 * GC * 16;  // bytes of one operand image of this block's weights: [chunk][tap][k-group][GC] slots
-  {
-    // weight copy, 8 loads in flight per thread (a dependent load -> store chain per slot would cost a memory round trip
-    // per 8 KB of the up to 147 KB)
-    const int slots = nck * 36 * GC;  // per operand image; a multiple of 512
-    const char* wsrc = reinterpret_cast<const char*>(d.w);
-    for (int i0 = tid; i0 < 2 * slots; i0 += 512 * 8) {
-      u32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 512;
-        if (i < 2 * slots) {
-          const int im = i >= slots, idx = im ? i - slots : i;
-          const int r = idx / GC, j = idx - r * GC;
-          v[u] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)im * w_gimage + ((size_t)r * d.Cout + n0 + j) * 16);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 512;
-        if (i < 2 * slots) *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = v[u];
-      }
-    }
-  }
+  copy_weights(smem, d, nck, GC, n0, w_gimage, tid);
   __syncthreads();
 
   // this XCD's rows, this wave's row segments
@@ -182,9 +184,153 @@ __global__ __launch_bounds__(512, 1) void conv_s2_sp_kernel(TapConv d, int nck, 
   }
 }
 
+
+// ---- ConvTranspose2d(k = 3, s = 2, p = 1, output_padding = 1) of UpConvBlock.transform (reference :185, :206) -------------
+// out[2 iy - 1 + ky][2 ix - 1 + kx] += in[iy][ix] * w[ky][kx]: output phase (py, px) of input pixel (y, x) takes ky = 1 from
+// row y (py = 0) or ky = 0 from row y + 1 and ky = 2 from row y (py = 1), the same in x: every one of the nine taps feeds
+// exactly one of the four phases, and the operands are the four pixels (y, x), (y, x + 1), (y + 1, x), (y + 1, x + 1).
+// Same structure as the stride-2 kernel above: weights resident in LDS, operands global -> registers (two rows of 16
+// pixels per K-chunk; the x + 1 operand is the right neighbour lane: a DPP shift, lanes lr == 15 load the segment's
+// 17th pixel), four accumulator sets, 2x2 output pixels per lane stored as SP lines.  The lock-step kernel ran these
+// layers (128 -> 128 at 64x64, 64 -> 64 at 128x128) at 86 / 110 us; 335 MB at 5.7 TB/s would be 59 us for the larger.
 template <int NT>
+__global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, unsigned w_gimage) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using P = PolicyBF16X3;
+  constexpr int GC = 16 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kg = lane >> 4;
+  const int ngroups = d.Cout / GC;
+  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+  const int grp = j8 % ngroups, member = j8 / ngroups, members = nb8 / ngroups;
+  const int n0 = grp * GC;
+  const int img = nck * 36 * GC * 16;
+  copy_weights(smem, d, nck, GC, n0, w_gimage, tid);
+  __syncthreads();
+
+  const int bw = d.W / 16;  // (W is a multiple of 16: a lane's right neighbour is always a real pixel or the edge load)
+  const int rows = d.N * d.H;
+  const int r_lo = (int)((long long)rows * xcd / 8), r_hi = (int)((long long)rows * (xcd + 1) / 8);
+  const int Q = (r_hi - r_lo) * bw;
+  const int stride = members * 8, first = member * 8 + wave;
+  const int my_items = first < Q ? (Q - first + stride - 1) / stride : 0;
+  const int S = my_items * nck;
+  if (S == 0) return;
+  const int half = drs_sp_group_bytes(d.in_cs);
+  const char* zero = reinterpret_cast<const char*>(d.zero_line) + kg * 16;
+  const char* wbase = smem + ((size_t)kg * GC + lr) * 16;
+
+  struct Rows { typename P::Frag a[2], e[2]; };  // a[dy]: pixel (y + dy, x); e[dy] (lanes lr == 15): pixel (y + dy, x0 + 16)
+  Rows fa, fb;
+  auto issue = [&](int s, Rows& f) __attribute__((always_inline)) {
+    const int it = s / nck, c = s - it * nck;
+    const int q = first + it * stride;
+    const int row = r_lo + q / bw, xb = q - (q / bw) * bw;
+    const int n = row / d.H, y = row - n * d.H;
+    const int px = xb * 16 + lr;
+    const char* base = reinterpret_cast<const char*>(d.in) +
+                       ((((long long)n * d.H + y) * d.W + px) * d.in_cs + d.in_co) * 4 + c * 128 + kg * 16;
+    const int rowb = d.W * d.in_cs * 4, pixb = d.in_cs * 4;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const bool row_ok = y + dy < d.H;  // output_padding: the last odd output row / column sees zeros beyond the image
+      const char* p = row_ok ? base + dy * rowb : zero;
+      f.a[dy] = typename P::Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(row_ok ? p + half : zero)};
+      if (lr == 15) {
+        const bool ok = row_ok && px + 1 < d.W;
+        const char* pe = ok ? base + dy * rowb + pixb : zero;
+        f.e[dy] = typename P::Frag{*reinterpret_cast<const bf16x8*>(pe), *reinterpret_cast<const bf16x8*>(ok ? pe + half : zero)};
+      }
+    }
+  };
+  auto shift_in = [&](const bf16x8& edge, const bf16x8& own) __attribute__((always_inline)) {
+    const u32x4 e = __builtin_bit_cast(u32x4, edge), r = __builtin_bit_cast(u32x4, own);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)  // row_shl:1: lane lr takes lane lr + 1 of its 16-lane row; lane 15 keeps `edge`
+      o[j] = (unsigned)__builtin_amdgcn_update_dpp((int)e[j], (int)r[j], 0x101, 0xf, 0xf, false);
+    return __builtin_bit_cast(bf16x8, o);
+  };
+  f32x4 acc[4][NT];
+  float bias8[NT / 2][8];
+#pragma unroll
+  for (int pr = 0; pr < NT / 2; ++pr) {
+    const float4 a = d.bias ? *reinterpret_cast<const float4*>(d.bias + n0 + pr * 32 + kg * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = d.bias ? *reinterpret_cast<const float4*>(d.bias + n0 + pr * 32 + kg * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias8[pr][0] = a.x; bias8[pr][1] = a.y; bias8[pr][2] = a.z; bias8[pr][3] = a.w;
+    bias8[pr][4] = b.x; bias8[pr][5] = b.y; bias8[pr][6] = b.z; bias8[pr][7] = b.w;
+  }
+  auto store_item = [&](int n, int y, int x0) __attribute__((always_inline)) {
+    const bool lo = lr < 8;
+    const int pl = lr & 7;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+      for (int pr = 0; pr < NT / 2; ++pr) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = acc[ph][2 * pr][j] + bias8[pr][j]; v[4 + j] = acc[ph][2 * pr + 1][j] + bias8[pr][4 + j]; }
+        u32x4 H, L;
+        drs_sp_split8(v, H, L);
+        const u32x4 got = drs_dpp_swap8(lo ? L : H);
+        const size_t orow = ((size_t)n * d.OH + 2 * y + (ph >> 1)) * d.OW;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const size_t opix = orow + 2 * (x0 + pl + 8 * h) + (ph & 1);
+          char* gp = reinterpret_cast<char*>(d.out) + (opix * d.out_cs + d.out_co + n0 + pr * 32) * 4 + (lo ? 0 : 64) + kg * 16;
+          *reinterpret_cast<u32x4*>(gp) = (h == 0) ? (lo ? H : got) : (lo ? got : L);
+        }
+      }
+  };
+  auto compute = [&](int s, const Rows& f) __attribute__((always_inline)) {
+    const int it = s / nck, c = s - it * nck;
+    if (c == 0) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[ph][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const char* wc = wbase + (size_t)c * 36 * GC * 16;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const typename P::Frag right{shift_in(f.e[dy].hi, f.a[dy].hi), shift_in(f.e[dy].lo, f.a[dy].lo)};
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const typename P::Frag& a = dx == 0 ? f.a[dy] : right;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            if ((ky == 0 ? 1 : 0) != dy || (kx == 0 ? 1 : 0) != dx) continue;
+            const int ph = (ky == 1 ? 0 : 1) * 2 + (kx == 1 ? 0 : 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const typename P::Frag wf = P::load(wc, (size_t)img, (size_t)((ky * 3 + kx) * 4 * GC + t * 16) * 16);
+              acc[ph][t] = P::mma(wf, a, acc[ph][t]);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (c == nck - 1) {
+      const int q = first + it * stride;
+      const int row = r_lo + q / bw, xb = q - (q / bw) * bw;
+      const int n = row / d.H, y = row - n * d.H;
+      store_item(n, y, xb * 16);
+    }
+  };
+  issue(0, fa);
+  for (int s = 0; s < S; s += 2) {
+    if (s + 1 < S) issue(s + 1, fb);
+    compute(s, fa);
+    if (s + 2 < S) issue(s + 2, fa);
+    if (s + 1 < S) compute(s + 1, fb);
+  }
+}
+
+template <int NT, bool CONVT = false>
 int s2_launch(const TapConv& d, int nck, unsigned w_gimage, hipStream_t s) {
-  auto kern = conv_s2_sp_kernel<NT>;
+  auto kern = CONVT ? convt_sp_kernel<NT> : conv_s2_sp_kernel<NT>;
   const size_t lds = (size_t)2 * nck * 36 * 16 * NT * 16;
   int num_cu = 0;
   {
@@ -229,4 +375,24 @@ int drs_launch_conv_s2_sp(const TapConv& d, hipStream_t s) {
   const int nck = d.Cin / 32;
   const unsigned w_gimage = (unsigned)((size_t)nck * 9 * 4 * d.Cout * 16);  // bytes of the hi image in the packed weights
   return s2_tiles(d) == 4 ? s2_launch<4>(d, nck, w_gimage, s) : s2_launch<2>(d, nck, w_gimage, s);
+}
+
+bool drs_convt_sp_supported(const TapConv& d, int impl) {
+  static const int env = getenv("DRS_S2K") ? atoi(getenv("DRS_S2K")) : 1;
+  if (!env || impl != DRS_IMPL_MFMA_BF16X3) return false;
+  if (!d.in || !d.in_sp || !d.out || !d.out_sp || !d.zero_line || d.mode != DRS_TAPMODE_CONVT || d.ntaps != 9 || d.wtaps_total != 9) return false;
+  if (d.in_stride != 1 || d.out_scale != 2 || d.out_oy || d.out_ox) return false;
+  for (int i = 0; i < 9; ++i)
+    if (d.wtap[i] != i) return false;
+  if (d.in2 || d.out2 || d.fuse_out || d.dual || d.gate || d.in_add || d.res || d.sigmoid || d.out_nchw) return false;
+  if (d.post_add || d.bias2 || d.relu_pre || d.relu_post) return false;
+  if ((d.W & 15) || d.OH != 2 * d.H || d.OW != 2 * d.W || d.TH != d.H || d.TW != d.W) return false;
+  if (d.Cin % 32 || d.Cout % 32 || (d.in_cs & 31) || (d.in_co & 31) || (d.out_cs & 31) || (d.out_co & 31)) return false;
+  return s2_tiles(d) != 0;
+}
+
+int drs_launch_convt_sp(const TapConv& d, hipStream_t s) {
+  const int nck = d.Cin / 32;
+  const unsigned w_gimage = (unsigned)((size_t)nck * 9 * 4 * d.Cout * 16);
+  return s2_tiles(d) == 4 ? s2_launch<4, true>(d, nck, w_gimage, s) : s2_launch<2, true>(d, nck, w_gimage, s);
 }

@@ -1087,7 +1087,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       TapConv d = convT_fused_desc(TP(plan->t_U[i]), B, lh, lw, Cc, Cc, 0, PW(st.transform), PB(st.transform), cat, Cc,
                                    Cc + Ch, 0);
       d.shared_cu = concurrent ? 1 : 0;
-      d.in_sp = d.out_sp = sp;
+      d.in_sp = d.out_sp = sp; d.zero_line = zero_line;
       RUN(plan_conv(plan, st.transform, d, s));
     } else
     for (int py = 0; py < 2; ++py)
