@@ -1,0 +1,344 @@
+// 3x3 stride-1 tap-convolution over SP-format activations for the SHALLOW layers: few input channels, large images, all
+// weights resident in LDS (9 * Cin * Cout * 4 bytes <= ~150 KB) - the first residual block (conv1 + skip convolution,
+// conv2 + 1x1 shortcut; reference UNet_model_superres.py:153-172), ups.2.conv, and up_convs.2 with the fused output
+// projection (:197-207, :377).
+//
+// Why a second 3x3 kernel: on these layers a K-step of the wave-specialised kernel (conv_mfma_sp.hip) is short (one or
+// two 32-channel chunks per 16x16 patch), its movers re-stage 36-72 KB of weights for every patch next to 41 KB of window,
+// have one step of loads in flight against HBM latency, and every patch ends in an epilogue: 150-300 TFLOP/s where the deep
+// layers reach 400 (phase timeline: 9.1 k ticks per step for 3.5 k ticks of MFMA).  Here
+//   * the weights are copied into LDS once per block and stay (no ring, no counters, no mover waves);
+//   * operands go global -> registers (an SP slot is an MFMA B-operand register group): a wave owns a strip of 16 x RB
+//     output pixels and walks down its input rows; the x - 1 / x + 1 taps of a row are DPP lane shifts of the row's own
+//     fragment (lanes 0 / 15 take the strip's outer pixels from a two-lane edge load), rows are prefetched a row pair ahead
+//     and across pass boundaries;
+//   * two output rows share every weight-fragment read (0.33 LDS reads per MFMA);
+//   * per-image epilogue vectors (bias, time embedding rows) are staged in LDS at kernel start.
+// All eight waves of a block are equal; the only barrier is the one after the weight copy.
+// Flavours (template): NT channel tiles per wave (2: 32 channels of one group; 4: the 64 weight channels of the fused conv1 +
+// skip pair), HAS2 (the block's 1x1 shortcut input as one more tap in the last K-pass), DUAL, FUSE.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "conv_epilogue.h"
+#include "mfma_policy.h"
+
+namespace {
+
+constexpr int RB = 4;       // output rows per strip (two row pairs)
+constexpr int NPOST = 64;  // images whose per-image epilogue vectors are staged in LDS (later images read them from memory)
+
+struct RowOp { PolicyBF16X3::Frag c, e; };  // c: pixel x0 + lr of the row; e: lanes 0 / 15 hold pixels x0 - 1 / x0 + 16
+
+__device__ __forceinline__ bf16x8 dpp_shift(const bf16x8& edge, const bf16x8& own, bool left) {
+  const u32x4 e = __builtin_bit_cast(u32x4, edge), r = __builtin_bit_cast(u32x4, own);
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)  // row_shr:1 (x - 1): lane lr takes lane lr - 1, lane 0 keeps `edge`; row_shl:1 (x + 1): lane 15 keeps it
+    o[j] = left ? (unsigned)__builtin_amdgcn_update_dpp((int)e[j], (int)r[j], 0x111, 0xf, 0xf, false)
+                : (unsigned)__builtin_amdgcn_update_dpp((int)e[j], (int)r[j], 0x101, 0xf, 0xf, false);
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+template <int NT, bool HAS2, bool DUAL, bool FUSE>
+__global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, int nck, unsigned w_gimage, unsigned w2_gimage) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using P = PolicyBF16X3;
+  using Frag = typename P::Frag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kg = lane >> 4;
+  const int CW = DUAL ? 2 * d.Cout : d.Cout;  // resident weight channels
+  const int img = nck * 36 * CW * 16;         // bytes of one operand image of the 3x3 weights: [chunk][tap][k-group][CW] slots
+  const int img2 = HAS2 ? 4 * CW * 16 : 0;    // ... of the 1x1 shortcut weights (one K-chunk): [k-group][CW]
+  char* sW = smem;
+  char* sW2 = smem + 2 * img;
+  float* sBias = reinterpret_cast<float*>(sW2 + 2 * img2);  // [CW] bias (+ bias2)   (fused projection: + fuse_w[4][32] + fuse_b[4])
+  float* sPost = sBias + (FUSE ? 32 + 128 + 4 : CW);        // [N][Cout] post_add rows, then [N][Cout] post2 rows
+  const int npost = min(d.N, NPOST);
+  float* sPost2 = sPost + npost * d.Cout;
+  {
+    auto copy = [&](char* dst, const char* src, int bytes) __attribute__((always_inline)) {  // 8 loads in flight per thread
+      for (int o0 = tid * 16; o0 < bytes; o0 += 8 * 512 * 16) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int o = o0 + u * 512 * 16;
+          if (o < bytes) v[u] = *reinterpret_cast<const u32x4*>(src + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int o = o0 + u * 512 * 16;
+          if (o < bytes) *reinterpret_cast<u32x4*>(dst + o) = v[u];
+        }
+      }
+    };
+    const char* w = reinterpret_cast<const char*>(d.w);
+    copy(sW, w, img);
+    copy(sW + img, w + w_gimage, img);
+    if constexpr (HAS2) {
+      const char* w2 = reinterpret_cast<const char*>(d.w2);
+      copy(sW2, w2, img2);
+      copy(sW2 + img2, w2 + w2_gimage, img2);
+    }
+    for (int i = tid; i < CW; i += 512) sBias[i] = (d.bias ? d.bias[i] : 0.f) + ((HAS2 && d.bias2) ? d.bias2[i] : 0.f);
+    if constexpr (FUSE) {
+      for (int i = tid; i < 128; i += 512) sBias[32 + i] = d.fuse_w[min(i >> 5, d.fuse_dim - 1) * d.Cout + (i & 31)];
+      if (tid < 4) sBias[160 + tid] = d.fuse_b[min(tid, d.fuse_dim - 1)];
+    } else {
+      for (int i = tid; i < npost * d.Cout; i += 512) {
+        const int n = i / d.Cout, c = i - n * d.Cout;
+        sPost[i] = d.post_add ? d.post_add[(size_t)n * d.post_cs + c] : 0.f;
+        sPost2[i] = (!DUAL && d.out2) ? d.post2[(size_t)n * d.post2_cs + c] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+
+  // strips of 16 x RB output pixels x one 16 * NT channel group; blocks of an XCD (blockIdx % 8) take a contiguous eighth
+  const int gx = d.W >> 4, gy = d.H / RB;
+  const int groups = DUAL ? 1 : d.Cout / (16 * NT);
+  const int total = d.N * gy * gx * groups;
+  const int xcd = blockIdx.x & 7, member = blockIdx.x >> 3, members = gridDim.x >> 3;
+  const int t_lo = (int)((long long)total * xcd / 8), t_hi = (int)((long long)total * (xcd + 1) / 8);
+  const int stride = members * 8, first = member * 8 + wave;
+  const int my_items = first < t_hi - t_lo ? (t_hi - t_lo - first + stride - 1) / stride : 0;
+  const int S = my_items * nck;  // passes: one K-chunk of one strip each
+  if (S == 0) return;
+  const int half = drs_sp_group_bytes(d.in_cs), half2 = HAS2 ? drs_sp_group_bytes(d.in2_cs) : 0;
+  const int pixb = d.in_cs * 4;
+  const char* zero = reinterpret_cast<const char*>(d.zero_line) + kg * 16;
+  auto strip_of = [&](int it, int& n, int& yb, int& x0, int& n0) __attribute__((always_inline)) {
+    int q = t_lo + first + it * stride;
+    n0 = (q % groups) * 16 * NT; q /= groups;
+    x0 = (q % gx) * 16; q /= gx;
+    yb = (q % gy) * RB;
+    n = q / gy;
+  };
+  // one input row of a pass: window row wr (0 .. RB + 1) of chunk c of the strip
+  auto load_row = [&](RowOp& r, int n, int yb, int x0, int c, int wr) __attribute__((always_inline)) {
+    const int iy = yb - 1 + wr;
+    const bool ok = iy >= 0 && iy < d.H && c * 32 + kg * 8 < d.Cin;
+    const char* base = reinterpret_cast<const char*>(d.in) +
+                       ((((long long)n * d.H + iy) * d.W + x0 + lr) * d.in_cs + d.in_co) * 4 + c * 128 + kg * 16;
+    const char* p = ok ? base : zero;
+    r.c = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + half : zero)};
+    if (lr == 0 || lr == 15) {
+      const int ex = lr == 0 ? x0 - 1 : x0 + 16;
+      const bool eok = ok && ex >= 0 && ex < d.W;
+      const char* pe = eok ? (lr == 0 ? base - pixb : base + pixb) : zero;
+      r.e = Frag{*reinterpret_cast<const bf16x8*>(pe), *reinterpret_cast<const bf16x8*>(eok ? pe + half : zero)};
+    }
+  };
+  // the shortcut input at output row r of the strip (centre tap only, one K-chunk)
+  auto load_x2 = [&](Frag& f, int n, int yb, int x0, int r) __attribute__((always_inline)) {
+    const bool ok = kg * 8 < d.Cin2;
+    const char* base = reinterpret_cast<const char*>(d.in2) +
+                       ((((long long)n * d.H2 + yb + r) * d.W2 + x0 + lr) * d.in2_cs + d.in2_co) * 4 + kg * 16;
+    const char* p = ok ? base : zero;
+    f = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + half2 : zero)};
+  };
+  const char* wlane = sW + ((size_t)kg * CW + lr) * 16;
+  const char* w2lane = sW2 + ((size_t)kg * CW + lr) * 16;
+
+  f32x4 acc[RB][NT];
+  RowOp R[RB + 2], nx[4];
+  Frag X2[RB], nx2[2];
+  int n = 0, yb = 0, x0 = 0, n0 = 0;
+  strip_of(0, n, yb, x0, n0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_row(nx[i], n, yb, x0, 0, i);
+  if constexpr (HAS2) {
+    if (nck == 1) {
+      load_x2(nx2[0], n, yb, x0, 0);
+      load_x2(nx2[1], n, yb, x0, 1);
+    }
+  }
+  for (int s = 0; s < S; ++s) {
+    const int it = s / nck, c = s - it * nck;
+    const bool last_pass = c == nck - 1;
+    if (c == 0) {
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R[i] = nx[i];
+    if constexpr (HAS2) { X2[0] = nx2[0]; X2[1] = nx2[1]; }
+    // coordinates of the next pass (its first rows are fetched under this pass's last row pair)
+    int n1 = n, yb1 = yb, x01 = x0, n01 = n0;
+    const int c1 = c + 1 == nck ? 0 : c + 1;
+    if (c1 == 0 && s + 1 < S) strip_of(it + 1, n1, yb1, x01, n01);
+    const char* wc = wlane + (size_t)c * 36 * CW * 16 + (size_t)n0 * 16;
+#pragma unroll
+    for (int p = 0; p < RB / 2; ++p) {
+      // ---- prefetch: the next row pair of this pass, or the first four rows of the next pass ----
+      if (p + 1 < RB / 2) {
+        load_row(R[2 * p + 4], n, yb, x0, c, 2 * p + 4);
+        load_row(R[2 * p + 5], n, yb, x0, c, 2 * p + 5);
+        if constexpr (HAS2) {
+          if (last_pass) {
+            load_x2(X2[2 * p + 2], n, yb, x0, 2 * p + 2);
+            load_x2(X2[2 * p + 3], n, yb, x0, 2 * p + 3);
+          }
+        }
+      } else if (s + 1 < S) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_row(nx[i], n1, yb1, x01, c1, i);
+        if constexpr (HAS2) {
+          if (c1 == nck - 1) {
+            load_x2(nx2[0], n1, yb1, x01, 0);
+            load_x2(nx2[1], n1, yb1, x01, 1);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- output rows 2p, 2p + 1: window rows 2p + ky and 2p + 1 + ky; every weight fragment serves both ----
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const RowOp& ra = R[2 * p + ky];
+        const RowOp& rb = R[2 * p + 1 + ky];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          Frag a0, a1;
+          if (kx == 1) { a0 = ra.c; a1 = rb.c; }
+          else {
+            a0 = Frag{dpp_shift(ra.e.hi, ra.c.hi, kx == 0), dpp_shift(ra.e.lo, ra.c.lo, kx == 0)};
+            a1 = Frag{dpp_shift(rb.e.hi, rb.c.hi, kx == 0), dpp_shift(rb.e.lo, rb.c.lo, kx == 0)};
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const Frag wf = P::load(wc, (size_t)img, (size_t)((ky * 3 + kx) * 4 * CW + t * 16) * 16);
+            acc[2 * p][t] = P::mma(wf, a0, acc[2 * p][t]);
+            acc[2 * p + 1][t] = P::mma(wf, a1, acc[2 * p + 1][t]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (HAS2) {
+        if (last_pass) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const Frag wf = P::load(w2lane, (size_t)img2, (size_t)(n0 + t * 16) * 16);
+            acc[2 * p][t] = P::mma(wf, X2[2 * p], acc[2 * p][t]);
+            acc[2 * p + 1][t] = P::mma(wf, X2[2 * p + 1], acc[2 * p + 1][t]);
+          }
+        }
+      }
+    }
+    if (last_pass) {
+      auto lds8 = [&](const float* q, float (&v)[8]) __attribute__((always_inline)) {
+        const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      };
+      auto zero8 = [&](float (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      };
+      if constexpr (DUAL) {
+        // out = relu(main + b_main) + post_add + (skip + b_skip): tiles t (main) and t + 2 (skip) of the same lane
+        float bm[8], bs[8];
+        lds8(sBias + kg * 8, bm);
+        lds8(sBias + d.Cout + kg * 8, bs);
+        f32x4 comb[RB][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) comb[r][t][j] = fmaxf(acc[r][t][j] + bm[t * 4 + j], 0.f) + (acc[r][t + 2][j] + bs[t * 4 + j]);
+        SpEpiConst kc;
+        if (n < npost) lds8(sPost + n * d.Cout + kg * 8, kc.post);
+        else if (d.post_add) lds8(d.post_add + (size_t)n * d.post_cs + kg * 8, kc.post);
+        else zero8(kc.post);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kc.bias[j] = 0.f; kc.post2[j] = 0.f; }
+        TapConv de = d;
+        de.relu_pre = 0;
+        tile_epilogue_sp_pre<RB, false>(de, comb, kc, n, 0, yb, x0, 0, lr, kg);
+      } else if constexpr (FUSE) {
+        FuseEpiConst kc;
+        kc.b0 = *reinterpret_cast<const float4*>(sBias + kg * 4);
+        kc.b1 = *reinterpret_cast<const float4*>(sBias + 16 + kg * 4);
+        const int m = min(lr, 3);
+        const float4 w0 = *reinterpret_cast<const float4*>(sBias + 32 + m * 32 + kg * 4);
+        const float4 w1 = *reinterpret_cast<const float4*>(sBias + 32 + m * 32 + 16 + kg * 4);
+        kc.w8[0] = w0.x; kc.w8[1] = w0.y; kc.w8[2] = w0.z; kc.w8[3] = w0.w;
+        kc.w8[4] = w1.x; kc.w8[5] = w1.y; kc.w8[6] = w1.z; kc.w8[7] = w1.w;
+        const float4 fb = *reinterpret_cast<const float4*>(sBias + 160);
+        kc.fb[0] = fb.x; kc.fb[1] = fb.y; kc.fb[2] = fb.z; kc.fb[3] = fb.w;
+        fuse_epilogue_mfma_pre<RB>(d, acc, kc, n, n0, yb, x0, 0, lr, kg);
+      } else {
+        SpEpiConst kc;
+        lds8(sBias + n0 + kg * 8, kc.bias);
+        zero8(kc.post); zero8(kc.post2);
+        if (n < npost) {
+          lds8(sPost + n * d.Cout + n0 + kg * 8, kc.post);
+          lds8(sPost2 + n * d.Cout + n0 + kg * 8, kc.post2);
+        } else {
+          if (d.post_add) lds8(d.post_add + (size_t)n * d.post_cs + n0 + kg * 8, kc.post);
+          if (d.out2) lds8(d.post2 + (size_t)n * d.post2_cs + n0 + kg * 8, kc.post2);
+        }
+        tile_epilogue_sp_pre<RB, true>(d, acc, kc, n, n0, yb, x0, 0, lr, kg);
+      }
+    }
+    n = n1; yb = yb1; x0 = x01; n0 = n01;
+  }
+}
+
+size_t direct_lds_bytes(const TapConv& d) {
+  const int nck = (d.Cin + 31) / 32, CW = d.dual ? 2 * d.Cout : d.Cout;
+  size_t b = (size_t)2 * nck * 36 * CW * 16 + (d.in2 ? (size_t)2 * 4 * CW * 16 : 0);
+  b += d.fuse_out ? (32 + 128 + 4) * 4 : (size_t)(CW + 2 * (d.N < NPOST ? d.N : NPOST) * d.Cout) * 4;
+  return b;
+}
+
+template <int NT, bool HAS2, bool DUAL, bool FUSE>
+int direct_launch(const TapConv& d, hipStream_t s) {
+  auto kern = conv3x3_direct_sp_kernel<NT, HAS2, DUAL, FUSE>;
+  int num_cu = 0;
+  {
+    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
+    if (rc) return rc;
+  }
+  const int nck = (d.Cin + 31) / 32, CW = DUAL ? 2 * d.Cout : d.Cout;
+  const unsigned w_gimage = (unsigned)((size_t)nck * 9 * 4 * CW * 16);
+  const unsigned w2_gimage = HAS2 ? (unsigned)((size_t)((d.Cin2 + 31) / 32) * 4 * d.Cout * 16) : 0u;
+  const int blocks = num_cu / 8 * 8;  // one block per CU
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), direct_lds_bytes(d), s, d, nck, w_gimage, w2_gimage);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+bool std3x3(const TapConv& d) {
+  if (d.mode != 0 || d.ntaps != 9 || d.wtaps_total != 9 || d.in_stride != 1 || d.out_scale != 1 || d.out_oy || d.out_ox) return false;
+  for (int i = 0; i < 9; ++i)
+    if (d.dy[i] != i / 3 - 1 || d.dx[i] != i % 3 - 1 || d.wtap[i] != i) return false;
+  return true;
+}
+
+}  // namespace
+
+// Eligibility (shape only, never the batch size: a forward must not change its arithmetic with the batch): what
+// drs_tapconv_sp_supported takes, 32 output channels (the first / last level of every variant: one channel group per wave;
+// measured slower than the wave-specialised kernel on the 64-channel layers at 128x128), images of at least 64 rows, and
+// weights + epilogue vectors of NPOST images within LDS.  DRS_D3K=0 sends these layers back to the wave-specialised
+// kernel; bits: 1 plain, 2 with shortcut input, 4 conv1 + skip pair, 8 fused projection.
+bool drs_conv3x3_direct_sp_supported(const TapConv& d, int impl) {
+  static const int env = getenv("DRS_D3K") ? atoi(getenv("DRS_D3K")) : 15;
+  if (!env || impl != DRS_IMPL_MFMA_BF16X3) return false;
+  if (!(env & (d.dual ? 4 : d.fuse_out ? 8 : d.in2 ? 2 : 1))) return false;
+  if (!drs_tapconv_sp_supported(d, impl) || !std3x3(d)) return false;
+  if ((d.W & 15) || (d.H % RB) || d.H < 64 || d.TH != d.H || d.TW != d.W || d.OH != d.H || d.OW != d.W) return false;
+  if (d.in2 && (d.Cin2 > 32 || d.H2 != d.H || d.W2 != d.W)) return false;
+  if (d.Cout != 32) return false;
+  TapConv worst = d;
+  worst.N = NPOST;
+  return direct_lds_bytes(worst) <= 156 * 1024;
+}
+
+int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s) {
+  if (d.dual) return direct_launch<4, false, true, false>(d, s);
+  if (d.fuse_out) return direct_launch<2, false, false, true>(d, s);
+  return d.in2 ? direct_launch<2, true, false, false>(d, s) : direct_launch<2, false, false, false>(d, s);
+}

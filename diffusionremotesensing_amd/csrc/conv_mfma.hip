@@ -528,6 +528,8 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   geom(d, impl, &g, &bn, &rpw, &mode, &lds);
   if (mode == MODE_GENERIC && drs_conv_s2_sp_supported(d, impl)) return drs_launch_conv_s2_sp(d, s);
   if (mode == MODE_CONVT && drs_convt_sp_supported(d, impl)) return drs_launch_convt_sp(d, s);
+  if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_conv3x3_direct_sp_supported(d, impl))
+    return drs_launch_conv3x3_direct_sp(d, s);
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_sp_supported(d, impl)) {
     static const int spk = getenv("DRS_SPK") ? atoi(getenv("DRS_SPK")) : 1;
     return (spk == 2 && !d.dual) ? drs_launch_tapconv_sp1(d, g, s) : drs_launch_tapconv_sp(d, g, s);
