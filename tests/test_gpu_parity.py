@@ -579,15 +579,18 @@ def test_full_length_chain_is_deterministic(dev, model):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DRS_SP": "0"}, {"DRS_SP": "0", "DRS_WS": "0"}, {"DRS_SPK": "0"}, {"DRS_FUSE_GATE": "0"},
-                                 {"DRS_CONCURRENT": "1"}],
-                         ids=["fp32-activations+ws", "fp32-activations+lockstep", "sp+lockstep", "sp-unfused-gate", "sp-two-streams"])
+                                 {"DRS_CONCURRENT": "1"}, {"DRS_SPK": "2", "DRS_D3K": "0"}, {"DRS_D3K": "0", "DRS_S2K": "0"}],
+                         ids=["fp32-activations+ws", "fp32-activations+lockstep", "sp+lockstep", "sp-unfused-gate", "sp-two-streams",
+                              "sp-one-consumer-per-simd", "sp-without-direct-kernels"])
 def test_conv_kernel_variants_in_subprocess(env):
     """The kernel families of the eval split-bf16 plan are chosen once per process.  Default = SP-format activations with
     the wave-specialised SP kernel and the fused attention gate, serial stages; the switches select the older paths that
     the training / fp32 plans and small shapes still use: DRS_SP=0 fp32 channels-last activations (wave-specialised
     fp32-input kernel, DRS_WS=0: lock-step kernel only), DRS_SPK=0 SP format on the lock-step kernel, DRS_FUSE_GATE=0 the
-    five-launch attention gate, DRS_CONCURRENT=1 two-stream decoder stages.  All must reproduce the same goldens.  Own
-    process, because the switches are read once."""
+    five-launch attention gate, DRS_CONCURRENT=1 two-stream decoder stages, DRS_SPK=2 the one-consumer-per-SIMD variant of
+    the SP kernel (on every layer: DRS_D3K=0), DRS_D3K=0 / DRS_S2K=0 the plan without the direct-operand kernels (3x3 on the
+    32-channel layers, stride-2 and transposed convolutions).  All must reproduce the same goldens.  Own process, because
+    the switches are read once."""
     import os
     import subprocess
     import sys
