@@ -347,12 +347,26 @@ def main():
                 fwd_traffic = {"pmc_bytes": round(fb), "GBs": round(fb / 1e9 / (all_ms * 1e-3), 1),
                                "frac": round(fb / 1e9 / (all_ms * 1e-3) / HBM_PEAK_GBS, 4)}
         mfma_per_product = 3 if args.impl == "mfma_bf16x3" else 1
+        # the family's two kernels on the default plan: the 32-channel layers at full resolution run the direct-operand
+        # kernel (conv3x3_direct_sp.hip), everything else the wave-specialised one; per-kernel averages for the cross-check
+        # against the rocprofv3 kernel trace (profiles/r02_bench_kernel_stats.csv)
+        by_kernel = None
+        if args.impl == "mfma_bf16x3":
+            direct_ops = ("conv_blocks.0.conv1.0+skip", "conv_blocks.0.conv2.0", "up_convs.2")
+            by_kernel = {}
+            for kname, sel in (("conv3x3_direct_sp_kernel", [o for o in dom if o[0] in direct_ops]),
+                               ("tapconv_sp_kernel", [o for o in dom if o[0] not in direct_ops])):
+                if sel:
+                    ms = sum(o[1] for o in sel)
+                    by_kernel[kname] = {"launches": len(sel), "avg_launch_us": round(1e3 * ms / len(sel), 2),
+                                        "achieved": round(sum(o[2] for o in sel) / (ms * 1e-3) / 1e12, 2)}
         roofline = {"bound": "mfma",
-                    "kernel": ("3x3 stride-1 convolution: tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL> (conv_mfma_sp.hip; 8 MFMA + 4 "
-                               "mover waves per CU, SP-format operands)" if args.impl == "mfma_bf16x3" else
+                    "kernel": ("3x3 stride-1 convolutions: tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL> (conv_mfma_sp.hip; 8 MFMA + 4 "
+                               "mover waves per CU) on the deep layers + conv3x3_direct_sp_kernel (weights resident in LDS, "
+                               "operands global -> registers) on the 32-channel layers; SP-format operands" if args.impl == "mfma_bf16x3" else
                                "3x3 stride-1 family: tapconv_ws_kernel / tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *>" % args.impl)
                     if args.impl != "direct" else "tapconv_direct_kernel",
-                    "launches_per_forward": len(dom),
+                    "launches_per_forward": len(dom), "by_kernel": by_kernel,
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
                     "flops_per_launch": round(dom_fl / len(dom)), "avg_launch_us": round(1e3 * dom_ms / len(dom), 2),
                     "algorithmic_bytes_per_launch": round(dom_by / len(dom)),

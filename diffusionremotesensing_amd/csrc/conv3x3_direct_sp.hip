@@ -16,7 +16,7 @@
 //   * per-image epilogue vectors (bias, time embedding rows) are staged in LDS at kernel start.
 // All eight waves of a block are equal; the only barrier is the one after the weight copy.
 // Flavours (template): NT channel tiles per wave (2: 32 channels of one group; 4: the 64 weight channels of the fused conv1 +
-// skip pair), HAS2 (the block's 1x1 shortcut input as one more tap in the last K-pass), DUAL, FUSE.
+// skip pair, whose 16 input channels leave half of an MFMA's K empty: it multiplies TWO taps per MFMA, 5 instead of 9), HAS2 (the block's 1x1 shortcut input as one more tap in the last K-pass), DUAL, FUSE.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -48,7 +48,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, kg = lane >> 4;
   const int CW = DUAL ? 2 * d.Cout : d.Cout;  // resident weight channels
-  const int img = nck * 36 * CW * 16;         // bytes of one operand image of the 3x3 weights: [chunk][tap][k-group][CW] slots
+  // bytes of one operand image of the 3x3 weights: [chunk][tap][k-group][CW] slots; the 16-channel pair flavour packs TWO taps
+  // into the K = 32 of an MFMA (k-groups 0-1: tap 2j, k-groups 2-3: tap 2j + 1): [tap pair 5][k-group][CW]
+  const int img = DUAL ? 5 * 4 * CW * 16 : nck * 36 * CW * 16;
   const int img2 = HAS2 ? 4 * CW * 16 : 0;    // ... of the 1x1 shortcut weights (one K-chunk): [k-group][CW]
   char* sW = smem;
   char* sW2 = smem + 2 * img;
@@ -73,8 +75,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
       }
     };
     const char* w = reinterpret_cast<const char*>(d.w);
-    copy(sW, w, img);
-    copy(sW + img, w + w_gimage, img);
+    if constexpr (DUAL) {
+      for (int i = tid; i < 2 * 20 * CW; i += 512) {
+        const int im = i >= 20 * CW, idx = im ? i - 20 * CW : i;
+        const int ch = idx % CW, kgp = (idx / CW) & 3, j = idx / (4 * CW), tap = 2 * j + (kgp >> 1);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (tap < 9) v = *reinterpret_cast<const u32x4*>(w + (size_t)im * w_gimage + ((size_t)(tap * 4 + (kgp & 1)) * CW + ch) * 16);
+        *reinterpret_cast<u32x4*>(sW + (size_t)im * img + (size_t)idx * 16) = v;
+      }
+    } else {
+      copy(sW, w, img);
+      copy(sW + img, w + w_gimage, img);
+    }
     if constexpr (HAS2) {
       const char* w2 = reinterpret_cast<const char*>(d.w2);
       copy(sW2, w2, img2);
@@ -117,9 +129,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
   // one input row of a pass: window row wr (0 .. RB + 1) of chunk c of the strip
   auto load_row = [&](RowOp& r, int n, int yb, int x0, int c, int wr) __attribute__((always_inline)) {
     const int iy = yb - 1 + wr;
-    const bool ok = iy >= 0 && iy < d.H && c * 32 + kg * 8 < d.Cin;
+    const int kgc = DUAL ? (kg & 1) : kg;  // pair flavour (16 channels): k-groups 2-3 carry the same channels as 0-1
+    const bool ok = iy >= 0 && iy < d.H && c * 32 + kgc * 8 < d.Cin;
     const char* base = reinterpret_cast<const char*>(d.in) +
-                       ((((long long)n * d.H + iy) * d.W + x0 + lr) * d.in_cs + d.in_co) * 4 + c * 128 + kg * 16;
+                       ((((long long)n * d.H + iy) * d.W + x0 + lr) * d.in_cs + d.in_co) * 4 + c * 128 + kgc * 16;
     const char* p = ok ? base : zero;
     r.c = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + half : zero)};
     if (lr == 0 || lr == 15) {
@@ -194,18 +207,42 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- output rows 2p, 2p + 1: window rows 2p + ky and 2p + 1 + ky; every weight fragment serves both ----
+      auto tap_operand = [&](const RowOp& r, int kx) __attribute__((always_inline)) {
+        if (kx == 1) return r.c;
+        return Frag{dpp_shift(r.e.hi, r.c.hi, kx == 0), dpp_shift(r.e.lo, r.c.lo, kx == 0)};
+      };
+      if constexpr (DUAL) {
+        // two taps per MFMA: lanes of k-groups 0-1 take tap 2j's pixel, lanes of k-groups 2-3 tap 2j + 1's (the ninth tap
+        // shares its MFMA with zero weights)
+        auto pick = [&](const Frag& a, const Frag& b) __attribute__((always_inline)) {
+          const u32x4 ah = __builtin_bit_cast(u32x4, a.hi), al = __builtin_bit_cast(u32x4, a.lo);
+          const u32x4 bh = __builtin_bit_cast(u32x4, b.hi), bl = __builtin_bit_cast(u32x4, b.lo);
+          u32x4 h, l;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { h[q] = kg < 2 ? ah[q] : bh[q]; l[q] = kg < 2 ? al[q] : bl[q]; }
+          return Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+        };
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int ta = 2 * j, tb = 2 * j + 1 < 9 ? 2 * j + 1 : 2 * j;
+          const Frag a0 = pick(tap_operand(R[2 * p + ta / 3], ta % 3), tap_operand(R[2 * p + tb / 3], tb % 3));
+          const Frag a1 = pick(tap_operand(R[2 * p + 1 + ta / 3], ta % 3), tap_operand(R[2 * p + 1 + tb / 3], tb % 3));
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const Frag wf = P::load(wlane, (size_t)img, (size_t)(j * 4 * CW + t * 16) * 16);
+            acc[2 * p][t] = P::mma(wf, a0, acc[2 * p][t]);
+            acc[2 * p + 1][t] = P::mma(wf, a1, acc[2 * p + 1][t]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const RowOp& ra = R[2 * p + ky];
         const RowOp& rb = R[2 * p + 1 + ky];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          Frag a0, a1;
-          if (kx == 1) { a0 = ra.c; a1 = rb.c; }
-          else {
-            a0 = Frag{dpp_shift(ra.e.hi, ra.c.hi, kx == 0), dpp_shift(ra.e.lo, ra.c.lo, kx == 0)};
-            a1 = Frag{dpp_shift(rb.e.hi, rb.c.hi, kx == 0), dpp_shift(rb.e.lo, rb.c.lo, kx == 0)};
-          }
+          const Frag a0 = tap_operand(ra, kx), a1 = tap_operand(rb, kx);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const Frag wf = P::load(wc, (size_t)img, (size_t)((ky * 3 + kx) * 4 * CW + t * 16) * 16);
@@ -214,6 +251,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
       if constexpr (HAS2) {
         if (last_pass) {
@@ -288,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
 
 size_t direct_lds_bytes(const TapConv& d) {
   const int nck = (d.Cin + 31) / 32, CW = d.dual ? 2 * d.Cout : d.Cout;
-  size_t b = (size_t)2 * nck * 36 * CW * 16 + (d.in2 ? (size_t)2 * 4 * CW * 16 : 0);
+  size_t b = (d.dual ? (size_t)2 * 5 * 4 * CW * 16 : (size_t)2 * nck * 36 * CW * 16) + (d.in2 ? (size_t)2 * 4 * CW * 16 : 0);
   b += d.fuse_out ? (32 + 128 + 4) * 4 : (size_t)(CW + 2 * (d.N < NPOST ? d.N : NPOST) * d.Cout) * 4;
   return b;
 }
@@ -332,6 +370,7 @@ bool drs_conv3x3_direct_sp_supported(const TapConv& d, int impl) {
   if ((d.W & 15) || (d.H % RB) || d.H < 64 || d.TH != d.H || d.TW != d.W || d.OH != d.H || d.OW != d.W) return false;
   if (d.in2 && (d.Cin2 > 32 || d.H2 != d.H || d.W2 != d.W)) return false;
   if (d.Cout != 32) return false;
+  if (d.dual && (d.Cin != 16 || d.in_cs != 16)) return false;  // (the pair flavour packs two taps of 16 channels into one MFMA)
   TapConv worst = d;
   worst.N = NPOST;
   return direct_lds_bytes(worst) <= 156 * 1024;
