@@ -3,17 +3,21 @@
 // blocks, ups.*.conv, up_convs.*; reference UNet_model_superres.py:153-172,197-207,377).
 //
 // Same GEMM view, MFMA schedule and weight ring as tapconv_ws_kernel (conv_mfma_ws.hip); what is gone is every
-// conversion: the producers stored the operand halves, so the mover waves LDS-DMA the input window STRAIGHT INTO THE
-// OPERAND IMAGE (global_load_lds_dwordx4, whole 128-byte lines: 8 pixels x [4 hi slots | 4 lo slots] per instruction), and
-// the consumer waves only read fragments and issue MFMAs.  Zero padding costs nothing either: a lane whose window pixel
-// lies outside the image (or whose channels lie beyond Cin) takes a line of zeros as its source address.
-//   block = 12 waves on one CU: 8 consumer waves (2 per SIMD) + 4 mover waves (1 per SIMD, no vector registers to speak of)
+// conversion: the producers stored the operand halves, so the mover waves copy the input window STRAIGHT INTO THE OPERAND
+// IMAGE (whole 128-byte lines: 8 pixels x [4 hi slots | 4 lo slots] per instruction, global -> registers a step ahead ->
+// ds_write_b128; LDS-DMA was measured and is 3x slower per wave, see the mover section), and the consumer waves only read
+// fragments and issue MFMAs.  Zero padding costs nothing either: a lane whose window pixel lies outside the image (or
+// whose channels lie beyond Cin) takes a line of zeros as its source address.
+//   block = 12 waves on one CU: 8 consumer waves (2 per SIMD) + 4 mover waves (1 per SIMD)
 //   LDS   = 2 window buffers x 41 KB (double-buffered: window k+1 lands while window k is multiplied)
-//           + weight ring of the 3 kernel columns (72 KB at 64 output channels per block) + 5 counters = 154 KB
+//           + weight ring of the 3 kernel columns (72 KB at 64 output channels per block) + 10 counters
+//           + 2 slots of per-item epilogue constants = 156 KB
 //   step k (one 32-channel K-chunk of one 16x16 patch): NO block-wide barrier, ten monotonic LDS counters ("landed" /
 //   "released" per window buffer and per weight ring slot; protocol at the mover loop).  Waves drift apart by up to a
-//   step: while one wave of a SIMD waits for fragments or writes its tile out, its partner's MFMAs keep the pipe busy
-//   (with a barrier per step both waves of a SIMD stalled and multiplied at the same times: 65 % pipe occupancy).
+//   step: while one wave of a SIMD waits for fragments or writes its tile out, its partner's MFMAs keep the pipe busy.
+// In steady state the kernel runs within ~10 % of what the matrix pipe sustains at the clock the chip's power limit
+// allows under this load (tools/micro/cons_loop.hip); the shallow 32-channel layers, where its
+// per-patch costs dominate, go to conv3x3_direct_sp.hip instead.
 // Window image in LDS: like memory, 128 bytes per window pixel (18 x 18 window, row-major) = the pixel's 8 operand slots
 // [hi k-groups 0-3 | lo k-groups 0-3], ROTATED by the pixel index: slot c of pixel p sits at position (c + p) & 7.  The
 // DMA reads whole lines (8 consecutive lanes = one pixel's 128 bytes: full coalescing; without the rotation a fragment
