@@ -31,6 +31,7 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
   char* sWg = sGate + 2 * gate_img;
   char* sWx = sWg + 2 * wg_img;
   char* sRes = sWx + 2 * wx_img;
+  float* sB = reinterpret_cast<float*>(sRes + 2 * wg_img);  // b_gate | b_wg + b_wx | w_psi | b_res | b_psi
   {
     const int tid = threadIdx.x;
     auto copy = [&](char* dst, const void* src, int bytes) {  // 8 loads in flight per thread (not a round trip per 8 KB)
@@ -52,6 +53,14 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
     copy(sWg, d.w_wg, 2 * wg_img);
     copy(sWx, d.w_wx, 2 * wx_img);
     copy(sRes, d.w_res, 2 * wg_img);
+    // bias vectors: a global load inside an item is a memory round trip on the wave's critical path (five of them per item)
+    for (int i = tid; i < Ch; i += 512) {
+      sB[i] = d.b_gate[i];
+      sB[Ch + i] = d.b_wg[i] + d.b_wx[i];
+      sB[2 * Ch + i] = d.w_psi[i];
+      sB[3 * Ch + i] = d.b_res[i];
+    }
+    if (tid == 0) sB[4 * Ch] = d.b_psi[0];
   }
   __syncthreads();
 
@@ -98,8 +107,8 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
     typename P::Frag gfr[NC];
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
-      const float4 b0 = *reinterpret_cast<const float4*>(d.b_gate + cc * 32 + kg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(d.b_gate + cc * 32 + kg * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(sB + cc * 32 + kg * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(sB + cc * 32 + kg * 8 + 4);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       float v[8];
 #pragma unroll
@@ -133,14 +142,14 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       const int ch = (tt >> 1) * 32 + kg * 8 + (tt & 1) * 4;
-      const float4 bg = *reinterpret_cast<const float4*>(d.b_wg + ch), bx = *reinterpret_cast<const float4*>(d.b_wx + ch);
-      const float4 wp = *reinterpret_cast<const float4*>(d.w_psi + ch);
-      dot += fmaxf(acc[tt][0] + bg.x + bx.x, 0.f) * wp.x + fmaxf(acc[tt][1] + bg.y + bx.y, 0.f) * wp.y +
-             fmaxf(acc[tt][2] + bg.z + bx.z, 0.f) * wp.z + fmaxf(acc[tt][3] + bg.w + bx.w, 0.f) * wp.w;
+      const float4 bs = *reinterpret_cast<const float4*>(sB + Ch + ch);
+      const float4 wp = *reinterpret_cast<const float4*>(sB + 2 * Ch + ch);
+      dot += fmaxf(acc[tt][0] + bs.x, 0.f) * wp.x + fmaxf(acc[tt][1] + bs.y, 0.f) * wp.y +
+             fmaxf(acc[tt][2] + bs.z, 0.f) * wp.z + fmaxf(acc[tt][3] + bs.w, 0.f) * wp.w;
     }
     dot += __shfl_xor(dot, 16);
     dot += __shfl_xor(dot, 32);
-    const float psi = 1.f / (1.f + expf(-(dot + d.b_psi[0])));
+    const float psi = 1.f / (1.f + expf(-(dot + sB[4 * Ch])));
     if (d.psi_out && valid && kg == 0) d.psi_out[((size_t)n * d.LH + y) * d.LW + px] = psi;
     // ---- att = psi * (W' x_res) + b' for the 4 pixels, stored as SP halves into the concat slice ----
 #pragma unroll
@@ -156,8 +165,8 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
       char* o = reinterpret_cast<char*>(d.out) + (pix * d.out_cs + d.out_co) * 4 + kg * 16;
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) {
-        const float4 b0 = *reinterpret_cast<const float4*>(d.b_res + cc * 32 + kg * 8);
-        const float4 b1 = *reinterpret_cast<const float4*>(d.b_res + cc * 32 + kg * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(sB + 3 * Ch + cc * 32 + kg * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(sB + 3 * Ch + cc * 32 + kg * 8 + 4);
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float v[8];
 #pragma unroll
@@ -186,6 +195,15 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
   constexpr int Ch = 128, NG = 4;
   __shared__ __attribute__((aligned(16))) char sG[4 * NG * 2 * 4 * 16 * 16];  // [pixel block 4][chunk 4][hi | lo][k-group 4][pixel 16]
   __shared__ float sPsi[NG][64];
+  __shared__ __attribute__((aligned(16))) float sB[4 * 128 + 4];  // b_gate | b_wg + b_wx | w_psi | b_res | b_psi
+  for (int i = threadIdx.x; i < Ch; i += 512) {
+    sB[i] = d.b_gate[i];
+    sB[Ch + i] = d.b_wg[i] + d.b_wx[i];
+    sB[2 * Ch + i] = d.w_psi[i];
+    sB[3 * Ch + i] = d.b_res[i];
+  }
+  if (threadIdx.x == 0) sB[4 * Ch] = d.b_psi[0];
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, kg = lane >> 4;
   const int cg = wave & 3, pb2 = wave >> 2;
@@ -255,8 +273,8 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
       }
     }
     {
-      const float4 b0 = *reinterpret_cast<const float4*>(d.b_gate + cg * 32 + kg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(d.b_gate + cg * 32 + kg * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(sB + cg * 32 + kg * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(sB + cg * 32 + kg * 8 + 4);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -319,12 +337,10 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
       const int ch = cg * 32 + kg * 8;
       float wp[8], bsum[8];
       {
-        const float4 a0 = *reinterpret_cast<const float4*>(d.w_psi + ch), a1 = *reinterpret_cast<const float4*>(d.w_psi + ch + 4);
-        const float4 g0 = *reinterpret_cast<const float4*>(d.b_wg + ch), g1 = *reinterpret_cast<const float4*>(d.b_wg + ch + 4);
-        const float4 x0 = *reinterpret_cast<const float4*>(d.b_wx + ch), x1 = *reinterpret_cast<const float4*>(d.b_wx + ch + 4);
+        const float4 a0 = *reinterpret_cast<const float4*>(sB + 2 * Ch + ch), a1 = *reinterpret_cast<const float4*>(sB + 2 * Ch + ch + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(sB + Ch + ch), s1 = *reinterpret_cast<const float4*>(sB + Ch + ch + 4);
         wp[0] = a0.x; wp[1] = a0.y; wp[2] = a0.z; wp[3] = a0.w; wp[4] = a1.x; wp[5] = a1.y; wp[6] = a1.z; wp[7] = a1.w;
-        bsum[0] = g0.x + x0.x; bsum[1] = g0.y + x0.y; bsum[2] = g0.z + x0.z; bsum[3] = g0.w + x0.w;
-        bsum[4] = g1.x + x1.x; bsum[5] = g1.y + x1.y; bsum[6] = g1.z + x1.z; bsum[7] = g1.w + x1.w;
+        bsum[0] = s0.x; bsum[1] = s0.y; bsum[2] = s0.z; bsum[3] = s0.w; bsum[4] = s1.x; bsum[5] = s1.y; bsum[6] = s1.z; bsum[7] = s1.w;
       }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -344,13 +360,13 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int i = (pb2 * 2 + b) * 16 + lr;
-      psi[b] = 1.f / (1.f + expf(-(sPsi[0][i] + sPsi[1][i] + sPsi[2][i] + sPsi[3][i] + d.b_psi[0])));
+      psi[b] = 1.f / (1.f + expf(-(sPsi[0][i] + sPsi[1][i] + sPsi[2][i] + sPsi[3][i] + sB[4 * Ch])));
       if (d.psi_out && valid[b] && kg == 0 && cg == 0) d.psi_out[((size_t)nn[b] * d.LH + yy[b]) * d.LW + px[b]] = psi[b];
     }
     // ---- att = psi * (W' x_res) + b' for the 4 pixels under each low-resolution pixel ----
     {
-      const float4 b0 = *reinterpret_cast<const float4*>(d.b_res + cg * 32 + kg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(d.b_res + cg * 32 + kg * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(sB + 3 * Ch + cg * 32 + kg * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(sB + 3 * Ch + cg * 32 + kg * 8 + 4);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       typename P::Frag wr[NG][2];  // the result weights of this wave's channels: the same for all four pixels
 #pragma unroll
@@ -421,7 +437,7 @@ int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
 
 size_t drs_attn_gate_lds_bytes(int Cc, int Ch) {
   // gate Ch x Cc, w_g Ch x Ch, w_x 4 x Ch x Ch, result Ch x Ch, two bf16 images each
-  return (size_t)4 * Ch * ((size_t)Cc + 6 * (size_t)Ch);
+  return (size_t)4 * Ch * ((size_t)Cc + 6 * (size_t)Ch) + (size_t)(4 * Ch + 4) * 4;  // + the bias vectors
 }
 
 bool drs_attn_gate_supported(int Cc, int Ch) {
