@@ -191,7 +191,9 @@ __global__ __launch_bounds__(512, 1) void conv_s2_sp_kernel(TapConv d, int nck, 
 // exactly one of the four phases, and the operands are the four pixels (y, x), (y, x + 1), (y + 1, x), (y + 1, x + 1).
 // Same structure as the stride-2 kernel above: weights resident in LDS, operands global -> registers (two rows of 16
 // pixels per K-chunk; the x + 1 operand is the right neighbour lane: a DPP shift, lanes lr == 15 load the segment's
-// 17th pixel), four accumulator sets, 2x2 output pixels per lane stored as SP lines.  The lock-step kernel ran these
+// 17th pixel), four accumulator sets, 2x2 output pixels per lane stored as SP lines.  A wave item is TWO input rows: three
+// fragment rows feed both, and every weight-fragment read from LDS serves two rows of MFMAs (0.33 instead of 0.67 reads per
+// MFMA: with 36 reads per 54 MFMAs the LDS, not the matrix pipe, set the pace; 75 -> 68 us at 64x64).  The lock-step kernel ran these
 // layers (128 -> 128 at 64x64, 64 -> 64 at 128x128) at 86 / 110 us; 335 MB at 5.7 TB/s would be 59 us for the larger.
 template <int NT>
 __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, unsigned w_gimage) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
   __syncthreads();
 
   const int bw = d.W / 16;  // (W is a multiple of 16: a lane's right neighbour is always a real pixel or the edge load)
-  const int rows = d.N * d.H;
+  const int rows = d.N * (d.H >> 1);  // a wave item = TWO input rows x 16 pixels (H is even): every weight fragment read serves both
   const int r_lo = (int)((long long)rows * xcd / 8), r_hi = (int)((long long)rows * (xcd + 1) / 8);
   const int Q = (r_hi - r_lo) * bw;
   const int stride = members * 8, first = member * 8 + wave;
@@ -220,19 +222,20 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
   const char* zero = reinterpret_cast<const char*>(d.zero_line) + kg * 16;
   const char* wbase = smem + ((size_t)kg * GC + lr) * 16;
 
-  struct Rows { typename P::Frag a[2], e[2]; };  // a[dy]: pixel (y + dy, x); e[dy] (lanes lr == 15): pixel (y + dy, x0 + 16)
+  struct Rows { typename P::Frag a[3], e[3]; };  // a[i]: pixel (y + i, x), i = 0..2; e[i] (lanes lr == 15): pixel (y + i, x0 + 16)
   Rows fa, fb;
   auto issue = [&](int s, Rows& f) __attribute__((always_inline)) {
     const int it = s / nck, c = s - it * nck;
     const int q = first + it * stride;
     const int row = r_lo + q / bw, xb = q - (q / bw) * bw;
-    const int n = row / d.H, y = row - n * d.H;
+    const int hh = d.H >> 1;
+    const int n = row / hh, y = 2 * (row - n * hh);
     const int px = xb * 16 + lr;
     const char* base = reinterpret_cast<const char*>(d.in) +
                        ((((long long)n * d.H + y) * d.W + px) * d.in_cs + d.in_co) * 4 + c * 128 + kg * 16;
     const int rowb = d.W * d.in_cs * 4, pixb = d.in_cs * 4;
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
+    for (int dy = 0; dy < 3; ++dy) {
       const bool row_ok = y + dy < d.H;  // output_padding: the last odd output row / column sees zeros beyond the image
       const char* p = row_ok ? base + dy * rowb : zero;
       f.a[dy] = typename P::Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(row_ok ? p + half : zero)};
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
       o[j] = (unsigned)__builtin_amdgcn_update_dpp((int)e[j], (int)r[j], 0x101, 0xf, 0xf, false);
     return __builtin_bit_cast(bf16x8, o);
   };
-  f32x4 acc[4][NT];
+  f32x4 acc[2][4][NT];  // [input row of the pair][output phase][channel tile]
   float bias8[NT / 2][8];
 #pragma unroll
   for (int pr = 0; pr < NT / 2; ++pr) {
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
     bias8[pr][0] = a.x; bias8[pr][1] = a.y; bias8[pr][2] = a.z; bias8[pr][3] = a.w;
     bias8[pr][4] = b.x; bias8[pr][5] = b.y; bias8[pr][6] = b.z; bias8[pr][7] = b.w;
   }
-  auto store_item = [&](int n, int y, int x0) __attribute__((always_inline)) {
+  auto store_item = [&](int r, int n, int y, int x0) __attribute__((always_inline)) {
     const bool lo = lr < 8;
     const int pl = lr & 7;
 #pragma unroll
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
       for (int pr = 0; pr < NT / 2; ++pr) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = acc[ph][2 * pr][j] + bias8[pr][j]; v[4 + j] = acc[ph][2 * pr + 1][j] + bias8[pr][4 + j]; }
+        for (int j = 0; j < 4; ++j) { v[j] = acc[r][ph][2 * pr][j] + bias8[pr][j]; v[4 + j] = acc[r][ph][2 * pr + 1][j] + bias8[pr][4 + j]; }
         u32x4 H, L;
         drs_sp_split8(v, H, L);
         const u32x4 got = drs_dpp_swap8(lo ? L : H);
@@ -286,17 +289,21 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
     const int it = s / nck, c = s - it * nck;
     if (c == 0) {
 #pragma unroll
-      for (int ph = 0; ph < 4; ++ph)
+      for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[ph][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[r][ph][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const char* wc = wbase + (size_t)c * 36 * GC * 16;
+    // input row r of the pair takes tap row dy from fragment row r + dy: three fragment rows serve both
+    typename P::Frag right[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) right[i] = typename P::Frag{shift_in(f.e[i].hi, f.a[i].hi), shift_in(f.e[i].lo, f.a[i].lo)};
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-      const typename P::Frag right{shift_in(f.e[dy].hi, f.a[dy].hi), shift_in(f.e[dy].lo, f.a[dy].lo)};
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
-        const typename P::Frag& a = dx == 0 ? f.a[dy] : right;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -306,7 +313,8 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
               const typename P::Frag wf = P::load(wc, (size_t)img, (size_t)((ky * 3 + kx) * 4 * GC + t * 16) * 16);
-              acc[ph][t] = P::mma(wf, a, acc[ph][t]);
+#pragma unroll
+              for (int r = 0; r < 2; ++r) acc[r][ph][t] = P::mma(wf, dx == 0 ? f.a[r + dy] : right[r + dy], acc[r][ph][t]);
             }
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -315,8 +323,10 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
     if (c == nck - 1) {
       const int q = first + it * stride;
       const int row = r_lo + q / bw, xb = q - (q / bw) * bw;
-      const int n = row / d.H, y = row - n * d.H;
-      store_item(n, y, xb * 16);
+      const int hh = d.H >> 1;
+      const int n = row / hh, y = 2 * (row - n * hh);
+      store_item(0, n, y, xb * 16);
+      store_item(1, n, y + 1, xb * 16);
     }
   };
   issue(0, fa);
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
 
 template <int NT, bool CONVT = false>
 int s2_launch(const TapConv& d, int nck, unsigned w_gimage, hipStream_t s) {
-  auto kern = CONVT ? convt_sp_kernel<NT> : conv_s2_sp_kernel<NT>;
+  auto kern = CONVT ? convt_sp_kernel<2> : conv_s2_sp_kernel<NT>;
   const size_t lds = (size_t)2 * nck * 36 * 16 * NT * 16;
   int num_cu = 0;
   {
@@ -386,13 +396,13 @@ bool drs_convt_sp_supported(const TapConv& d, int impl) {
     if (d.wtap[i] != i) return false;
   if (d.in2 || d.out2 || d.fuse_out || d.dual || d.gate || d.in_add || d.res || d.sigmoid || d.out_nchw) return false;
   if (d.post_add || d.bias2 || d.relu_pre || d.relu_post) return false;
-  if ((d.W & 15) || d.OH != 2 * d.H || d.OW != 2 * d.W || d.TH != d.H || d.TW != d.W) return false;
+  if ((d.W & 15) || (d.H & 1) || d.OH != 2 * d.H || d.OW != 2 * d.W || d.TH != d.H || d.TW != d.W) return false;
   if (d.Cin % 32 || d.Cout % 32 || (d.in_cs & 31) || (d.in_co & 31) || (d.out_cs & 31) || (d.out_co & 31)) return false;
-  return s2_tiles(d) != 0;
+  return (size_t)2 * (d.Cin / 32) * 36 * 32 * 16 <= 156 * 1024;
 }
 
 int drs_launch_convt_sp(const TapConv& d, hipStream_t s) {
   const int nck = d.Cin / 32;
   const unsigned w_gimage = (unsigned)((size_t)nck * 9 * 4 * d.Cout * 16);
-  return s2_tiles(d) == 4 ? s2_launch<4, true>(d, nck, w_gimage, s) : s2_launch<2, true>(d, nck, w_gimage, s);
+  return s2_launch<2, true>(d, nck, w_gimage, s);  // (two rows per wave: 32 channels per block keep the accumulators at 64 registers)
 }
