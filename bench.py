@@ -400,6 +400,18 @@ def main():
                 if q is not None:
                     result["psnr_vs_ref_db"] = q["psnr_db"]
                     result["psnr_detail"] = q
+                if world == 1:
+                    # a full sample() of T - 1 = 1499 steps at configs[1] (16 images, one cached LR image):
+                    # the end-to-end chain the reference's callers run, wall clock incl. the conditioning branch
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    out = diffusion.sample(BATCH, model, lr_cpu[0], input_channels=3)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                    model.eval()
+                    result["full_chain"] = {"steps": T_STEPS - 1, "seconds": round(dt, 3),
+                                            "batch16_steps_per_s": round((T_STEPS - 1) / dt, 2),
+                                            "finite": bool(torch.isfinite(out).all().item())}
                 if args.impl != "mfma_f32":
                     # the exact-fp32 line beside the headline (same step, v_mfma_f32_16x16x4_f32 kernels): what the
                     # precision choice buys, in the driver's own record
