@@ -94,7 +94,8 @@ struct SpGeom {
   static constexpr int WBUF = NBLK * 1024;         // bytes of one window buffer
   static constexpr int BNB = BNB_;
   static constexpr int W_IMAGE = 9 * 4 * BNB * 16;  // one operand image (hi or lo) of a chunk's weights
-  static constexpr int LDS = 2 * WBUF + 2 * W_IMAGE + 64;
+  static constexpr int EPI = 768;                   // bytes of one slot of per-item epilogue constants (two slots)
+  static constexpr int LDS = 2 * WBUF + 2 * W_IMAGE + 64 + 2 * EPI;
 };
 
 template <bool HAS2, int BNB_, bool FUSE, bool DUAL>
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(512, 1) void tapconv_sp1_kernel(TapConv d, MfmaGeom
   sp_flag_ptr sCL = sCR + 3;                          // CL[3]: mover waves whose part of weight column j has landed
   sp_flag_ptr sWL = sCR + 6;                          // WL[2]: mover waves whose part of window buffer b has landed
   sp_flag_ptr sWR = sCR + 8;                          // WR[2]: consumer waves that have finished reading window buffer b
+  float* sEpi = reinterpret_cast<float*>(sW + 2 * W_IMAGE + 64);  // per-item epilogue constants (conv_sp_movers.inc)
+  constexpr int EC = DUAL ? 64 : BNB;
 
 #ifdef DRS_SP_TIMELINE
   const bool sp_free_run = (g.debug & 16) != 0, sp_mute = (g.debug & 32) != 0;
@@ -156,178 +159,11 @@ __global__ __launch_bounds__(512, 1) void tapconv_sp1_kernel(TapConv d, MfmaGeom
   int c = -1, ord = -1, n = 0, ty0 = 0, tx0 = 0, n0 = 0;  // current step: chunk, item ordinal, item coordinates
 
   if (mover) {
-    // ===================== movers =====================
-    // Everything goes global -> REGISTERS -> LDS.  Measured on this kernel: one wave sustains about one 1 KB LDS-DMA
-    // instruction per 300 cycles (each seems to wait for the previous one to land), 3.4 bytes per cycle and wave, whatever
-    // else the CU or the chip is doing, so four movers cannot bring in the 113 KB a step needs (41 KB window + 72 KB
-    // weights) next to 6.9 k cycles of MFMA.  Plain global loads issue ~3x faster and need no LDS slot while in flight:
-    // the operands of step k+1 are prefetched into the movers' registers a whole step ahead and written into the window
-    // buffer / a weight ring slot the moment the consumers have released it (~100 cycles instead of a memory round trip).
-    // Protocol (step k = one K-chunk of one patch; window buffer k & 1; weight ring slot j = kernel column j), mover M(k)
-    // fills step k:   loads: column 0, window, column 1 (in the order the stores need them; column 2 follows the store
-    //                 of column 0 into the same registers)
-    //                 wait CR0 (every consumer holds column 0 of step k-1 in registers) -> store column 0 -> CL0
-    //                 wait WR[k&1] (the consumers left the buffer in step k-2)           -> store window   -> WL[k&1]
-    //                 wait CR1 -> store column 1 -> CL1;  wait CR2 -> store column 2 -> CL2
-    //   consumer(k):  wait WL[k&1], CL0 -> read column 0 -> CR0 -> MFMA | wait CL1 -> read -> CR1 -> MFMA | wait CL2 ->
-    //                 read -> CR2 -> MFMA -> WR[k&1] -> epilogue of the item
-    // Every wait is for an event whose own prerequisites lie strictly earlier in this order: no cycle.  Counters are
-    // bumped with release semantics after the ds_writes have completed (lgkmcnt(0)).
-    const int pw = wid - NCONS;
-    // Default priority: with one consumer wave per SIMD the movers get the issue slots they need between two MFMAs; raised
-    // priority (what the two-consumer kernel needs) costs the consumer 0.9 k ticks per step here.
-#ifdef DRS_SP_TIMELINE
-    if (g.debug & 8) __builtin_amdgcn_s_setprio(3);
-#endif
-    const char* wg = reinterpret_cast<const char*>(d.w);
-    const size_t w_chunk = (size_t)9 * 4 * wcout * 16;
-    const size_t w_gimage = DUAL ? 2 * (size_t)g.w_gimage : (size_t)g.w_gimage;  // (the geometry was sized for d.Cout channels)
-    const char* zero = reinterpret_cast<const char*>(d.zero_line) + (lane & 15) * 16;
-    // this lane's role inside a window piece (8 pixels x 128 bytes): lanes 8*px .. 8*px + 7 fetch the 8 operand slots of
-    // pixel px = ONE 128-byte line (coalesced), rotated by px: LDS slot s of the pixel holds operand slot (s - px) & 7
-    const int l_px = lane >> 3, l_c = ((lane & 7) - l_px) & 7, l_img = l_c >> 2, l_kg = l_c & 3;
-    const int half1 = drs_sp_group_bytes(d.in_cs), half2 = HAS2 ? drs_sp_group_bytes(d.in2_cs) : 0;
-    const int l_off1 = l_img * half1 + l_kg * 16, l_off2 = l_img * half2 + l_kg * 16;
-    constexpr int NPW = (NBLK + 3) / 4;  // window pieces per mover wave (at most): blocks pw + 4*i
-    static_assert(NBLK == 4 * (NPW - 1) + 1, "piece distribution: the last round holds block NBLK - 1 only, owned by mover 0");
-    // per-lane byte offsets of this wave's window pixels relative to the window origin, computed ONCE (32 bits: a tensor
-    // spans less than 2 GB): the per-step work of the fast path is one scalar base pointer + one load per piece
-    int off1[NPW];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      const int p = (pw + 4 * i) * 8 + l_px;
-      const int py = (p * 3641) >> 16, px = p - py * IW;  // p / 18 (exact for p < 1024)
-      off1[i] = ((py * d.W + px) * d.in_cs) * 4 + l_off1;
-    }
-    const bool tail_ok = (NBLK - 1) * 8 + l_px < G::NPIX;  // the last block is half empty
-    constexpr int WPC = BNB == 64 ? 6 : 3;  // weight pieces (1 KB) per mover wave and kernel column
-    u32x4 wr[2][WPC], ww[NPW];  // column registers: column 2 re-uses column 0's once that one is stored
-    // weight piece i of column col: source address and LDS destination of this lane's 16 bytes
-    // Address of a weight piece = scalar base of the step (chunk, channel group) + scalar offset of the piece (operand
-    // image, kernel row / column, k-group: 32 bits) + this lane's constant byte offset: no per-lane 64-bit arithmetic
-    // inside the step loop.
-    const unsigned lane_w = BNB == 64 ? (unsigned)lane * 16u : (unsigned)(((lane >> 5) * d.Cout + (lane & 31)) * 16);
-    auto piece = [&](int col, bool second, int cc, int n0_, int i, const char*& src, char*& dst) __attribute__((always_inline)) {
-      int im, ky, kq;  // operand image, kernel row, (first) k-group of the piece: wave-uniform
-      if constexpr (BNB == 64) {  // piece = one (image, ky, k-group) row of 64 channels; second input: (image, k-group)
-        const int idx = pw * (second ? 2 : WPC) + i;
-        im = second ? idx >> 2 : idx / 12; ky = second ? 0 : (idx % 12) >> 2; kq = idx & 3;
-      } else {  // piece = two consecutive k-group rows of 32 channels
-        const int row0 = (pw * (second ? 1 : WPC) + i) * 2;
-        im = second ? row0 >> 2 : row0 / 12; ky = second ? 0 : (row0 % 12) >> 2; kq = row0 & 3;
-      }
-      const char* base = second ? reinterpret_cast<const char*>(d.w2) + (size_t)cc * 4 * wcout * 16 + (size_t)n0_ * 16
-                                : wg + (size_t)cc * w_chunk + (size_t)n0_ * 16;
-      const unsigned soff = second ? (unsigned)im * (unsigned)g.w2_gimage + (unsigned)(kq * wcout * 16)
-                                   : (unsigned)im * (unsigned)w_gimage + (unsigned)(((ky * 3 + col) * 4 + kq) * wcout * 16);
-      src = base + soff + lane_w;
-      dst = sW + im * W_IMAGE + (((second ? 0 : col) * 3 + ky) * 4 + kq) * BNB * 16 + lane * 16;
-    };
-    const int nwin = pw == 0 ? NPW : NPW - 1;  // window pieces of this wave
-    for (int k = 0; k < S; ++k) {
-      if (++c == nck) c = 0;
-      if (c == 0) item_of(++ord, n, ty0, tx0, n0);
-      const bool second = HAS2 && c >= g.nchunks;
-      const int cc = second ? c - g.nchunks : c;
-      // pieces per column (the second input has one tap: column 0 only)
-      int np[3];
-#pragma unroll
-      for (int col = 0; col < 3; ++col) {
-        np[col] = second ? (col == 0 ? (BNB == 64 ? 2 : 1) : 0) : WPC;
-#ifdef DRS_SP_TIMELINE
-        if (g.debug & 2) np[col] = 0;
-#endif
-      }
-      auto load_col = [&](int col) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < WPC; ++i)
-          if (i < np[col]) {
-            const char* src; char* dst;
-            piece(col, second, cc, n0, i, src, dst);
-            wr[col & 1][i] = *reinterpret_cast<const u32x4*>(src);
-          }
-      };
-      auto store_col = [&](int col) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < WPC; ++i)
-          if (i < np[col]) {
-            const char* src; char* dst;
-            piece(col, second, cc, n0, i, src, dst);
-            *reinterpret_cast<u32x4*>(dst) = wr[col & 1][i];
-          }
-        sp_wait_lds();
-        if (lane == 0) sp_bump(sCL + col);
-      };
-      SP_STAMP(7);
-      load_col(0);
-      // ---- window loads ----
-#ifdef DRS_SP_TIMELINE
-      const bool skip_win = (g.debug & 1) != 0;
-#else
-      const bool skip_win = false;
-#endif
-      if (skip_win) {
-      } else if (!second && ty0 >= 1 && ty0 + TH + 1 <= d.H && tx0 >= 1 && tx0 + TW + 1 <= d.W && cc * KC + KC <= d.Cin) {
-        // fast path: every window pixel inside the image, every k-group inside the channel count
-        const char* base = reinterpret_cast<const char*>(d.in) +
-                           ((((long long)n * d.H + (ty0 - 1)) * d.W + (tx0 - 1)) * d.in_cs + d.in_co) * 4 + cc * 128;
-#pragma unroll
-        for (int i = 0; i < NPW - 1; ++i) ww[i] = *reinterpret_cast<const u32x4*>(base + (unsigned)off1[i]);
-        if (pw == 0) ww[NPW - 1] = *reinterpret_cast<const u32x4*>(tail_ok ? base + (unsigned)off1[NPW - 1] : zero);
-      } else {
-        // border patches, partial K-chunks, the second input: per-lane validity; anything invalid reads the zero line
-        const bool ch_ok = cc * KC + l_kg * 8 < (second ? d.Cin2 : d.Cin);
-#pragma unroll
-        for (int i = 0; i < NPW; ++i)
-          if (i < nwin) {
-            const int p = (pw + 4 * i) * 8 + l_px;
-            const int py = (p * 3641) >> 16, px = p - py * IW;
-            const char* src;
-            bool ok;
-            if (!second) {
-              const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-              ok = ch_ok && p < G::NPIX && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-              src = reinterpret_cast<const char*>(d.in) +
-                    ((((long long)n * d.H + iy) * d.W + ix) * d.in_cs + d.in_co) * 4 + cc * 128 + l_off1;
-            } else {
-              const int iy = ty0 + py, ix = tx0 + px;
-              ok = ch_ok && py < TH && px < TW && iy < d.H2 && ix < d.W2;
-              src = reinterpret_cast<const char*>(d.in2) +
-                    ((((long long)n * d.H2 + iy) * d.W2 + ix) * d.in2_cs + d.in2_co) * 4 + cc * 128 + l_off2;
-            }
-            ww[i] = *reinterpret_cast<const u32x4*>(ok ? src : zero);
-          }
-      }
-      load_col(1);
-      SP_STAMP(0);
-      // ---- stores, each as soon as its destination is free and its loads have landed (in-order vector-memory counter) ----
-      if (k >= 1) if (!SP_FREE) sp_poll(sCR, (unsigned)NCONS * (unsigned)k);
-      SP_STAMP(1);
-      sp_wait_vm(nwin + np[1]);
-      store_col(0);
-      load_col(2);  // into column 0's registers; needed two thirds of a step from now
-      SP_STAMP(2);
-      if (k >= 2) if (!SP_FREE) sp_poll(sWR + (k & 1), (unsigned)NCONS * (unsigned)(k >> 1));
-      sp_wait_vm(np[1] + np[2]);
-      {
-        char* buf = sWin + (k & 1) * WBUF + lane * 16;
-#pragma unroll
-        for (int i = 0; i < NPW; ++i)
-          if (i < nwin && !skip_win) *reinterpret_cast<u32x4*>(buf + (pw + 4 * i) * 1024) = ww[i];
-        sp_wait_lds();
-        if (lane == 0) sp_bump(sWL + (k & 1));
-      }
-      SP_STAMP(3);
-      if (k >= 1) if (!SP_FREE) sp_poll(sCR + 1, (unsigned)NCONS * (unsigned)k);
-      SP_STAMP(4);
-      sp_wait_vm(np[2]);
-      store_col(1);
-      if (k >= 1) if (!SP_FREE) sp_poll(sCR + 2, (unsigned)NCONS * (unsigned)k);
-      SP_STAMP(5);
-      sp_wait_vm(0);
-      store_col(2);
-      SP_STAMP(6);
-    }
+#define SP_NCONS 4
+#define SP_MOVER_PRIO 0  // (raised priority, what the two-consumer kernel needs, costs this one 0.9 k ticks per step)
+#include "conv_sp_movers.inc"
+#undef SP_NCONS
+#undef SP_MOVER_PRIO
   } else {
     // ===================== consumers =====================
     const int rw = NRW == 2 ? (wid & 1) : (wid & 3);  // row-wave: rows [rw*RPW, rw*RPW + RPW) of the patch
@@ -472,6 +308,8 @@ __global__ __launch_bounds__(512, 1) void tapconv_sp1_kernel(TapConv d, MfmaGeom
         // out of the step loop (where it would be spilled and reloaded between the stores)
         int lr_e = lr, kg_e = kg;
         asm volatile("" : "+v"(lr_e), "+v"(kg_e));
+        // (this variant keeps the epilogue that loads its constants from memory: with the primed fragment registers of the next
+        // item live across it, the LDS-constant form of conv_sp_item_epilogue.inc spills 59 registers here)
         if constexpr (DUAL) {
           // out = relu(main + b_main) + post_add + (skip + b_skip): tiles t (main) and t + 2 (skip) of the same lane;
           // channel of (tile t, register j) in SP order: kg*8 + t*4 + j
