@@ -6,7 +6,9 @@ cd "$(dirname "$0")/../diffusionremotesensing_amd/csrc"
 mkdir -p build_tl
 for f in *.hip; do
   o=build_tl/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ conv_epilogue.h -nt "$o" ] || [ drs_common.h -nt "$o" ]; then
+  stale=0
+  for h in *.h *.inc; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDRS_SP_TIMELINE -c "$f" -o "$o" &
   fi
 done
