@@ -41,6 +41,8 @@ SIGNATURES = {
     "drs_aggregate_tiles": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "drs_conv2d_workspace_bytes": (_Z, [_I] * 11),
     "drs_conv2d_nchw": (_I, [_P, _P, _P, _P] + [_I] * 12 + [_P, _Z, _I, _P]),
+    "drs_upconv_fused_workspace_bytes": (_Z, [_I] * 5),
+    "drs_upconv_fused_nchw": (_I, [_P] * 9 + [_I] + [_P, _P] + [_I] * 5 + [_P, _Z, _P]),
     "drs_bicubic_upsample_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "drs_time_mlp": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "drs_unet_plan_create": (_I, [C.POINTER(_P), C.POINTER(UNetConfig)]),
@@ -60,6 +62,7 @@ SIGNATURES = {
     "drs_unet_packed_bwd_bytes": (_Z, [_P]),
     "drs_unet_backward": (_I, [_P, _P, _P, _Z, _P, _P, _P, C.POINTER(_P), _P, _Z, _P]),
     "drs_unet_backward_labels": (_I, [_P, _P, _P, _Z, _P, _P, _P, _I, _P, C.POINTER(_P), _P, _Z, _P]),
+    "drs_unet_check_faults": (_I, [_P, _P, _P]),
     "drs_unet_profile_enable": (_I, [_P, _I]),
     "drs_unet_profile_num_ops": (_I, [_P]),
     "drs_unet_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

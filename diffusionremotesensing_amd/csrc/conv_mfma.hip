@@ -531,8 +531,7 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_conv3x3_direct_sp_supported(d, impl))
     return drs_launch_conv3x3_direct_sp(d, s);
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_sp_supported(d, impl)) {
-    static const int spk = getenv("DRS_SPK") ? atoi(getenv("DRS_SPK")) : 1;
-    return (spk == 2 && !d.dual) ? drs_launch_tapconv_sp1(d, g, s) : drs_launch_tapconv_sp(d, g, s);
+    return drs_launch_tapconv_sp(d, g, s);
   }
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_ws_supported(d, impl))
     return drs_launch_tapconv_ws(d, g, impl, s);
@@ -553,7 +552,9 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
                                       char* __restrict__ dst_w, float* __restrict__ dst_b, int Cout, int Cin, int taps,
                                       int transposed, int nchunks, size_t image_bytes, int cout_src, int flip_taps, int co_off,
-                                      int partial, int perm) {
+                                      int partial, int perm, int cin_total, int cin_off) {
+  // cin_total > 0: the source has cin_total input channels of which [cin_off, cin_off + Cin) are packed (one half of a
+  // convolution over a channel concatenation); not for transposed sources
   // cout_src < Cout: the source has only cout_src output channels; the rest of the image is zero (a 16-channel
   // output padded to the kernel's 32-channel tile)
   constexpr int KC = 4 * P::SLOT_CH;
@@ -583,7 +584,7 @@ __global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* 
       float v = 0.f;
       if (ci < Cin && co >= 0 && co < cout_src) {
         const size_t src = transposed ? (((size_t)ci * cout_src + co) * taps + tap_src)
-                                      : (((size_t)co * Cin + ci) * taps + tap_src);
+                                      : (((size_t)co * (cin_total > 0 ? cin_total : Cin) + cin_off + ci) * taps + tap_src);
         v = w[src];
         if (gamma) v *= sc;
       }
@@ -614,7 +615,7 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl) {
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
                               int transposed, int impl, hipStream_t s, int cout_src, int flip_taps, int co_off, int partial,
-                              int perm) {
+                              int perm, int cin_total, int cin_off) {
   if (cout_src <= 0) cout_src = Cout;
   const int KC = 4 * slot_ch(impl);
   const int nchunks = drs_cdiv(Cin, KC);
@@ -625,7 +626,8 @@ int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma
   if (blocks < 1) blocks = 1;
 #define DRS_PACK(P)                                                                                                   \
   hipLaunchKernelGGL(pack_conv_mfma_kernel<P>, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps,    \
-                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps, co_off, partial, perm)
+                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps, co_off, partial, perm, \
+                     cin_total, cin_off)
   if (impl == DRS_IMPL_MFMA_F32) DRS_PACK(PolicyF32);
   else if (impl == DRS_IMPL_MFMA_F16) DRS_PACK(PolicyF16);
   else DRS_PACK(PolicyBF16X3);

@@ -33,28 +33,9 @@
 
 #include "conv_epilogue.h"
 #include "mfma_policy.h"
+#include "sp_sync.h"
 
 namespace {
-
-__device__ __forceinline__ void sp_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void sp_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform)
-__device__ __forceinline__ void sp_wait_vm(int n) {
-#define DRS_SP_CASE(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
-  switch (n) {
-    DRS_SP_CASE(1) DRS_SP_CASE(2) DRS_SP_CASE(3) DRS_SP_CASE(4) DRS_SP_CASE(5) DRS_SP_CASE(6) DRS_SP_CASE(7)
-    DRS_SP_CASE(8) DRS_SP_CASE(9) DRS_SP_CASE(10) DRS_SP_CASE(11) DRS_SP_CASE(12) DRS_SP_CASE(13) DRS_SP_CASE(14)
-    DRS_SP_CASE(15) DRS_SP_CASE(16) DRS_SP_CASE(17) DRS_SP_CASE(18) DRS_SP_CASE(19) DRS_SP_CASE(20) DRS_SP_CASE(21)
-    DRS_SP_CASE(22) DRS_SP_CASE(23) DRS_SP_CASE(24) DRS_SP_CASE(25) DRS_SP_CASE(26) DRS_SP_CASE(27) DRS_SP_CASE(28)
-    DRS_SP_CASE(29) DRS_SP_CASE(30) DRS_SP_CASE(31)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef DRS_SP_CASE
-}
 
 #ifdef DRS_SP_TIMELINE
 __device__ unsigned long long drs_sp_tl[48];
@@ -63,22 +44,6 @@ __device__ unsigned long long drs_sp_tl[48];
 #define SP_STAMP(i) do { } while (0)
 #endif
 
-typedef __attribute__((address_space(1))) void* sp_gptr;
-typedef __attribute__((address_space(3))) void* sp_lptr;
-typedef __attribute__((address_space(3))) unsigned* sp_flag_ptr;
-
-// spin until the LDS counter *f reaches `target`.  A protocol error must never leave waves spinning on the GPU: after
-// ~2^22 polls (about a second) the wave traps and the launch fails loudly.
-__device__ __forceinline__ void sp_poll(sp_flag_ptr f, unsigned target) {
-  unsigned spins = 0;
-  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-    __builtin_amdgcn_s_sleep(2);
-    if (++spins > (1u << 22)) __builtin_trap();
-  }
-}
-__device__ __forceinline__ void sp_bump(sp_flag_ptr f) {
-  __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 // consumer release of a ring slot + instruction priority for what follows.  The two consumer waves of a SIMD share its
 // matrix pipe and the hardware arbitrates "oldest first": left alone, the older wave runs a column at full speed while the
 // younger one crawls, then blocks one step ahead at the ring and idles while the younger one runs ALONE (LDS latencies
@@ -220,7 +185,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
             if (wr == ky + RPW - 1) {
-              if (ky == 0) sp_poll(sCL + col + 1, ltarget);
+              if (ky == 0) sp_poll(sCL + col + 1, ltarget, d.fault);
 #pragma unroll
               for (int t = 0; t < NT; ++t)
                 wf[ky][t] = P::load(wbase, W_IMAGE, (size_t)((((col + 1) * 3 + ky) * 4 * BNB) + t * 16) * 16);
@@ -241,8 +206,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
       const char* buf = sWin + (k & 1) * WBUF;
       const unsigned ltarget = 4u * (unsigned)(k + 1);  // four movers per column and step
       SP_STAMP(7);
-      sp_poll(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1));  // window k is in its buffer
-      sp_poll(sCL, ltarget);                                   // ... and weight column 0 of k
+      sp_poll(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1), d.fault);  // window k is in its buffer
+      sp_poll(sCL, ltarget, d.fault);                                   // ... and weight column 0 of k
       SP_STAMP(0);
       read_wf(0);
       sp_wait_lds();

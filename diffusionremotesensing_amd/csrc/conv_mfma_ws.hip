@@ -73,12 +73,13 @@ typedef __attribute__((address_space(1))) void* ws_gptr;
 typedef __attribute__((address_space(3))) unsigned* ws_flag_ptr;
 
 // spin until the LDS counter *f reaches `target`.  A protocol error must never leave waves spinning on the GPU (a hung
-// wave can take the whole node down): after ~2^22 polls (about a second) the wave traps and the launch fails loudly.
+// wave can take the whole node down): after 2^24 polls (seconds; a legitimate wait is
+// microseconds) the wave traps: a GPU fault reported from this kernel means a protocol timeout, not a bad address.
 __device__ __forceinline__ void ws_poll(ws_flag_ptr f, unsigned target) {
   unsigned spins = 0;
   while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
     __builtin_amdgcn_s_sleep(4);
-    if (++spins > (1u << 22)) __builtin_trap();
+    if (++spins > (1u << 24)) __builtin_trap();
   }
 }
 typedef __attribute__((address_space(3))) void* ws_lptr;

@@ -84,6 +84,9 @@ struct TapConv {
   //   out[c] = relu(acc[c] + bias[c]) + post_add[c] + acc[Cout + c] + bias[Cout + c].
   // Wave-specialised kernel only (both halves of a pixel end up in one lane: no exchange, no round trip of the skip tensor).
   int dual;
+  // device word set to 1 by a wave of the wave-specialised SP kernels whose bounded poll of an LDS counter ran out (a
+  // protocol bug: sp_sync.h); null = no report.  Read back by drs_unet_check_faults.
+  unsigned* fault;
 };
 
 struct DrsErr {
@@ -131,7 +134,7 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl);
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
                               int transposed, int impl, hipStream_t s, int cout_src = 0, int flip_taps = 0, int co_off = 0,
-                              int partial = 0, int perm = 0);
+                              int partial = 0, int perm = 0, int cin_total = 0, int cin_off = 0);
 
 int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
                             hipStream_t s);
@@ -157,6 +160,47 @@ struct AttnGateDesc {
 };
 bool drs_attn_gate_supported(int Cc, int Ch);
 int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s);
+
+// ---- ups.i.transform composed with the x-half of up_convs.i (upfuse_sp.hip) -------------------------------------------------
+// y = up_conv(cat[ConvTranspose(h), att]) has no non-linearity between the transposed convolution and the 3x3 convolution
+// (reference UpConvBlock.forward returns self.transform(x), UNet_model_superres.py:206-207; up_convs[i] is a bare Conv2d,
+// :320-322,376-377), so the x-path is ONE stride-2 transposed convolution of h with per-axis 3 input taps at even outputs
+// and 2 at odd ones: 6.25 taps x Cc per output pixel instead of 2.25 x Cc (ConvT, Cc outputs) + 9 x Cc (x-half of up_conv).
+//   out[n][2my+py][2mx+px][co] = sum_{ty in T(py)} sum_{tx in T(px)} sum_ci U[py][px][ty][tx][co][ci] * h[n][my+ty-1][mx+tx-1][ci]
+//                                + bias[co] + res[n][oy][ox][co] + edge terms,      T(0) = {0,1,2}, T(1) = {1,2}
+// `res` is the att-half of up_convs.i (a plain 3x3 convolution of the attention output, computed by the existing kernels),
+// the edge terms (eh / ev, fp32) undo the composite's paths through the transposed convolution's cropped row / column -1
+// and carry the position-dependent part of the folded ConvTranspose bias (upfuse_edges_kernel).
+struct UpFuseDesc {
+  const float* in; int in_cs, in_co;   // h = ups.i.conv output (SP), N x LH x LW x Cc
+  int N, LH, LW, Cc, Ch;               // Cc input channels, Ch = output channels of up_convs.i
+  const void* w;                       // composite operand image: [Ch/32][Cc/32][group 5][image 2][tap 5][k-group 4][32][8 x bf16]
+  const float* bias;                   // [Ch]: up_convs bias + the ConvTranspose bias through all nine taps
+  const float* res; int res_cs, res_co;  // att-half partial sums (SP), N x 2LH x 2LW x Ch, or null
+  const float* eh;                     // [N][2: top, bottom][2LW][Ch] fp32, or null (then ev is null too)
+  const float* ev;                     // [N][2: left, right][2LH][Ch] fp32 (zero in rows 0 and 2LH-1)
+  float* out; int out_cs, out_co;      // SP result, N x 2LH x 2LW x Ch, or null (fused projection)
+  float* out2; int out2_cs, out2_co;   // optional second SP output: out + post2[n][c]
+  const float* post2; int post2_cs;
+  const float* fuse_w; const float* fuse_b; float* fuse_out; int fuse_dim;  // Ch == 32: fp32 NCHW projection (the UNet's `output`)
+  const void* zero_line;
+  unsigned* fault;
+};
+// edge-term / bias preparation weights (fp32): rt [5][Cc][Ch], rl [6][Cc][Ch], bt [9][Ch]
+struct UpFuseEdgeDesc {
+  const float* in; int in_cs, in_co; int N, LH, LW, Cc, Ch;
+  const float* rt; const float* rl; const float* bt;
+  float* eh; float* ev;
+};
+bool drs_upfuse_supported(int Cc, int Ch, int LH, int LW);
+size_t drs_upfuse_weight_bytes(int Cc, int Ch);       // composite operand image
+size_t drs_upfuse_aux_floats(int Cc, int Ch);         // rt | rl | bt | bias, in this order
+// v_w: up_convs.i.weight (Ch, Cc + Ch, 3, 3); v_b: its bias; t_w: ups.i.transform.weight (Cc, Cc, 3, 3); t_b: its bias
+int drs_launch_upfuse_pack(const float* v_w, const float* v_b, const float* t_w, const float* t_b, int Cc, int Ch, void* dst_w,
+                           float* dst_aux, hipStream_t s);
+int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s);
+int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s);
+int drs_launch_nchw_to_sp(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 
 int drs_launch_sp_add_rowvec(const float* src, float* dst, const float* vec, int vec_stride, int N, long long pix_per_image,
                              int C, hipStream_t s);

@@ -93,5 +93,3 @@ int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s);
 // fused ConvTranspose2d(3, 2, 1, 1), same structure (conv_s2_sp.hip)
 bool drs_convt_sp_supported(const TapConv& d, int impl);
 int drs_launch_convt_sp(const TapConv& d, hipStream_t s);
-// the same layers with one consumer wave per SIMD (conv_mfma_sp1.hip; DRS_SPK=2)
-int drs_launch_tapconv_sp1(const TapConv& d, const MfmaGeom& g, hipStream_t s);

@@ -24,7 +24,7 @@ void DrsErr::set(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* drs_last_error(void) { return g_err; }
-extern "C" int drs_abi_version(void) { return 4; }
+extern "C" int drs_abi_version(void) { return 5; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -220,6 +220,100 @@ extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// operator-level fused up-sampling stage (NCHW boundary): y = conv3x3(cat[conv_transpose(h), att])
+// ------------------------------------------------------------------------------------------------
+static size_t upfused_sizes(int N, int Cc, int Ch, int LH, int LW, size_t* o) {
+  // o[0] h (SP), o[1] att (SP), o[2] att-half partial sums, o[3] result (SP), o[4] composite image, o[5] aux, o[6] att-half
+  // weights, o[7] att-half bias, o[8] eh, o[9] ev, o[10] zero line + fault word, o[11] projection output staging (unused)
+  const size_t hi = (size_t)N * 4 * LH * LW;
+  size_t b = 0;
+  o[0] = b; b += align_up((size_t)N * LH * LW * Cc * 4);
+  o[1] = b; b += align_up(hi * Ch * 4);
+  o[2] = b; b += align_up(hi * Ch * 4);
+  o[3] = b; b += align_up(hi * Ch * 4);
+  o[4] = b; b += align_up(drs_upfuse_weight_bytes(Cc, Ch));
+  o[5] = b; b += align_up(drs_upfuse_aux_floats(Cc, Ch) * 4);
+  o[6] = b; b += align_up(drs_pack_conv_mfma_bytes(Ch, Ch, 9, DRS_IMPL_MFMA_BF16X3));
+  o[7] = b; b += align_up((size_t)Ch * 4);
+  o[8] = b; b += align_up((size_t)N * 2 * 2 * LW * Ch * 4);
+  o[9] = b; b += align_up((size_t)N * 2 * 2 * LH * Ch * 4);
+  o[10] = b; b += 512;
+  return b + 256;
+}
+extern "C" size_t drs_upconv_fused_workspace_bytes(int N, int Cc, int Ch, int LH, int LW) {
+  size_t o[12];
+  return upfused_sizes(N, Cc, Ch, LH, LW, o);
+}
+extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const float* t_w, const float* t_b, const float* v_w,
+                                     const float* v_b, const float* post2, const float* fuse_w, const float* fuse_b,
+                                     int fuse_dim, float* y, float* y2, int N, int Cc, int Ch, int LH, int LW, void* workspace,
+                                     size_t workspace_bytes, drs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) return DRS_OK;
+  DRS_REQUIRE(h && att && t_w && t_b && v_w && v_b && y && workspace, DRS_ERR_ARG, "upconv_fused: null pointer");
+  DRS_REQUIRE(N > 0 && LH > 0 && LW > 0 && Cc >= 32 && Ch >= 32 && Cc % 32 == 0 && Ch % 32 == 0, DRS_ERR_SHAPE,
+              "upconv_fused: N=%d Cc=%d Ch=%d LH=%d LW=%d (channel counts must be multiples of 32)", N, Cc, Ch, LH, LW);
+  DRS_REQUIRE(!fuse_w || (Ch == 32 && fuse_dim >= 1 && fuse_dim <= 4 && fuse_b && !post2 && !y2), DRS_ERR_SHAPE,
+              "upconv_fused: the fused projection needs Ch == 32, fuse_dim <= 4 and no second output");
+  DRS_REQUIRE((post2 == nullptr) == (y2 == nullptr), DRS_ERR_ARG, "upconv_fused: post2 and y2 come together");
+  size_t o[12];
+  DRS_REQUIRE(workspace_bytes >= upfused_sizes(N, Cc, Ch, LH, LW, o), DRS_ERR_WORKSPACE, "upconv_fused: workspace too small");
+  char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const int OH = 2 * LH, OW = 2 * LW;
+  int rc;
+  DRS_CHECK_HIP(hipMemsetAsync(base + o[10], 0, 512, s));
+  if ((rc = drs_launch_nchw_to_sp(h, (float*)(base + o[0]), N, Cc, LH, LW, s))) return rc;
+  if ((rc = drs_launch_nchw_to_sp(att, (float*)(base + o[1]), N, Ch, OH, OW, s))) return rc;
+  if ((rc = drs_launch_upfuse_pack(v_w, v_b, t_w, t_b, Cc, Ch, base + o[4], (float*)(base + o[5]), s))) return rc;
+  if ((rc = drs_launch_pack_conv_mfma(v_w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + o[6], (float*)(base + o[7]), Ch,
+                                      Ch, 9, 0, DRS_IMPL_MFMA_BF16X3, s, 0, 0, 0, 0, 1, Cc + Ch, Cc)))
+    return rc;
+  const float* aux = (const float*)(base + o[5]);
+  const size_t mat = (size_t)Cc * Ch;
+  unsigned* fault = (unsigned*)(base + o[10] + 256);
+  {
+    UpFuseEdgeDesc e = {};
+    e.in = (const float*)(base + o[0]); e.in_cs = Cc; e.in_co = 0;
+    e.N = N; e.LH = LH; e.LW = LW; e.Cc = Cc; e.Ch = Ch;
+    e.rt = aux; e.rl = aux + 5 * mat; e.bt = aux + 11 * mat;
+    e.eh = (float*)(base + o[8]); e.ev = (float*)(base + o[9]);
+    if ((rc = drs_launch_upfuse_edges(e, s))) return rc;
+  }
+  {
+    TapConv d = conv_desc((const float*)(base + o[1]), N, OH, OW, Ch, Ch, 0, (const float*)(base + o[6]), (const float*)(base + o[7]),
+                          (float*)(base + o[2]), Ch, Ch, 0, 3, 3, 1, 1);
+    d.in_sp = d.out_sp = 1; d.zero_line = base + o[10]; d.fault = fault;
+    if ((rc = drs_launch_tapconv_mfma(d, DRS_IMPL_MFMA_BF16X3, s))) return rc;
+  }
+  {
+    UpFuseDesc u = {};
+    u.in = (const float*)(base + o[0]); u.in_cs = Cc; u.in_co = 0;
+    u.N = N; u.LH = LH; u.LW = LW; u.Cc = Cc; u.Ch = Ch;
+    u.w = base + o[4];
+    u.bias = aux + 11 * mat + 9 * Ch;
+    u.res = (const float*)(base + o[2]); u.res_cs = Ch; u.res_co = 0;
+    u.eh = (const float*)(base + o[8]); u.ev = (const float*)(base + o[9]);
+    u.zero_line = base + o[10]; u.fault = fault;
+    if (fuse_w) {
+      u.fuse_w = fuse_w; u.fuse_b = fuse_b; u.fuse_out = y; u.fuse_dim = fuse_dim;
+    } else {
+      u.out = (float*)(base + o[3]); u.out_cs = Ch; u.out_co = 0;
+      if (y2) { u.out2 = (float*)(base + o[1]); u.out2_cs = Ch; u.out2_co = 0; u.post2 = post2; u.post2_cs = Ch; }  // (att is consumed by now)
+    }
+    if ((rc = drs_launch_upfuse(u, s))) return rc;
+  }
+  if (!fuse_w) {
+    if ((rc = drs_launch_sp_to_nchw((const float*)(base + o[3]), y, N, Ch, OH, OW, Ch, 0, s))) return rc;
+    if (y2 && (rc = drs_launch_sp_to_nchw((const float*)(base + o[1]), y2, N, Ch, OH, OW, Ch, 0, s))) return rc;
+  }
+  unsigned word = 0;
+  DRS_CHECK_HIP(hipMemcpyAsync(&word, fault, 4, hipMemcpyDeviceToHost, s));
+  DRS_CHECK_HIP(hipStreamSynchronize(s));
+  DRS_REQUIRE(word == 0, DRS_ERR_HIP, "upconv_fused: a wave-specialised kernel timed out on an LDS counter (protocol fault)");
+  return DRS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // UNet plan
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -258,6 +352,12 @@ struct DecStage {
   // fused attention gate (attn_gate_sp.hip): w_g and w_x once more with the SP output-row permutation
   bool fused_gate = false;
   size_t fz_wg_off = 0, fz_wx_off = 0;
+  // ups.i.transform composed with the x-half of up_convs.i (upfuse_sp.hip): composite operand image, edge / bias weights,
+  // and the att-half of up_convs.i packed as its own Ch -> Ch 3x3 convolution (no bias: it is in the composite's)
+  bool upfuse = false;
+  size_t uf_w_off = 0, uf_aux_off = 0, ah_w_off = 0, ah_b_off = 0;
+  int t_PA = -1;                  // att-half partial sums (SP), B x Ch x 2lh x 2lw
+  size_t o_eh = 0, o_ev = 0;      // workspace: edge vectors of this forward
 };
 
 }  // namespace
@@ -278,7 +378,7 @@ struct drs_plan {
   ConvLayer output;
 
   size_t packed_bytes = 0, ws_bytes = 0;
-  size_t o_inv_freq = 0, o_mlp_table = 0, o_out_w = 0, o_out_b = 0, o_label = 0, o_zero = 0;
+  size_t o_inv_freq = 0, o_mlp_table = 0, o_out_w = 0, o_out_b = 0, o_label = 0, o_zero = 0, o_fault = 0;
   // eval plans of the split-bf16 implementation keep every MFMA-consumed activation in SP format (drs_common.h)
   bool sp = false;
   int t_XT[3] = {-1, -1, -1};  // x + relu(time_mlp(t)) of UpConvBlock i (reference :199), second output of its producer
@@ -289,6 +389,7 @@ struct drs_plan {
   size_t o_bn_sums = 0;                  // train plans: fp64 scratch for the BatchNorm reductions
   bool packed_ok = false;
   const void* packed_ptr = nullptr;
+  unsigned* fault_ptr = nullptr;  // device word of the current forward's packed buffer (TapConv::fault)
 
   // optional per-op timing (drs_unet_profile_*): events recorded on the forward's stream
   struct OpRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
@@ -510,6 +611,19 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
       d.fz_wx_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(d.wx.Cout, d.wx.Cin, 4, DRS_IMPL_MFMA_BF16X3));
     }
   }
+  for (int i = 0; i < 3; ++i) {
+    DecStage& d = p->dec[i];
+    const int Cc = kUp[i], Ch = kUp[i + 1];
+    // (KEEP_ALL plans stay unfused: ups.i is a parity tap; stage 2 needs the fused output projection: its result is fp32)
+    d.upfuse = p->sp && !(cfg->flags & DRS_PLAN_KEEP_ALL) && (i < 2 || (Ch == 32 && cfg->out_dim <= 4)) &&
+               drs_upfuse_supported(Cc, Ch, cfg->height >> (3 - i), cfg->width >> (3 - i));
+    if (d.upfuse) {
+      d.uf_w_off = cur; cur += align_up(drs_upfuse_weight_bytes(Cc, Ch));
+      d.uf_aux_off = cur; cur += align_up(drs_upfuse_aux_floats(Cc, Ch) * 4);
+      d.ah_w_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(Ch, Ch, 9, DRS_IMPL_MFMA_BF16X3));
+      d.ah_b_off = cur; cur += align_up((size_t)Ch * 4);
+    }
+  }
   for (PlanarConv* L : p->planars) {
     L->w_off = cur; cur += align_up((size_t)L->Cout * L->Cin * 9 * 4);
     L->b_off = cur; cur += align_up((size_t)L->Cout * 4);
@@ -525,6 +639,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
   p->o_out_w = cur; cur += align_up((size_t)cfg->out_dim * kUp[3] * 4);
   p->o_out_b = cur; cur += align_up((size_t)cfg->out_dim * 4);
   p->o_zero = cur; cur += 256;  // a line of zeros: source of out-of-image pixels for LDS-DMA staging
+  p->o_fault = cur; cur += 256;  // TapConv::fault word of the wave-specialised kernels (drs_unet_check_faults)
   p->packed_bytes = cur;
 
   // ---- workspace layout ----
@@ -567,6 +682,15 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
       p->t_XT[i] = p->T("ups." + std::to_string(i) + ".in", ws, B, kUp[i], lh, lw);
     }
     auto mark = [&](int t) { p->tensors[t].sp = true; };
+    for (int i = 0; i < 3; ++i) {
+      DecStage& d = p->dec[i];
+      if (!d.upfuse) continue;
+      const int lh = H >> (3 - i), lw = W >> (3 - i), Ch = kUp[i + 1];
+      d.t_PA = p->T("up_convs." + std::to_string(i) + ".att_half", ws, B, Ch, 2 * lh, 2 * lw);
+      mark(d.t_PA);
+      d.o_eh = ws; ws += align_up((size_t)B * 2 * (2 * lw) * Ch * 4);
+      d.o_ev = ws; ws += align_up((size_t)B * 2 * (2 * lh) * Ch * 4);
+    }
     mark(p->t_x0);
     for (int i = 0; i < 4; ++i) { mark(p->t_H[i]); mark(p->t_R[i]); if (i < 3) mark(p->t_D[i]); }
     for (int i = 0; i < 3; ++i) {
@@ -707,6 +831,18 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
                                         (float*)(base + d.wx.b_off), d.wx.Cout, d.wx.Cin, 4, 0, impl, s, 0, 0, 0, 0, 1)))
       return rc;
   }
+  for (int i = 0; i < 3; ++i) {
+    const DecStage& d = plan->dec[i];
+    if (!d.upfuse) continue;
+    const int Cc = kUp[i], Ch = kUp[i + 1];
+    if ((rc = drs_launch_upfuse_pack(F(d.upconv.w), F(d.upconv.b), F(d.transform.w), F(d.transform.b), Cc, Ch, base + d.uf_w_off,
+                                     (float*)(base + d.uf_aux_off), s)))
+      return rc;
+    // att-half: input channels [Cc, Cc + Ch) of up_convs.i, SP output rows, zero bias
+    if ((rc = drs_launch_pack_conv_mfma(F(d.upconv.w), nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + d.ah_w_off,
+                                        (float*)(base + d.ah_b_off), Ch, Ch, 9, 0, impl, s, 0, 0, 0, 0, 1, Cc + Ch, Cc)))
+      return rc;
+  }
   for (PlanarConv* L : plan->planars) {
     DRS_CHECK_HIP(hipMemcpyAsync(base + L->w_off, F(L->w), (size_t)L->Cout * L->Cin * 9 * 4, hipMemcpyDeviceToDevice, s));
     DRS_CHECK_HIP(hipMemcpyAsync(base + L->b_off, F(L->b), (size_t)L->Cout * 4, hipMemcpyDeviceToDevice, s));
@@ -735,7 +871,7 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_b, F(plan->output.b), (size_t)plan->cfg.out_dim * 4,
                                  hipMemcpyDeviceToDevice, s));
   }
-  DRS_CHECK_HIP(hipMemsetAsync(base + plan->o_zero, 0, 256, s));
+  DRS_CHECK_HIP(hipMemsetAsync(base + plan->o_zero, 0, 512, s));  // zero line + fault word
   plan->param_ptrs.assign(params, params + plan->params.size());
   plan->packed_ok = true;
   plan->packed_ptr = packed;
@@ -757,6 +893,7 @@ static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d_in, hi
   // second output (TapConv::out2): written by the wave-specialised SP kernel's epilogue; shapes that kernel does not
   // take get it from a separate pass over the first output
   TapConv d = d_in;
+  d.fault = plan->fault_ptr;
   const bool split_out2 = d.out2 && !drs_tapconv_sp_supported(d, plan->cfg.impl);
   if (split_out2) d.out2 = nullptr;
   std::string name = plan->params[L.w].name;
@@ -806,6 +943,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   const bool train = (c.flags & DRS_PLAN_TRAIN) != 0;
   const int sp = plan->sp ? 1 : 0;  // SP-format activations (eval, split-bf16)
   const void* zero_line = pk + plan->o_zero;
+  plan->fault_ptr = (unsigned*)(pk + plan->o_fault);
   // A convolution followed by BatchNorm.  Eval: BatchNorm is folded into the weights, one launch.  Train: the raw
   // convolution writes Z (input add and gate act before the norm and stay in the conv), then batch statistics,
   // running-stat update and the normalisation carry the rest of the block's epilogue.
@@ -927,7 +1065,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                             TP(plan->t_H[i]), co, co, 0, 3, 3, 1, 1);
       d.dual = 1;
       d.relu_pre = 1;
-      d.in_sp = d.out_sp = sp; d.zero_line = zero_line;
+      d.in_sp = d.out_sp = sp; d.zero_line = zero_line; d.fault = plan->fault_ptr;
       d.post_add = temb + rb.mlp.temb_off; d.post_cs = plan->temb_total;
       if (drs_tapconv_ws_supported(d, c.impl) || drs_tapconv_sp_supported(d, c.impl)) {
         const std::string& wn = plan->params[rb.conv1.w].name;
@@ -1083,6 +1221,67 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       d.shared_cu = concurrent ? 1 : 0;
       RUN(conv_bn(st.conv, d));
     }
+    if (st.upfuse) {
+      // ups.i.transform and the x-half of up_convs.i as ONE stride-2 transposed convolution of ups.i.conv's output
+      // (upfuse_sp.hip; reference :206-207 returns transform(x) with no activation, :377 is a bare convolution): the
+      // Cc-channel high-resolution tensor is never written.  Three launches: the edge vectors (first row / column of h),
+      // the att-half of up_convs.i as a plain 3x3 convolution of the attention output, and the composite with the att-half
+      // as its residual (+ the fused `output` projection in stage 2).
+      const float* aux = (const float*)(pk + st.uf_aux_off);
+      const size_t mat = (size_t)Cc * Ch;
+      float* eh = (float*)((char*)ws + st.o_eh);
+      float* ev = (float*)((char*)ws + st.o_ev);
+      {
+        UpFuseEdgeDesc e = {};
+        e.in = TP(plan->t_U[i]); e.in_cs = Cc; e.in_co = 0;
+        e.N = B; e.LH = lh; e.LW = lw; e.Cc = Cc; e.Ch = Ch;
+        e.rt = aux; e.rl = aux + 5 * mat; e.bt = aux + 11 * mat;
+        e.eh = eh; e.ev = ev;
+        const double epix = (double)B * 2.0 * (lh + lw);
+        prof_begin(plan, "up_convs." + std::to_string(i) + ".edges", 2.0 * epix * 2.5 * Cc * Ch, 4.0 * epix * (Cc + 4.0 * Ch), s);
+        rc = drs_launch_upfuse_edges(e, s);
+        prof_end(plan, s);
+        if (rc) return rc;
+      }
+      if (concurrent) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));  // the attention half of cat.i is complete
+      {
+        TapConv d = conv_desc(cat, B, 2 * lh, 2 * lw, Ch, Cc + Ch, Cc, (const float*)(pk + st.ah_w_off),
+                              (const float*)(pk + st.ah_b_off), TP(st.t_PA), Ch, Ch, 0, 3, 3, 1, 1);
+        d.in_sp = d.out_sp = 1; d.zero_line = zero_line; d.fault = plan->fault_ptr;
+        prof_begin(plan, "up_convs." + std::to_string(i) + ".att", conv_flops(d), conv_bytes(d), s);
+        rc = drs_launch_tapconv_mfma(d, c.impl, s);
+        prof_end(plan, s);
+        if (rc) return rc;
+      }
+      {
+        UpFuseDesc u = {};
+        u.in = TP(plan->t_U[i]); u.in_cs = Cc; u.in_co = 0;
+        u.N = B; u.LH = lh; u.LW = lw; u.Cc = Cc; u.Ch = Ch;
+        u.w = pk + st.uf_w_off;
+        u.bias = aux + 11 * mat + 9 * Ch;
+        u.res = TP(st.t_PA); u.res_cs = Ch; u.res_co = 0;
+        u.eh = eh; u.ev = ev;
+        u.zero_line = zero_line; u.fault = plan->fault_ptr;
+        if (i == 2) {  // output 1x1 conv (:379) rides in the epilogue; the 32-channel tensor is never written
+          u.fuse_w = (const float*)(pk + plan->o_out_w);
+          u.fuse_b = (const float*)(pk + plan->o_out_b);
+          u.fuse_out = out;
+          u.fuse_dim = c.out_dim;
+          fused_output = true;
+        } else {
+          u.out = TP(plan->t_X[i]); u.out_cs = Ch; u.out_co = 0;
+          u.out2 = TP(plan->t_XT[i + 1]); u.out2_cs = Ch; u.out2_co = 0;  // second output for the next stage's UpConvBlock
+          u.post2 = temb + plan->dec[i + 1].mlp.temb_off; u.post2_cs = plan->temb_total;
+        }
+        const double opix = (double)B * 4.0 * lh * lw;
+        // executed work: 6.25 composite taps per output pixel; bytes: h + att-half partial sums + result (+ weights)
+        prof_begin(plan, "up_convs." + std::to_string(i) + ".fused", 2.0 * opix * 6.25 * Cc * Ch,
+                   4.0 * (opix / 4.0 * Cc + 2.0 * opix * Ch + 25.0 * Cc * Ch), s);
+        rc = drs_launch_upfuse(u, s);
+        prof_end(plan, s);
+        if (rc) return rc;
+      }
+    } else {
     if (st.transform.mfma) {  // transform: ConvTranspose2d, into cat[:, :Cc]   (:206, :376), 4 phases in one launch
       TapConv d = convT_fused_desc(TP(plan->t_U[i]), B, lh, lw, Cc, Cc, 0, PW(st.transform), PB(st.transform), cat, Cc,
                                    Cc + Ch, 0);
@@ -1116,6 +1315,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       }
       RUN(plan_conv(plan, st.upconv, d, s));
     }
+    }  // !upfuse
     xcur = TP(plan->t_X[i]);
   }
   if (!fused_output) {  // output 1x1 conv (:379), straight to the caller's NCHW tensor
@@ -1125,6 +1325,18 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     RUN(plan_conv(plan, plan->output, d, s));
   }
 #undef RUN
+  return DRS_OK;
+}
+
+// Synchronises `stream` and reports whether a wave of the wave-specialised kernels ran into its bounded poll since the
+// weights were last packed into `packed` (a protocol bug: the forward's output is then incomplete).
+extern "C" int drs_unet_check_faults(drs_plan* plan, const void* packed, drs_stream_t stream) {
+  DRS_REQUIRE(plan && packed, DRS_ERR_ARG, "check_faults: null pointer");
+  DRS_REQUIRE(plan->packed_ok && plan->packed_ptr == packed, DRS_ERR_STATE, "check_faults: weights not packed into this buffer");
+  unsigned word = 0;
+  DRS_CHECK_HIP(hipMemcpyAsync(&word, aligned_base(packed) + plan->o_fault, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  DRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  DRS_REQUIRE(word == 0, DRS_ERR_HIP, "a wave-specialised kernel timed out on an LDS counter (protocol fault); results are incomplete");
   return DRS_OK;
 }
 

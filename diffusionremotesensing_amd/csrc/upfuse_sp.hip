@@ -1,0 +1,667 @@
+// ups.i.transform composed with the x-half of up_convs.i: ONE stride-2 transposed convolution of the low-resolution
+// UpConvBlock output h instead of ConvTranspose2d(Cc, Cc, 3, 2, 1, 1) -> cat -> the first Cc input channels of
+// Conv2d(Cc + Ch, Ch, 3, padding 1) (reference UNet_model_superres.py:197-207,320-322,376-377; UpFuseDesc in drs_common.h).
+//
+// Per axis, ConvT(k3, s2, p1, op1) followed by conv(k3, p1) reads 3 low-resolution taps at even outputs and 2 at odd ones:
+//   u[2m] = w1 x[m],  u[2m+1] = w2 x[m] + w0 x[m+1],  y[o] = v0 u[o-1] + v1 u[o] + v2 u[o+1]
+//   y[2m]   = v0w2 x[m-1] + (v0w0 + v1w1 + v2w2) x[m] + v2w0 x[m+1]
+//   y[2m+1] = (v0w1 + v1w2) x[m] + (v1w0 + v2w1) x[m+1]
+// (pair (kv, kw) belongs to tap t of phase p iff p + kv - kw == 2 (t - 1)), in 2-D 9 + 6 + 6 + 4 = 25 taps per 2 x 2 output
+// pixels = 6.25 taps x Cc per output pixel against 2.25 x Cc x (Cc / Ch) + 9 x Cc today: 26.8 instead of 58.0 GFLOP per
+// stage at B = 16, 256 x 256, the 4 x Cc-channel high-resolution tensor (67 / 134 / 268 MB) is neither written nor read,
+// and the ConvTranspose launch disappears.  The composite weights U[py][px][ty][tx] = sum_c V[:, c] W[:, c] over the pairs
+// are an fp32 contraction at pack time (the same class of re-association as the BatchNorm fold).  What the composite gets
+// wrong is the output's first row and column: the 3x3 convolution pads u with ZEROS at row / column -1, the composite
+// continues the transposed convolution there (u[-1] = w0 x[0]); and the ConvTranspose bias reaches an output pixel through
+// the taps that stay inside the image only.  Both are per-edge fp32 vectors (upfuse_edges_kernel: a 1-D composite over the
+// first row / column of h, 0.1 % of the layer's work) added in the epilogue of the border tiles.
+//
+// Kernel structure = tapconv_sp_kernel's (conv_mfma_sp.hip): 8 consumer + 4 mover waves on one CU, persistent blocks in
+// XCD-aware item order, 18 x 18 low-resolution window double-buffered in LDS in the rotated pixel-major operand image,
+// weights streamed through a ring of LDS slots, monotonic LDS counters instead of barriers.  Differences:
+//   item   = 16 x 16 low-resolution cells (32 x 32 output pixels) x 32 output channels; K-step = one 32-channel chunk;
+//   ring   = 3 slots of one "column group" (tx, px) = 5 taps ((py0: ty 0,1,2), (py1: ty 1,2)) x 32 x 32 x (hi, lo) = 20 KB;
+//            a step streams the 5 groups (tx0,px0) (tx1,px0) (tx1,px1) (tx2,px0) (tx2,px1) = 100 KB, group q = 5 k + g sits
+//            in slot q % 3;
+//   waves  : consumer (rw, px) owns cell rows 4 rw .. 4 rw + 3 and the output columns of x-phase px; the px = 0 waves
+//            multiply groups 0, 1, 3 (15 taps), the px = 1 waves groups 2, 4 (10 taps); waves w and w + 4 (one of each)
+//            share a SIMD, so every SIMD carries the same 600 MFMAs per step and its two waves are never in the same phase;
+//   accumulators: [4 cell rows][2 y-phases][2 channel tiles] x f32x4 = 64 registers; a group is two passes of the 3x3
+//            kernel's column schedule (3 taps over 6 window rows, then 2 taps over 5), 0.35 LDS fragment reads per MFMA;
+//   epilogue: + bias + att-half partial sums (`res`, SP) + edge vectors -> SP store (+ second output x + temb), or the
+//            fused `output` projection on the matrix pipe (stage 2).
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "conv_epilogue.h"
+#include "mfma_policy.h"
+#include "sp_sync.h"
+
+namespace {
+
+struct UfGeom {
+  static constexpr int IW = 18, NPIX = 18 * 18;
+  static constexpr int NBLK = (NPIX + 7) / 8;  // window pieces of 8 pixels = 1 KB
+  static constexpr int WBUF = NBLK * 1024;
+  static constexpr int TAPS = 5, NGRP = 5, NSLOT = 3;
+  static constexpr int W_IMAGE = TAPS * 4 * 32 * 16;  // one operand image (hi or lo) of a group: [tap][k-group][32 channels] slots
+  static constexpr int SLOT = 2 * W_IMAGE;            // 20 KB
+  static constexpr int LDS = 2 * WBUF + NSLOT * SLOT + 64;
+};
+
+// column groups (tx, px) and their taps (py, ty), in streaming order
+__host__ __device__ constexpr int uf_group_tx(int g) { return g == 0 ? 0 : (g <= 2 ? 1 : 2); }
+__host__ __device__ constexpr int uf_group_px(int g) { return (g == 2 || g == 4) ? 1 : 0; }
+__host__ __device__ constexpr int uf_tap_py(int j) { return j >= 3 ? 1 : 0; }
+__host__ __device__ constexpr int uf_tap_ty(int j) { return j >= 3 ? j - 2 : j; }
+// pair (kv, kw) of (3x3 convolution tap, transposed-convolution tap) contributes to tap t of output phase p
+__host__ __device__ constexpr bool uf_pair(int p, int t, int kv, int kw) { return p + kv - kw == 2 * (t - 1); }
+// SP output-row permutation (drs_sp_cout_perm of the pack kernels): MFMA row nn of a 32-channel group carries logical channel
+__host__ __device__ constexpr int uf_perm(int nn) { return ((nn & 15) >> 2) * 8 + (nn >> 4) * 4 + (nn & 3); }
+
+template <bool FUSE>
+__global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int tiles_y, int tiles_x, int nck) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using P = PolicyBF16X3;
+  using G = UfGeom;
+  constexpr int IW = G::IW, NBLK = G::NBLK, WBUF = G::WBUF, W_IMAGE = G::W_IMAGE, SLOT = G::SLOT;
+  constexpr int TH = 16, TW = 16, RPW = 4;
+  char* sWin = smem;           // [buffer 2][window pixel][rotated operand slot 8] x 16 bytes
+  char* sW = smem + 2 * WBUF;  // [ring slot 3][image 2][tap 5][k-group 4][32] operand slots
+  sp_flag_ptr sCR = (sp_flag_ptr)(sW + G::NSLOT * SLOT);  // CR[3]: consumer waves that hold the group in ring slot s in registers
+  sp_flag_ptr sCL = sCR + 3;                              // CL[3]: mover waves whose part of the group in ring slot s has landed
+  sp_flag_ptr sWL = sCR + 6;                              // WL[2]: mover waves whose part of window buffer b has landed
+  sp_flag_ptr sWR = sCR + 8;                              // WR[2]: consumer waves that have finished reading window buffer b
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 consumers, 8..11 movers
+  const bool mover = wid >= 8;
+  const int lr = lane & 15, kg = lane >> 4;
+
+  // persistent blocks, XCD-aware item order (see tapconv_mfma_kernel)
+  const int ngroups = d.Ch >> 5;
+  const int nitems = d.N * tiles_y * tiles_x * ngroups;
+  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+  const int per = (nitems + 7) >> 3;
+  const int lo_item = xcd * per, hi_item = min(nitems, lo_item + per);
+  const int span = hi_item - lo_item - j8;
+  const int my_items = span > 0 ? (span + nb8 - 1) / nb8 : 0;
+  const int S = my_items * nck;
+  if (S == 0) return;
+  auto item_of = [&](int ordinal, int& n_, int& ty0_, int& tx0_, int& n0_) __attribute__((always_inline)) {
+    int it = lo_item + ordinal * nb8 + j8;
+    n0_ = (it % ngroups) * 32;
+    it /= ngroups;
+    tx0_ = (it % tiles_x) * TW;
+    it /= tiles_x;
+    ty0_ = (it % tiles_y) * TH;
+    n_ = it / tiles_y;
+  };
+  if (tid < 10) __hip_atomic_store(sCR + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  sp_wait_lds();
+  sp_barrier();
+  int c = -1, ord = -1, n = 0, ty0 = 0, tx0 = 0, n0 = 0;  // current step: chunk, item ordinal, item coordinates (cells)
+
+  if (mover) {
+    // ===================== movers =====================
+    // global -> registers -> LDS, everything a group / a window ahead of the consumers (conv_sp_movers.inc has the
+    // measurements behind this form).  Protocol of step k (window buffer k & 1; group q = 5 k + g in ring slot q % 3):
+    //   loads: group 0, window, group 1;  then, each store as soon as its destination is free and its loads have landed:
+    //   wait CR[slot(q0)] -> store group 0 -> CL;  load group 2
+    //   wait WR[k & 1] (the consumers left the buffer in step k - 2) -> store window -> WL
+    //   wait CR -> store group 1 -> CL; load group 3 | group 2; load group 4 | group 3 | group 4
+    //   consumer (rw, px) of step k: wait WL[k & 1]; for its groups: wait CL[slot] -> read 3 taps -> MFMA pass py0 (reads the
+    //   other 2 taps under its tail) -> CR[slot] -> MFMA pass py1;  after the last group WR[k & 1] -> epilogue of the item
+    // A slot's CR counts 4 releases per group (the four waves of the group's x-phase), its CL 4 landings (the four movers).
+    // Every wait is for an event whose own prerequisites lie strictly earlier in this order: no cycle.
+    const int pw = wid - 8;
+    __builtin_amdgcn_s_setprio(3);
+    const char* zero = reinterpret_cast<const char*>(d.zero_line) + (lane & 15) * 16;
+    // this lane's role inside a window piece (8 pixels x 128 bytes): lanes 8*px .. 8*px + 7 fetch the 8 operand slots of
+    // pixel px = ONE 128-byte line, rotated by px: LDS slot s of the pixel holds operand slot (s - px) & 7
+    const int l_px = lane >> 3, l_c = ((lane & 7) - l_px) & 7, l_img = l_c >> 2, l_kg = l_c & 3;
+    const int l_off1 = l_img * 64 + l_kg * 16;
+    constexpr int NPW = (NBLK + 3) / 4;  // window pieces per mover wave (at most): blocks pw + 4*i
+    static_assert(NBLK == 4 * (NPW - 1) + 1, "piece distribution: the last round holds block NBLK - 1 only, owned by mover 0");
+    int off1[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int p = (pw + 4 * i) * 8 + l_px;
+      const int py = (p * 3641) >> 16, px = p - py * IW;  // p / 18 (exact for p < 1024)
+      off1[i] = ((py * d.LW + px) * d.in_cs) * 4 + l_off1;
+    }
+    const bool tail_ok = (NBLK - 1) * 8 + l_px < G::NPIX;  // the last block is half empty
+    constexpr int WPC = 5;                                 // weight pieces (1 KB) per mover wave and group
+    u32x4 wr[2][WPC], ww[NPW];
+    const int nwin = pw == 0 ? NPW : NPW - 1;
+    const char* wg = reinterpret_cast<const char*>(d.w);
+    const unsigned my_piece = (unsigned)(pw * WPC) * 1024u + (unsigned)lane * 16u;
+    for (int k = 0; k < S; ++k) {
+      if (++c == nck) c = 0;
+      if (c == 0) item_of(++ord, n, ty0, tx0, n0);
+      const char* gsrc = wg + ((size_t)(n0 >> 5) * nck + c) * (size_t)(G::NGRP * SLOT) + my_piece;
+      auto load_grp = [&](int g, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WPC; ++i) wr[set][i] = *reinterpret_cast<const u32x4*>(gsrc + (unsigned)(g * SLOT + i * 1024));
+      };
+      // store group g (registers `set`) once its ring slot is free; `after` = vector-memory operations issued after its loads
+      auto store_grp = [&](int g, int set, int after) __attribute__((always_inline)) {
+        const unsigned q = 5u * (unsigned)k + (unsigned)g, fill = q / 3u, slot = q - 3u * fill;
+        if (fill > 0) sp_poll(sCR + slot, 4u * fill, d.fault);
+        sp_wait_vm(after);
+        char* dst = sW + slot * SLOT + my_piece;
+#pragma unroll
+        for (int i = 0; i < WPC; ++i) *reinterpret_cast<u32x4*>(dst + i * 1024) = wr[set][i];
+        sp_wait_lds();
+        if (lane == 0) sp_bump(sCL + slot);
+      };
+      load_grp(0, 0);
+      // ---- window loads ----
+      if (ty0 >= 1 && ty0 + TH + 1 <= d.LH && tx0 >= 1 && tx0 + TW + 1 <= d.LW) {
+        // fast path: every window pixel inside the image
+        const char* base = reinterpret_cast<const char*>(d.in) +
+                           ((((long long)n * d.LH + (ty0 - 1)) * d.LW + (tx0 - 1)) * d.in_cs + d.in_co) * 4 + c * 128;
+#pragma unroll
+        for (int i = 0; i < NPW - 1; ++i) ww[i] = *reinterpret_cast<const u32x4*>(base + (unsigned)off1[i]);
+        if (pw == 0) ww[NPW - 1] = *reinterpret_cast<const u32x4*>(tail_ok ? base + (unsigned)off1[NPW - 1] : zero);
+      } else {
+        // border tiles: per-lane validity; anything outside the image reads the zero line
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          if (i < nwin) {
+            const int p = (pw + 4 * i) * 8 + l_px;
+            const int py = (p * 3641) >> 16, px = p - py * IW;
+            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+            const bool ok = p < G::NPIX && iy >= 0 && iy < d.LH && ix >= 0 && ix < d.LW;
+            const char* src = reinterpret_cast<const char*>(d.in) +
+                              ((((long long)n * d.LH + iy) * d.LW + ix) * d.in_cs + d.in_co) * 4 + c * 128 + l_off1;
+            ww[i] = *reinterpret_cast<const u32x4*>(ok ? src : zero);
+          }
+      }
+      load_grp(1, 1);
+      store_grp(0, 0, nwin + WPC);
+      load_grp(2, 0);
+      if (k >= 2) sp_poll(sWR + (k & 1), 8u * (unsigned)(k >> 1), d.fault);
+      sp_wait_vm(2 * WPC);
+      {
+        char* buf = sWin + (k & 1) * WBUF + lane * 16;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          if (i < nwin) *reinterpret_cast<u32x4*>(buf + (pw + 4 * i) * 1024) = ww[i];
+        sp_wait_lds();
+        if (lane == 0) sp_bump(sWL + (k & 1));
+      }
+      store_grp(1, 1, WPC);
+      load_grp(3, 1);
+      store_grp(2, 0, WPC);
+      load_grp(4, 0);
+      store_grp(3, 1, WPC);
+      store_grp(4, 0, 0);
+    }
+  } else {
+    // ===================== consumers =====================
+    const int rw = wid & 3;   // cell rows [4 rw, 4 rw + 4) of the tile
+    const int px_wave = wid >> 2;  // x-phase of this wave's output columns
+    // fragment addresses: window pixel p = B + q + lr with B = rw*RPW*18 (per wave) and q = wr*18 + tx (compile time);
+    // slot address = p * 128 + ((c + p) & 7) * 16, c = image * 4 + k-group (conv_mfma_sp.hip)
+    const int B = rw * RPW * IW;
+    // One lane table per residue q & 7; the lo image sits 4 slots further in the rotation, and (x + 4) & 7 == x ^ 4, so the
+    // lo address of residue j IS the hi address of residue j ^ 4: 8 registers serve both images.  The tables are rebuilt
+    // at the top of every step from opaque copies of the lane coordinates: their live range then ends before the item
+    // epilogue, which would otherwise push them into scratch (reloads inside the MFMA loop).
+    int tab[8];
+    const char* wlane = sW + (kg * 32 + lr) * 16;  // this lane's origin inside a ring slot
+    f32x4 acc[RPW][2][2];                           // [cell row][y-phase][channel tile]
+    typename P::Frag wf[3][2];
+    auto win_frag = [&](const char* buf, int q) __attribute__((always_inline)) {  // q: compile-time window offset
+      return typename P::Frag{*reinterpret_cast<const bf16x8*>(buf + tab[q & 7] + q * 128),
+                              *reinterpret_cast<const bf16x8*>(buf + tab[(q & 7) ^ 4] + q * 128)};
+    };
+    // one column group: taps (py0: ty 0,1,2 | py1: ty 1,2) of input column tx for this wave's x-phase
+    auto do_group = [&](const char* buf, int tx, unsigned q) __attribute__((always_inline)) {
+      const unsigned fill = q / 3u, slot = q - 3u * fill;
+      sp_poll_lds(sCL + slot, 4u * (fill + 1u), d.fault);
+      const char* sb = wlane + slot * SLOT;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wf[ty][t] = P::load(sb, W_IMAGE, (size_t)(ty * 2048 + t * 256));
+      // pass py0: 3 taps over window rows 0..5.  wf[0] (ty 0) is last used by row 3, wf[1] by row 4: the taps of pass py1
+      // (ty 1 -> wf[0], ty 2 -> wf[1]) are read under the tail of this pass.
+#pragma unroll
+      for (int wr = 0; wr < RPW + 2; ++wr) {
+        const typename P::Frag af = win_frag(buf, wr * IW + tx);
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const int r = wr - ty;
+          if (r >= 0 && r < RPW) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[r][0][t] = P::mma(wf[ty][t], af, acc[r][0][t]);
+          }
+        }
+        if (wr == RPW - 1) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) wf[0][t] = P::load(sb, W_IMAGE, (size_t)(3 * 2048 + t * 256));
+        }
+        if (wr == RPW) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) wf[1][t] = P::load(sb, W_IMAGE, (size_t)(4 * 2048 + t * 256));
+        }
+      }
+      sp_wait_lds();  // all five taps are in registers: the ring slot may be refilled
+      if (lane == 0) sp_bump(sCR + slot);
+      // pass py1: ty 1 (wf[0]) and ty 2 (wf[1]) over window rows 1..5
+#pragma unroll
+      for (int wr = 1; wr < RPW + 2; ++wr) {
+        const typename P::Frag af = win_frag(buf, wr * IW + tx);
+        if (wr - 1 < RPW) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[wr - 1][1][t] = P::mma(wf[0][t], af, acc[wr - 1][1][t]);
+        }
+        if (wr - 2 >= 0) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[wr - 2][1][t] = P::mma(wf[1][t], af, acc[wr - 2][1][t]);
+        }
+      }
+    };
+    // the whole step loop once per x-phase (compile-time px: straight-line group sequences, no accumulator copies
+    // between the two roles' code paths)
+    auto run = [&](auto PXC) __attribute__((always_inline)) {
+    constexpr int px = decltype(PXC)::value;
+    for (int k = 0; k < S; ++k) {
+      if (++c == nck) c = 0;
+      if (c == 0) {
+        item_of(++ord, n, ty0, tx0, n0);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[r][py][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      {
+        int lr_s = lr, kg_s = kg;
+        asm volatile("" : "+v"(lr_s), "+v"(kg_s));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tab[j] = (B + lr_s) * 128 + ((kg_s + B + j + lr_s) & 7) * 16;
+      }
+      const char* buf = sWin + (k & 1) * WBUF;
+      sp_poll_lds(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1), d.fault);  // window k is in its buffer
+      const unsigned q0 = 5u * (unsigned)k;
+      if constexpr (px == 0) {
+        do_group(buf, 0, q0);
+        do_group(buf, 1, q0 + 1u);
+        do_group(buf, 2, q0 + 3u);
+      } else {
+        do_group(buf, 1, q0 + 2u);
+        do_group(buf, 2, q0 + 4u);
+      }
+      sp_wait_lds();  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
+      if (lane == 0) sp_bump(sWR + (k & 1));
+      if (c == nck - 1) {
+        // ---------------- item epilogue ----------------
+        // lane (lr, kg) holds, per (cell row r, y-phase py), the 8 consecutive logical channels n0 + kg*8 .. +7 (tile 0:
+        // +0..3, tile 1: +4..7, SP output-row permutation) of output pixel (2 (ty0 + 4 rw + r) + py, 2 (tx0 + lr) + px)
+        int lr_e = lr, kg_e = kg;
+        asm volatile("" : "+v"(lr_e), "+v"(kg_e));
+        const int OH = 2 * d.LH, OW = 2 * d.LW;
+        const int c8 = n0 + kg_e * 8;
+        const bool lo = lr_e < 8;
+        const int pl = lr_e & 7;
+        const int mx = tx0 + lr_e;
+        const bool own_ok = mx < d.LW;
+        const int ox_own = 2 * min(mx, d.LW - 1) + px;
+        const bool ok0 = tx0 + pl < d.LW, ok1 = tx0 + pl + 8 < d.LW;
+        const int myb = ty0 + rw * RPW;
+        auto load8 = [&](const float* p, float (&v)[8]) __attribute__((always_inline)) {
+          const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        };
+        float bias8[8];
+        load8(d.bias + c8, bias8);
+        // att-half partial sums of this lane's pixels, added into the accumulators BEFORE the first store of the item (one
+        // in-order counter for loads and stores: a load issued behind a store is complete only once that store is)
+        if (d.res) {
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+              const int oy = 2 * min(myb + r, d.LH - 1) + py;
+              const char* g = reinterpret_cast<const char*>(d.res) +
+                              ((((size_t)n * OH + oy) * OW + ox_own) * d.res_cs + d.res_co + n0) * 4 + kg_e * 16;
+              float rv[8];
+              drs_sp_join8(*reinterpret_cast<const u32x4*>(g), *reinterpret_cast<const u32x4*>(g + 64), rv);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { acc[r][py][0][j] += rv[j]; acc[r][py][1][j] += rv[4 + j]; }
+            }
+        }
+        float post2_8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) post2_8[j] = 0.f;
+        typename P::Frag wfr;
+        float fb[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (FUSE) {
+          // A operand of the projection: row lr = fuse_w[lr][this lane's 8 channels] (rows >= fuse_dim are zero)
+          float w8[8];
+          load8(d.fuse_w + (size_t)min(lr_e, d.fuse_dim - 1) * d.Ch + c8, w8);
+          const float keep = lr_e < d.fuse_dim ? 1.f : 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w8[j] *= keep;
+          u32x4 h, l;
+          drs_sp_split8(w8, h, l);
+          wfr = typename P::Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[j] = d.fuse_b[min(j, d.fuse_dim - 1)];
+        } else {
+          if (d.out2) load8(d.post2 + (size_t)n * d.post2_cs + c8, post2_8);
+        }
+        const int lane_b = (lo ? 0 : 64) + kg_e * 16;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const int my = myb + r;
+          if (my < d.LH) {
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+              const int oy = 2 * my + py;
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[j] = acc[r][py][0][j] + bias8[j]; v[4 + j] = acc[r][py][1][j] + bias8[4 + j]; }
+              if (d.eh) {
+                if (oy == 0 || oy == OH - 1) {  // first / last output row (wave-uniform)
+                  float e8[8];
+                  load8(d.eh + (((size_t)n * 2 + (oy ? 1 : 0)) * OW + ox_own) * d.Ch + c8, e8);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[j] += e8[j];
+                } else if (ox_own == 0 || ox_own == OW - 1) {  // first / last output column (one lane of a border tile)
+                  float e8[8];
+                  load8(d.ev + (((size_t)n * 2 + (ox_own ? 1 : 0)) * OH + oy) * d.Ch + c8, e8);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[j] += e8[j];
+                }
+              }
+              if constexpr (FUSE) {
+                u32x4 h, l;
+                drs_sp_split8(v, h, l);
+                const typename P::Frag vf{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+                const f32x4 y = P::mma(wfr, vf, f32x4{0.f, 0.f, 0.f, 0.f});  // lanes of k-group 0: outputs 0..3 of pixel lr
+                if (own_ok && kg_e == 0) {
+                  const size_t plane = (size_t)OH * OW;
+                  float* o = d.fuse_out + (size_t)n * d.fuse_dim * plane + (size_t)oy * OW + ox_own;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    if (j < d.fuse_dim) o[(size_t)j * plane] = y[j] + fb[j];
+                }
+              } else {
+                // SP stores in full 128-byte lines: lanes lr < 8 write hi slots, lanes lr >= 8 lo slots, of cells pl and pl + 8
+                const size_t pix0 = ((size_t)n * OH + oy) * OW + 2 * (tx0 + pl) + px;
+                auto put = [&](float* base, int cs, int co, const float (&w8)[8]) __attribute__((always_inline)) {
+                  u32x4 H, L;
+                  drs_sp_split8(w8, H, L);
+                  const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo
+                  char* g = reinterpret_cast<char*>(base) + (pix0 * cs + co + n0) * 4 + lane_b;
+                  if (ok0) *reinterpret_cast<u32x4*>(g) = lo ? H : got;
+                  if (ok1) *reinterpret_cast<u32x4*>(g + (size_t)16 * cs * 4) = lo ? got : L;
+                };
+                if (d.out) put(d.out, d.out_cs, d.out_co, v);
+                if (d.out2) {
+                  float p2[8];
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) p2[j] = v[j] + post2_8[j];
+                  put(d.out2, d.out2_cs, d.out2_co, p2);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    };
+    if (px_wave == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+  }
+}
+
+// ---- pack: composite operand image ------------------------------------------------------------------------------------
+// dst: [Ch/32][Cc/32][group 5][image 2][tap 5][k-group 4][32 rows][8 x bf16]; row nn of a 32-channel group carries logical
+// channel uf_perm(nn).  One thread per 16-byte slot (8 input channels).
+__global__ void upfuse_pack_kernel(const float* __restrict__ v_w, const float* __restrict__ t_w, int Cc, int Ch,
+                                   char* __restrict__ dst) {
+  const int nck = Cc >> 5;
+  const size_t nslots = (size_t)(Ch >> 5) * nck * 5 * 5 * 4 * 32;
+  const int cinv = Cc + Ch;
+  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (size_t)gridDim.x * blockDim.x) {
+    const int nn = (int)(s & 31);
+    const int q = (int)((s >> 5) & 3);
+    const int j = (int)((s >> 7) % 5);
+    const int g = (int)((s / 640) % 5);
+    const int ck = (int)((s / 3200) % nck);
+    const int cgi = (int)(s / ((size_t)3200 * nck));
+    const int co = cgi * 32 + uf_perm(nn);
+    const int tx = uf_group_tx(g), px = uf_group_px(g), py = uf_tap_py(j), ty = uf_tap_ty(j);
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int ci0 = ck * 32 + q * 8;
+    for (int kvy = 0; kvy < 3; ++kvy)
+      for (int kwy = 0; kwy < 3; ++kwy) {
+        if (!uf_pair(py, ty, kvy, kwy)) continue;
+        for (int kvx = 0; kvx < 3; ++kvx)
+          for (int kwx = 0; kwx < 3; ++kwx) {
+            if (!uf_pair(px, tx, kvx, kwx)) continue;
+            const float* vp = v_w + (size_t)co * cinv * 9 + kvy * 3 + kvx;
+            const float* wp = t_w + (size_t)ci0 * Cc * 9 + kwy * 3 + kwx;
+            for (int c = 0; c < Cc; ++c) {
+              const float vv = vp[(size_t)c * 9];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] += vv * wp[((size_t)e * Cc + c) * 9];
+            }
+          }
+      }
+    const size_t base = (((size_t)cgi * nck + ck) * 5 + g) * UfGeom::SLOT + (size_t)j * 2048 + q * 512 + nn * 16;
+    PolicyBF16X3::cvt_store(dst, UfGeom::W_IMAGE, base, x);
+  }
+}
+
+// aux (fp32): rt [5][Cc][Ch] (first-ROW paths: kvy = kwy = 0, pairs over x), rl [6][Cc][Ch] (first-COLUMN paths: kvx = kwx = 0,
+// pairs over y; entry 5 = (py 0, ty 1) without the pair (0, 0): output row 0, whose row -1 paths are already in rt),
+// bt [9][Ch] = sum_c V[co][c][kv] b_t[c], bias [Ch] = b_v + sum over the nine taps of bt.
+__global__ void upfuse_aux_kernel(const float* __restrict__ v_w, const float* __restrict__ v_b, const float* __restrict__ t_w,
+                                  const float* __restrict__ t_b, int Cc, int Ch, float* __restrict__ aux) {
+  const int cinv = Cc + Ch;
+  const size_t nr = (size_t)11 * Cc * Ch;
+  float* rt = aux;
+  float* bt = aux + nr;
+  float* bias = bt + 9 * Ch;
+  const size_t total = nr + (size_t)9 * Ch;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < nr) {
+      const int co = (int)(i % Ch);
+      const int ci = (int)((i / Ch) % Cc);
+      const int jj = (int)(i / ((size_t)Ch * Cc));  // 0..4 rt, 5..10 rl
+      const bool top = jj < 5;
+      const int j = top ? jj : (jj - 5 == 5 ? 1 : jj - 5);
+      const bool variant = jj == 10;
+      const int p = uf_tap_py(j), t = uf_tap_ty(j);  // (phase, tap) along the free axis
+      float acc = 0.f;
+      for (int kv = 0; kv < 3; ++kv)
+        for (int kw = 0; kw < 3; ++kw) {
+          if (!uf_pair(p, t, kv, kw)) continue;
+          if (variant && kv == 0 && kw == 0) continue;
+          const int vt = top ? kv : kv * 3;  // top: (kvy 0, kvx kv); left: (kvy kv, kvx 0)
+          const int wt = top ? kw : kw * 3;
+          const float* vp = v_w + (size_t)co * cinv * 9 + vt;
+          const float* wp = t_w + (size_t)ci * Cc * 9 + wt;
+          for (int c = 0; c < Cc; ++c) acc += vp[(size_t)c * 9] * wp[(size_t)c * 9];
+        }
+      rt[i] = acc;
+    } else {
+      const size_t r = i - nr;
+      const int co = (int)(r % Ch), kv = (int)(r / Ch);
+      float acc = 0.f;
+      for (int c = 0; c < Cc; ++c) acc += v_w[((size_t)co * cinv + c) * 9 + kv] * t_b[c];
+      bt[r] = acc;
+    }
+  }
+  (void)bias;
+}
+__global__ void upfuse_bias_kernel(const float* __restrict__ v_b, int Ch, const float* __restrict__ bt, float* __restrict__ bias) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= Ch) return;
+  float b = v_b ? v_b[co] : 0.f;
+  for (int kv = 0; kv < 9; ++kv) b += bt[kv * Ch + co];
+  bias[co] = b;
+}
+
+// ---- edge vectors -----------------------------------------------------------------------------------------------------
+// eh[n][0 | 1][ox][co]: everything the composite needs added in output rows 0 and OH-1 (all columns, corners included);
+// ev[n][0 | 1][oy][co]: the same for output columns 0 and OW-1, rows 1 .. OH-2 (zero in rows 0 and OH-1).
+//   bias part: minus bt[kvy][kvx] for every tap whose transposed-convolution position lies outside the image;
+//   data part: minus the composite's paths through row -1 (rt, output row 0) and column -1 (rl, output column 0).
+__device__ __forceinline__ float uf_sp_value(const char* base, int ci) {  // element ci of a pixel's SP channel vector
+  const char* g = base + (ci >> 5) * 128 + (ci & 31) * 2;
+  return (float)*reinterpret_cast<const __bf16*>(g) + (float)*reinterpret_cast<const __bf16*>(g + 64);
+}
+__global__ __launch_bounds__(256) void upfuse_edges_kernel(UpFuseEdgeDesc d) {
+  const int OH = 2 * d.LH, OW = 2 * d.LW, Ch = d.Ch, Cc = d.Cc;
+  const size_t n_eh = (size_t)d.N * 2 * OW * Ch, n_ev = (size_t)d.N * 2 * OH * Ch;
+  const size_t mat = (size_t)Cc * Ch;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_eh + n_ev; i += (size_t)gridDim.x * blockDim.x) {
+    const bool horiz = i < n_eh;
+    const size_t r = horiz ? i : i - n_eh;
+    const int co = (int)(r % Ch);
+    const int pos = (int)((r / Ch) % (horiz ? OW : OH));
+    const int which = (int)((r / ((size_t)Ch * (horiz ? OW : OH))) & 1);
+    const int n = (int)(r / ((size_t)Ch * (horiz ? OW : OH) * 2));
+    const int oy = horiz ? (which ? OH - 1 : 0) : pos;
+    const int ox = horiz ? pos : (which ? OW - 1 : 0);
+    float val = 0.f;
+    if (horiz || (oy > 0 && oy < OH - 1)) {
+      for (int kvy = 0; kvy < 3; ++kvy)
+        for (int kvx = 0; kvx < 3; ++kvx) {
+          const bool out = (oy == 0 && kvy == 0) || (oy == OH - 1 && kvy == 2) || (ox == 0 && kvx == 0) || (ox == OW - 1 && kvx == 2);
+          if (out) val -= d.bt[(kvy * 3 + kvx) * Ch + co];
+        }
+      auto pixel = [&](int y, int x) {
+        return reinterpret_cast<const char*>(d.in) + ((((size_t)n * d.LH + y) * d.LW + x) * d.in_cs + d.in_co) * 4;
+      };
+      if (oy == 0) {  // paths through row -1 of the transposed convolution: a 1-D composite over the first row of h
+        const int m = ox >> 1, p = ox & 1;
+        for (int t = p; t < 3; ++t) {
+          const int x = m + t - 1;
+          if (x < 0 || x >= d.LW) continue;
+          const float* w = d.rt + (size_t)(p == 0 ? t : 2 + t) * mat + co;
+          const char* hp = pixel(0, x);
+          float a = 0.f;
+          for (int ci = 0; ci < Cc; ++ci) a += w[(size_t)ci * Ch] * uf_sp_value(hp, ci);
+          val -= a;
+        }
+      }
+      if (ox == 0) {  // paths through column -1 (without those through row -1, already counted above)
+        const int m = oy >> 1, p = oy & 1;
+        for (int t = p; t < 3; ++t) {
+          const int y = m + t - 1;
+          if (y < 0 || y >= d.LH) continue;
+          const int jj = (oy == 0 && t == 1) ? 5 : (p == 0 ? t : 2 + t);
+          const float* w = d.rl + (size_t)jj * mat + co;
+          const char* hp = pixel(y, 0);
+          float a = 0.f;
+          for (int ci = 0; ci < Cc; ++ci) a += w[(size_t)ci * Ch] * uf_sp_value(hp, ci);
+          val -= a;
+        }
+      }
+    }
+    (horiz ? d.eh : d.ev)[r] = val;
+  }
+}
+
+// NCHW fp32 -> SP channels-last (operator-level entry / tests only)
+__global__ void nchw_to_sp_kernel(const float* __restrict__ src, char* __restrict__ dst, int N, int C, int H, int W) {
+  const int64_t hw = (int64_t)H * W, slots = (int64_t)N * hw * (C / 8);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (int64_t)gridDim.x * blockDim.x) {
+    const int sl = (int)(i % (C / 8));
+    const int64_t pix = i / (C / 8);
+    const int n = (int)(pix / hw);
+    const int64_t r = pix % hw;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = src[((int64_t)n * C + sl * 8 + j) * hw + r];
+    PolicyBF16X3::cvt_store(dst, 64, (size_t)((pix * C + (sl >> 2) * 32) * 4 + (sl & 3) * 16), x);
+  }
+}
+
+}  // namespace
+
+bool drs_upfuse_supported(int Cc, int Ch, int LH, int LW) {
+  static const int env = getenv("DRS_UPFUSE") ? atoi(getenv("DRS_UPFUSE")) : 1;
+  return env && Cc % 32 == 0 && Ch % 32 == 0 && Cc >= 32 && Ch >= 32 && LH > 8 && LW > 8;
+}
+size_t drs_upfuse_weight_bytes(int Cc, int Ch) { return (size_t)(Ch / 32) * (Cc / 32) * UfGeom::NGRP * UfGeom::SLOT; }
+size_t drs_upfuse_aux_floats(int Cc, int Ch) { return (size_t)11 * Cc * Ch + (size_t)10 * Ch; }
+
+int drs_launch_upfuse_pack(const float* v_w, const float* v_b, const float* t_w, const float* t_b, int Cc, int Ch, void* dst_w,
+                           float* dst_aux, hipStream_t s) {
+  DRS_REQUIRE(Cc % 32 == 0 && Ch % 32 == 0, DRS_ERR_SHAPE, "upfuse_pack: Cc=%d Ch=%d", Cc, Ch);
+  const size_t nslots = drs_upfuse_weight_bytes(Cc, Ch) / 32;
+  int blocks = (int)((nslots + 127) / 128);
+  hipLaunchKernelGGL(upfuse_pack_kernel, dim3(blocks), dim3(128), 0, s, v_w, t_w, Cc, Ch, (char*)dst_w);
+  DRS_CHECK_HIP(hipGetLastError());
+  const size_t total = (size_t)11 * Cc * Ch + (size_t)9 * Ch;
+  blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(upfuse_aux_kernel, dim3(blocks), dim3(256), 0, s, v_w, v_b, t_w, t_b, Cc, Ch, dst_aux);
+  DRS_CHECK_HIP(hipGetLastError());
+  float* bt = dst_aux + (size_t)11 * Cc * Ch;
+  hipLaunchKernelGGL(upfuse_bias_kernel, dim3((Ch + 127) / 128), dim3(128), 0, s, v_b, Ch, bt, bt + 9 * Ch);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s) {
+  const size_t total = (size_t)d.N * 2 * (2 * d.LW + 2 * d.LH) * d.Ch;
+  if (total == 0) return DRS_OK;
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(upfuse_edges_kernel, dim3(blocks), dim3(256), 0, s, d);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
+  DRS_REQUIRE(d.in && d.w && d.bias && d.zero_line && (d.out || d.fuse_out), DRS_ERR_ARG, "upfuse: null tensor");
+  DRS_REQUIRE(d.Cc % 32 == 0 && d.Ch % 32 == 0 && (d.in_cs & 31) == 0 && (d.in_co & 31) == 0, DRS_ERR_SHAPE, "upfuse: channels");
+  DRS_REQUIRE(!d.res || ((d.res_cs & 31) == 0 && (d.res_co & 31) == 0), DRS_ERR_SHAPE, "upfuse: res slice");
+  DRS_REQUIRE(!d.out || ((d.out_cs & 31) == 0 && (d.out_co & 31) == 0), DRS_ERR_SHAPE, "upfuse: out slice");
+  DRS_REQUIRE(!d.out2 || (d.out && d.post2 && (d.out2_cs & 31) == 0 && (d.out2_co & 31) == 0 && (d.post2_cs & 3) == 0),
+              DRS_ERR_SHAPE, "upfuse: out2");
+  DRS_REQUIRE(!d.fuse_out || (d.Ch == 32 && d.fuse_dim >= 1 && d.fuse_dim <= 4 && d.fuse_w && d.fuse_b && !d.out && !d.out2),
+              DRS_ERR_SHAPE, "upfuse: fused projection needs Ch == 32, fuse_dim <= 4 and no wide output");
+  DRS_REQUIRE((d.eh == nullptr) == (d.ev == nullptr), DRS_ERR_ARG, "upfuse: edge vectors");
+  if ((size_t)d.N * d.LH * d.LW == 0) return DRS_OK;
+  const int tiles_y = drs_cdiv(d.LH, 16), tiles_x = drs_cdiv(d.LW, 16), nck = d.Cc / 32;
+  const long long nitems = (long long)d.N * tiles_y * tiles_x * (d.Ch / 32);
+  int num_cu = 0;
+  const void* kern = d.fuse_out ? reinterpret_cast<const void*>(upfuse_sp_kernel<true>)
+                                : reinterpret_cast<const void*>(upfuse_sp_kernel<false>);
+  static_assert(UfGeom::LDS <= 160 * 1024, "LDS budget");
+  {
+    const int rc = drs_kernel_prepare(kern, 160 * 1024, &num_cu);
+    if (rc) return rc;
+  }
+  long long blocks = num_cu;  // one 12-wave block per CU
+  if (blocks > nitems) blocks = nitems;
+  blocks = (blocks + 7) / 8 * 8;
+  if (d.fuse_out)
+    hipLaunchKernelGGL(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
+  else
+    hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+int drs_launch_nchw_to_sp(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s) {
+  DRS_REQUIRE(C % 32 == 0, DRS_ERR_SHAPE, "nchw_to_sp: C=%d", C);
+  const int64_t slots = (int64_t)N * H * W * (C / 8);
+  if (slots == 0) return DRS_OK;
+  int64_t b = (slots + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(nchw_to_sp_kernel, dim3((unsigned)b), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), N, C, H, W);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}

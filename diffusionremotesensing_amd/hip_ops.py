@@ -62,6 +62,37 @@ def conv2d(x, w, b=None, stride=1, padding=0, transposed=False, output_padding=0
     return y
 
 
+def upconv_fused(h, att, t_w, t_b, v_w, v_b, post2=None, fuse_w=None, fuse_b=None):
+    """conv2d(cat([conv_transpose2d(h, t_w, t_b, 2, 1, 1), att], 1), v_w, v_b, padding=1) the way the eval plan runs a
+    decoder stage: transposed convolution and the x-half of the 3x3 convolution composed into one stride-2 transposed
+    convolution (include/drs_hip.h: drs_upconv_fused_nchw).  Returns y, or (y, y + post2[:, :, None, None]) with
+    `post2` (N, Ch), or conv1x1(y, fuse_w, fuse_b) with `fuse_w` (fuse_dim, Ch)."""
+    lib = _lib.load()
+    h = _req(h, "h"); att = _req(att, "att"); t_w = _req(t_w, "t_w"); t_b = _req(t_b, "t_b")
+    v_w = _req(v_w, "v_w"); v_b = _req(v_b, "v_b")
+    N, Cc, LH, LW = h.shape
+    Ch = v_w.shape[0]
+    if att.shape != (N, Ch, 2 * LH, 2 * LW) or v_w.shape[1] != Cc + Ch or tuple(t_w.shape) != (Cc, Cc, 3, 3):
+        raise RuntimeError(f"upconv_fused: shapes h {tuple(h.shape)} att {tuple(att.shape)} t_w {tuple(t_w.shape)} "
+                           f"v_w {tuple(v_w.shape)} do not fit one decoder stage")
+    fd = 0
+    if fuse_w is not None:
+        fuse_w = _req(fuse_w.reshape(fuse_w.shape[0], -1), "fuse_w"); fuse_b = _req(fuse_b, "fuse_b")
+        fd = fuse_w.shape[0]
+    if post2 is not None:
+        post2 = _req(post2, "post2")
+    y = torch.empty((N, fd if fd else Ch, 2 * LH, 2 * LW), dtype=torch.float32, device=h.device)
+    y2 = torch.empty_like(y) if post2 is not None else None
+    nbytes = lib.drs_upconv_fused_workspace_bytes(N, Cc, Ch, LH, LW)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
+    with torch.cuda.device(h.device):
+        st = lib.drs_upconv_fused_nchw(_ptr(h), _ptr(att), _ptr(t_w), _ptr(t_b), _ptr(v_w), _ptr(v_b), _ptr(post2),
+                                       _ptr(fuse_w), _ptr(fuse_b), fd, _ptr(y), _ptr(y2), N, Cc, Ch, LH, LW, _ptr(ws),
+                                       nbytes, _stream(h.device))
+    _lib.check(st, "drs_upconv_fused_nchw")
+    return (y, y2) if y2 is not None else y
+
+
 def bicubic_upsample(x, scale):
     lib = _lib.load()
     x = _req(x, "x")

@@ -47,11 +47,13 @@ enum {
 /* Threading: a drs_plan (and the buffers bound to it) is used by ONE host thread at a time - its launches, events and side
  * streams are not locked.  Different plans may be driven from different threads and on different devices; the plan-less
  * entry points (noise_images, sampler steps, adam / ema, downblur, aggregate) are re-entrant.  The library's only
- * process-wide state is a mutex-guarded per-device cache of kernel attributes.
+ * process-wide state is a mutex-guarded per-device cache of kernel attributes, plus kernel-family switches read ONCE per
+ * process from the environment (A/B experiments and the variant tests; unset = the shipped defaults): DRS_SP, DRS_SPK,
+ * DRS_WS, DRS_D3K, DRS_S2K, DRS_NWG, DRS_BLOCKS_PER_CU, DRS_FUSE_GATE, DRS_UPFUSE, DRS_CONCURRENT, DRS_DEBUG_FLAGS.
  * Human-readable message for the last non-zero status returned on this thread. */
 const char* drs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
-int drs_abi_version(void);
+int drs_abi_version(void);  /* 5 */
 
 /* ------------------------------------------------------------------------------------------
  * Diffusion arithmetic
@@ -146,6 +148,22 @@ size_t drs_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int KH
 int drs_conv2d_nchw(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
                     int Cout, int KH, int KW, int stride, int pad, int transposed, int out_pad, int relu,
                     void* workspace, size_t workspace_bytes, int impl, drs_stream_t stream);
+
+/* One up-sampling stage of the decoder as the eval plan runs it (split-bf16 kernels, activations in the plan's SP format):
+ *   y = conv2d(cat([conv_transpose2d(h, t_w, t_b, stride 2, padding 1, output_padding 1), att], 1), v_w, v_b, padding 1)
+ * computed WITHOUT the transposed convolution's output: ups.i.transform and the first Cc input channels of up_convs.i are
+ * one linear map (no activation between them), composed at pack time into a stride-2 transposed convolution with 3 x 3 /
+ * 3 x 2 / 2 x 3 / 2 x 2 taps per output phase (csrc/upfuse_sp.hip).
+ *   h: (N,Cc,LH,LW)  att: (N,Ch,2LH,2LW)  t_w: (Cc,Cc,3,3)  t_b: (Cc)  v_w: (Ch,Cc+Ch,3,3)  v_b: (Ch)  y: (N,Ch,2LH,2LW)
+ *   post2 / y2 (both or neither): y2 = y + post2[n][c] (the next UpConvBlock's x + relu(time_mlp(t)), reference :199)
+ *   fuse_w (fuse_dim,Ch) / fuse_b (fuse_dim): with Ch == 32, y is (N,fuse_dim,2LH,2LW) = conv1x1(y32) (the UNet's `output`)
+ * Cc, Ch multiples of 32.  Replaces UpConvBlock.transform + torch.cat + up_convs[i] (+ output),
+ * UNet_model_superres.py:206-207,376-377,379. */
+size_t drs_upconv_fused_workspace_bytes(int N, int Cc, int Ch, int LH, int LW);
+int drs_upconv_fused_nchw(const float* h, const float* att, const float* t_w, const float* t_b, const float* v_w,
+                          const float* v_b, const float* post2, const float* fuse_w, const float* fuse_b, int fuse_dim,
+                          float* y, float* y2, int N, int Cc, int Ch, int LH, int LW, void* workspace, size_t workspace_bytes,
+                          drs_stream_t stream);
 
 /* y = F.interpolate(x, scale_factor=scale, mode='bicubic') (align_corners=False, A=-0.75, border clamp),
  * integer scale.  x: (N,C,H,W) -> y: (N,C,H*scale,W*scale).  Replaces UNet_model_superres.py:349. */
@@ -254,6 +272,11 @@ int drs_unet_backward_labels(drs_plan* plan, const void* packed, void* packed_bw
 /* Per-op timing of the forward schedule: with profiling on, drs_unet_forward brackets every op with HIP events on
  * the stream it launches on; afterwards read (name, milliseconds, algorithmic FLOPs, algorithmic bytes) per op.
  * Used by bench.py for the roofline of the dominant kernel.  Not for use inside graph capture. */
+/* Synchronises `stream` and returns DRS_ERR_HIP if a wave of the wave-specialised kernels gave up waiting on an LDS
+ * counter since the weights were last packed into `packed` (a protocol bug; such a wave records it and ends instead of
+ * hanging or faulting the device: csrc/sp_sync.h).  Debug / test aid; a healthy run never sets it. */
+int drs_unet_check_faults(drs_plan* plan, const void* packed, drs_stream_t stream);
+
 int drs_unet_profile_enable(drs_plan* plan, int on);
 int drs_unet_profile_num_ops(const drs_plan* plan);
 int drs_unet_profile_read(drs_plan* plan, int i, char* name, int name_len, float* ms, double* flops, double* bytes);

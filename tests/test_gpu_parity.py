@@ -93,6 +93,59 @@ def test_conv2d_flavours(dev, case, impl):
             _assert_close(got, want, _tol(impl), f"conv {case} relu={relu}")
 
 
+# (N, Cc, Ch, LH, LW): one decoder stage at sizes that hit interior tiles, all four image borders, ragged tiles, several
+# channel groups / K-chunks, more items than CUs per XCD slice, and the 1-tile image
+UPFUSE_CASES = [
+    (2, 64, 32, 16, 16),     # stage-2 shape: one tile per image, 2 K-chunks
+    (1, 128, 64, 24, 40),    # ragged tiles on both axes, 2 channel groups, 4 K-chunks
+    (2, 256, 128, 32, 32),   # stage-0 shape: 2 x 2 tiles, 4 channel groups, 8 K-chunks
+    (1, 64, 32, 48, 48),     # 3 x 3 tiles: an interior tile (fast window path)
+    (3, 32, 32, 9, 17),      # smallest supported heights, odd sizes
+]
+TOL_UPFUSE = 1e-4  # measured ~1e-5 (16-bit operand mantissas, fp32 accumulation, fp32 edge vectors)
+
+
+@pytest.mark.parametrize("case", UPFUSE_CASES)
+def test_upconv_fused_matches_convtranspose_cat_conv(dev, case):
+    """ups.i.transform -> torch.cat -> up_convs.i as ONE composite transposed convolution + the att-half convolution
+    (csrc/upfuse_sp.hip) against the reference's three ops (UNet_model_superres.py:206-207,376-377) in fp32 on the CPU."""
+    from diffusionremotesensing_amd import hip_ops, synthetic
+    N, Cc, Ch, LH, LW = case
+    h = synthetic.tensor_normal(f"uf.h.{case}", (N, Cc, LH, LW))
+    att = synthetic.tensor_normal(f"uf.att.{case}", (N, Ch, 2 * LH, 2 * LW))
+    t_w = synthetic.tensor_normal(f"uf.tw.{case}", (Cc, Cc, 3, 3), std=(Cc * 2.25) ** -0.5)
+    t_b = synthetic.tensor_normal(f"uf.tb.{case}", (Cc,), std=0.3)
+    v_w = synthetic.tensor_normal(f"uf.vw.{case}", (Ch, Cc + Ch, 3, 3), std=((Cc + Ch) * 9) ** -0.5)
+    v_b = synthetic.tensor_normal(f"uf.vb.{case}", (Ch,), std=0.3)
+    post2 = synthetic.tensor_normal(f"uf.p2.{case}", (N, Ch), std=0.5)
+    want = F.conv2d(torch.cat([F.conv_transpose2d(h, t_w, t_b, stride=2, padding=1, output_padding=1), att], 1), v_w, v_b,
+                    padding=1)
+    args = [t.to(dev) for t in (h, att, t_w, t_b, v_w, v_b)]
+    got = hip_ops.upconv_fused(*args)
+    _assert_close(got, want, TOL_UPFUSE, f"upconv_fused {case}")
+    # borders are where the composite differs from the plain formula: check them on their own scale too
+    for sl in ((slice(None), slice(None), slice(0, 1)), (slice(None), slice(None), slice(-1, None)),
+               (slice(None), slice(None), slice(None), slice(0, 1)), (slice(None), slice(None), slice(None), slice(-1, None))):
+        _assert_close(got[sl], want[sl], TOL_UPFUSE, f"upconv_fused {case} edge")
+    got, got2 = hip_ops.upconv_fused(*args, post2=post2.to(dev))
+    _assert_close(got, want, TOL_UPFUSE, f"upconv_fused {case} (with second output)")
+    _assert_close(got2, want + post2[:, :, None, None], TOL_UPFUSE, f"upconv_fused {case} second output")
+    if Ch == 32:
+        f_w = synthetic.tensor_normal(f"uf.fw.{case}", (3, 32, 1, 1), std=32 ** -0.5)
+        f_b = synthetic.tensor_normal(f"uf.fb.{case}", (3,), std=0.2)
+        gotp = hip_ops.upconv_fused(*args, fuse_w=f_w.to(dev), fuse_b=f_b.to(dev))
+        _assert_close(gotp, F.conv2d(want, f_w, f_b), TOL_UPFUSE, f"upconv_fused {case} fused projection")
+
+
+def test_upconv_fused_rejects_bad_shapes(dev):
+    from diffusionremotesensing_amd import hip_ops
+    z = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(RuntimeError, match="multiples of 32"):
+        hip_ops.upconv_fused(z(1, 48, 4, 4), z(1, 16, 8, 8), z(48, 48, 3, 3), z(48), z(16, 64, 3, 3), z(16))
+    with pytest.raises(RuntimeError, match="do not fit"):
+        hip_ops.upconv_fused(z(1, 32, 4, 4), z(1, 32, 8, 9), z(32, 32, 3, 3), z(32), z(32, 64, 3, 3), z(32))
+
+
 def test_conv2d_rejects_unsupported(dev):
     from diffusionremotesensing_amd import hip_ops
     x = torch.zeros(1, 4, 8, 8, device=dev)
@@ -579,16 +632,16 @@ def test_full_length_chain_is_deterministic(dev, model):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DRS_SP": "0"}, {"DRS_SP": "0", "DRS_WS": "0"}, {"DRS_SPK": "0"}, {"DRS_FUSE_GATE": "0"},
-                                 {"DRS_CONCURRENT": "1"}, {"DRS_SPK": "2", "DRS_D3K": "0"}, {"DRS_D3K": "0", "DRS_S2K": "0"}],
+                                 {"DRS_CONCURRENT": "1"}, {"DRS_D3K": "0", "DRS_S2K": "0"}, {"DRS_UPFUSE": "0"}],
                          ids=["fp32-activations+ws", "fp32-activations+lockstep", "sp+lockstep", "sp-unfused-gate", "sp-two-streams",
-                              "sp-one-consumer-per-simd", "sp-without-direct-kernels"])
+                              "sp-without-direct-kernels", "sp-unfused-up"])
 def test_conv_kernel_variants_in_subprocess(env):
     """The kernel families of the eval split-bf16 plan are chosen once per process.  Default = SP-format activations with
     the wave-specialised SP kernel and the fused attention gate, serial stages; the switches select the older paths that
     the training / fp32 plans and small shapes still use: DRS_SP=0 fp32 channels-last activations (wave-specialised
     fp32-input kernel, DRS_WS=0: lock-step kernel only), DRS_SPK=0 SP format on the lock-step kernel, DRS_FUSE_GATE=0 the
-    five-launch attention gate, DRS_CONCURRENT=1 two-stream decoder stages, DRS_SPK=2 the one-consumer-per-SIMD variant of
-    the SP kernel (on every layer: DRS_D3K=0), DRS_D3K=0 / DRS_S2K=0 the plan without the direct-operand kernels (3x3 on the
+    five-launch attention gate, DRS_CONCURRENT=1 two-stream decoder stages, DRS_UPFUSE=0 the ConvTranspose + up_conv pair
+    instead of the composite up-sampling kernel, DRS_D3K=0 / DRS_S2K=0 the plan without the direct-operand kernels (3x3 on the
     32-channel layers, stride-2 and transposed convolutions).  All must reproduce the same goldens.  Own process, because
     the switches are read once."""
     import os
