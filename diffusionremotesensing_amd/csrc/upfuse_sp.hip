@@ -40,6 +40,13 @@
 
 namespace {
 
+#ifdef DRS_SP_TIMELINE
+__device__ unsigned long long drs_uf_tl[64];
+#define UF_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl[i] += t_ - tl_last; tl_last = t_; } while (0)
+#else
+#define UF_STAMP(i) do { } while (0)
+#endif
+
 struct UfGeom {
   static constexpr int IW = 18, NPIX = 18 * 18;
   static constexpr int NBLK = (NPIX + 7) / 8;  // window pieces of 8 pixels = 1 KB
@@ -102,6 +109,10 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
   sp_wait_lds();
   sp_barrier();
   int c = -1, ord = -1, n = 0, ty0 = 0, tx0 = 0, n0 = 0;  // current step: chunk, item ordinal, item coordinates (cells)
+#ifdef DRS_SP_TIMELINE
+  unsigned long long tl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long tl_begin = tl_last;
+#endif
 
   if (mover) {
     // ===================== movers =====================
@@ -148,13 +159,17 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
       // store group g (registers `set`) once its ring slot is free; `after` = vector-memory operations issued after its loads
       auto store_grp = [&](int g, int set, int after) __attribute__((always_inline)) {
         const unsigned q = 5u * (unsigned)k + (unsigned)g, fill = q / 3u, slot = q - 3u * fill;
+        UF_STAMP(0);
         if (fill > 0) sp_poll(sCR + slot, 4u * fill, d.fault);
+        UF_STAMP(1);
         sp_wait_vm(after);
+        UF_STAMP(2);
         char* dst = sW + slot * SLOT + my_piece;
 #pragma unroll
         for (int i = 0; i < WPC; ++i) *reinterpret_cast<u32x4*>(dst + i * 1024) = wr[set][i];
         sp_wait_lds();
         if (lane == 0) sp_bump(sCL + slot);
+        UF_STAMP(3);
       };
       load_grp(0, 0);
       // ---- window loads ----
@@ -182,8 +197,11 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
       load_grp(1, 1);
       store_grp(0, 0, nwin + WPC);
       load_grp(2, 0);
+      UF_STAMP(0);
       if (k >= 2) sp_poll(sWR + (k & 1), 8u * (unsigned)(k >> 1), d.fault);
+      UF_STAMP(4);
       sp_wait_vm(2 * WPC);
+      UF_STAMP(5);
       {
         char* buf = sWin + (k & 1) * WBUF + lane * 16;
 #pragma unroll
@@ -192,6 +210,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         sp_wait_lds();
         if (lane == 0) sp_bump(sWL + (k & 1));
       }
+      UF_STAMP(6);
       store_grp(1, 1, WPC);
       load_grp(3, 1);
       store_grp(2, 0, WPC);
@@ -221,7 +240,9 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
     // one column group: taps (py0: ty 0,1,2 | py1: ty 1,2) of input column tx for this wave's x-phase
     auto do_group = [&](const char* buf, int tx, unsigned q) __attribute__((always_inline)) {
       const unsigned fill = q / 3u, slot = q - 3u * fill;
+      UF_STAMP(0);
       sp_poll_lds(sCL + slot, 4u * (fill + 1u), d.fault);
+      UF_STAMP(1);
       const char* sb = wlane + slot * SLOT;
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty)
@@ -249,8 +270,10 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
           for (int t = 0; t < 2; ++t) wf[1][t] = P::load(sb, W_IMAGE, (size_t)(4 * 2048 + t * 256));
         }
       }
+      UF_STAMP(2);
       sp_wait_lds();  // all five taps are in registers: the ring slot may be refilled
       if (lane == 0) sp_bump(sCR + slot);
+      UF_STAMP(3);
       // pass py1: ty 1 (wf[0]) and ty 2 (wf[1]) over window rows 1..5
 #pragma unroll
       for (int wr = 1; wr < RPW + 2; ++wr) {
@@ -287,7 +310,9 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         for (int j = 0; j < 8; ++j) tab[j] = (B + lr_s) * 128 + ((kg_s + B + j + lr_s) & 7) * 16;
       }
       const char* buf = sWin + (k & 1) * WBUF;
+      UF_STAMP(7);
       sp_poll_lds(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1), d.fault);  // window k is in its buffer
+      UF_STAMP(4);
       const unsigned q0 = 5u * (unsigned)k;
       if constexpr (px == 0) {
         do_group(buf, 0, q0);
@@ -297,8 +322,10 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         do_group(buf, 1, q0 + 2u);
         do_group(buf, 2, q0 + 4u);
       }
+      UF_STAMP(5);
       sp_wait_lds();  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
       if (lane == 0) sp_bump(sWR + (k & 1));
+      UF_STAMP(6);
       if (c == nck - 1) {
         // ---------------- item epilogue ----------------
         // lane (lr, kg) holds, per (cell row r, y-phase py), the 8 consecutive logical channels n0 + kg*8 .. +7 (tile 0:
@@ -420,6 +447,14 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
     if (px_wave == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
   }
+#ifdef DRS_SP_TIMELINE
+  if (blockIdx.x == 0 && (wid == 0 || wid == 4 || wid == 8) && lane == 0) {
+    const int o = wid == 0 ? 0 : (wid == 4 ? 16 : 32);
+    for (int i = 0; i < 10; ++i) drs_uf_tl[o + i] = tl[i];
+    drs_uf_tl[o + 10] = S;
+    drs_uf_tl[o + 11] = __builtin_amdgcn_s_memtime() - tl_begin;
+  }
+#endif
 }
 
 // ---- pack: composite operand image ------------------------------------------------------------------------------------
@@ -520,56 +555,92 @@ __device__ __forceinline__ float uf_sp_value(const char* base, int ci) {  // ele
   const char* g = base + (ci >> 5) * 128 + (ci & 31) * 2;
   return (float)*reinterpret_cast<const __bf16*>(g) + (float)*reinterpret_cast<const __bf16*>(g + 64);
 }
-__global__ __launch_bounds__(256) void upfuse_edges_kernel(UpFuseEdgeDesc d) {
+// One block = (image n, kind: 0 = first row | 1 = first column, segment of 4 cells = 8 output positions along the edge).
+// 1024 threads = Ch output channels x KS slices of the input channels; the slices' partial sums meet in LDS and are added
+// in a fixed order (bit-reproducible: no atomics).  Row blocks also write the last row's bias terms and, in segment 0, the
+// corner (0, 0) with its column -1 paths; column blocks write the last column's bias terms and the corner (OH-1, 0).
+constexpr int UF_ESEG = 4;
+__global__ __launch_bounds__(1024) void upfuse_edges_kernel(UpFuseEdgeDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float esm[];
   const int OH = 2 * d.LH, OW = 2 * d.LW, Ch = d.Ch, Cc = d.Cc;
-  const size_t n_eh = (size_t)d.N * 2 * OW * Ch, n_ev = (size_t)d.N * 2 * OH * Ch;
+  const int seg = blockIdx.x, kind = blockIdx.y, n = blockIdx.z;
+  const int L = kind ? d.LH : d.LW;  // cells along this edge
+  const int m0 = seg * UF_ESEG;
+  if (m0 >= L) return;
+  const int tid = threadIdx.x;
+  const int KS = 1024 / Ch, co = tid % Ch, ks = tid / Ch;
+  float* hs = esm;                     // [7][Cc]: cells m0-1 .. m0+4 of the edge, then pixel (1, 0) (corner term)
+  float* part = esm + 7 * Cc;          // [KS][9][Ch]
   const size_t mat = (size_t)Cc * Ch;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_eh + n_ev; i += (size_t)gridDim.x * blockDim.x) {
-    const bool horiz = i < n_eh;
-    const size_t r = horiz ? i : i - n_eh;
-    const int co = (int)(r % Ch);
-    const int pos = (int)((r / Ch) % (horiz ? OW : OH));
-    const int which = (int)((r / ((size_t)Ch * (horiz ? OW : OH))) & 1);
-    const int n = (int)(r / ((size_t)Ch * (horiz ? OW : OH) * 2));
-    const int oy = horiz ? (which ? OH - 1 : 0) : pos;
-    const int ox = horiz ? pos : (which ? OW - 1 : 0);
-    float val = 0.f;
-    if (horiz || (oy > 0 && oy < OH - 1)) {
-      for (int kvy = 0; kvy < 3; ++kvy)
-        for (int kvx = 0; kvx < 3; ++kvx) {
-          const bool out = (oy == 0 && kvy == 0) || (oy == OH - 1 && kvy == 2) || (ox == 0 && kvx == 0) || (ox == OW - 1 && kvx == 2);
-          if (out) val -= d.bt[(kvy * 3 + kvx) * Ch + co];
-        }
-      auto pixel = [&](int y, int x) {
-        return reinterpret_cast<const char*>(d.in) + ((((size_t)n * d.LH + y) * d.LW + x) * d.in_cs + d.in_co) * 4;
-      };
-      if (oy == 0) {  // paths through row -1 of the transposed convolution: a 1-D composite over the first row of h
-        const int m = ox >> 1, p = ox & 1;
-        for (int t = p; t < 3; ++t) {
-          const int x = m + t - 1;
-          if (x < 0 || x >= d.LW) continue;
-          const float* w = d.rt + (size_t)(p == 0 ? t : 2 + t) * mat + co;
-          const char* hp = pixel(0, x);
-          float a = 0.f;
-          for (int ci = 0; ci < Cc; ++ci) a += w[(size_t)ci * Ch] * uf_sp_value(hp, ci);
-          val -= a;
-        }
-      }
-      if (ox == 0) {  // paths through column -1 (without those through row -1, already counted above)
-        const int m = oy >> 1, p = oy & 1;
-        for (int t = p; t < 3; ++t) {
-          const int y = m + t - 1;
-          if (y < 0 || y >= d.LH) continue;
-          const int jj = (oy == 0 && t == 1) ? 5 : (p == 0 ? t : 2 + t);
-          const float* w = d.rl + (size_t)jj * mat + co;
-          const char* hp = pixel(y, 0);
-          float a = 0.f;
-          for (int ci = 0; ci < Cc; ++ci) a += w[(size_t)ci * Ch] * uf_sp_value(hp, ci);
-          val -= a;
-        }
+  auto pixel = [&](int y, int x) {
+    return reinterpret_cast<const char*>(d.in) + ((((size_t)n * d.LH + y) * d.LW + x) * d.in_cs + d.in_co) * 4;
+  };
+  for (int i = tid; i < 7 * Cc; i += 1024) {
+    const int cell = i / Cc, ci = i - cell * Cc;
+    int y, x;
+    bool ok;
+    if (cell < 6) {
+      const int m = m0 - 1 + cell;
+      ok = m >= 0 && m < L;
+      y = kind ? m : 0; x = kind ? 0 : m;
+    } else {
+      ok = d.LH > 1; y = 1; x = 0;
+    }
+    hs[i] = ok ? uf_sp_value(pixel(ok ? y : 0, ok ? x : 0), ci) : 0.f;
+  }
+  __syncthreads();
+  const bool corner = kind == 0 && seg == 0;
+  float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* W = (kind ? d.rl : d.rt) + co;
+  for (int ci = ks; ci < Cc; ci += KS) {
+    const float* w = W + (size_t)ci * Ch;
+    const float w0 = w[0], w1 = w[mat], w2 = w[2 * mat], w3 = w[3 * mat], w4 = w[4 * mat];
+    float h[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) h[c] = hs[c * Cc + ci];
+#pragma unroll
+    for (int a = 0; a < UF_ESEG; ++a) {
+      acc[2 * a] += w0 * h[a] + w1 * h[a + 1] + w2 * h[a + 2];   // even position: cells m-1, m, m+1
+      acc[2 * a + 1] += w3 * h[a + 1] + w4 * h[a + 2];           // odd position: cells m, m+1
+    }
+    if (corner)  // output (0, 0): paths through column -1 that do not pass row -1: rl0 x h[0][0] + rl[(0, 2)] x h[1][0]
+      acc[8] += d.rl[5 * mat + (size_t)ci * Ch + co] * h[1] + d.rl[2 * mat + (size_t)ci * Ch + co] * hs[6 * Cc + ci];
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) part[(ks * 9 + j) * Ch + co] = acc[j];
+  __syncthreads();
+  auto biasdelta = [&](int oy, int ox, int c) {
+    float v = 0.f;
+    for (int kvy = 0; kvy < 3; ++kvy)
+      for (int kvx = 0; kvx < 3; ++kvx)
+        if ((oy == 0 && kvy == 0) || (oy == OH - 1 && kvy == 2) || (ox == 0 && kvx == 0) || (ox == OW - 1 && kvx == 2))
+          v -= d.bt[(kvy * 3 + kvx) * Ch + c];
+    return v;
+  };
+  for (int idx = tid; idx < 8 * Ch; idx += 1024) {
+    const int j = idx / Ch, c = idx - j * Ch;
+    const int pos = 2 * m0 + j;
+    if (pos >= 2 * L) continue;
+    float D = 0.f, Dc = 0.f;
+    for (int k = 0; k < KS; ++k) {
+      D += part[(k * 9 + j) * Ch + c];
+      if (corner && j == 0) Dc += part[(k * 9 + 8) * Ch + c];
+    }
+    if (kind == 0) {
+      const int ox = pos;
+      d.eh[(((size_t)n * 2 + 0) * OW + ox) * Ch + c] = biasdelta(0, ox, c) - D - Dc;
+      if (ox != 0 && OH > 1) d.eh[(((size_t)n * 2 + 1) * OW + ox) * Ch + c] = biasdelta(OH - 1, ox, c);
+    } else {
+      const int oy = pos;
+      if (oy == 0) continue;  // the row block owns output row 0
+      const float v = biasdelta(oy, 0, c) - D;
+      if (oy == OH - 1) {
+        d.eh[(((size_t)n * 2 + 1) * OW + 0) * Ch + c] = v;
+      } else {
+        d.ev[(((size_t)n * 2 + 0) * OH + oy) * Ch + c] = v;
+        d.ev[(((size_t)n * 2 + 1) * OH + oy) * Ch + c] = biasdelta(oy, OW - 1, c);
       }
     }
-    (horiz ? d.eh : d.ev)[r] = val;
   }
 }
 
@@ -615,10 +686,13 @@ int drs_launch_upfuse_pack(const float* v_w, const float* v_b, const float* t_w,
 }
 
 int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s) {
-  const size_t total = (size_t)d.N * 2 * (2 * d.LW + 2 * d.LH) * d.Ch;
-  if (total == 0) return DRS_OK;
-  const int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(upfuse_edges_kernel, dim3(blocks), dim3(256), 0, s, d);
+  if ((size_t)d.N * d.LH * d.LW == 0) return DRS_OK;
+  DRS_REQUIRE(d.Ch >= 32 && d.Ch <= 1024 && 1024 % d.Ch == 0 && d.Cc % 32 == 0, DRS_ERR_SHAPE, "upfuse_edges: Cc=%d Ch=%d", d.Cc,
+              d.Ch);
+  const size_t lds = ((size_t)7 * d.Cc + (size_t)9 * 1024) * 4;
+  DRS_REQUIRE(lds <= 64 * 1024, DRS_ERR_SHAPE, "upfuse_edges: Cc=%d too wide", d.Cc);
+  const int segs = drs_cdiv(d.LH > d.LW ? d.LH : d.LW, UF_ESEG);
+  hipLaunchKernelGGL(upfuse_edges_kernel, dim3(segs, 2, d.N), dim3(1024), lds, s, d);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -652,6 +726,35 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
   else
     hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
   DRS_CHECK_HIP(hipGetLastError());
+#ifdef DRS_SP_TIMELINE
+  {
+    unsigned long long h[64];
+    hipEvent_t e0, e1;
+    float ms = 0.f;
+    DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
+    DRS_CHECK_HIP(hipEventRecord(e0, s));
+    if (d.fuse_out)  // timed repeat (same result)
+      hipLaunchKernelGGL(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
+    else
+      hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
+    DRS_CHECK_HIP(hipEventRecord(e1, s));
+    DRS_CHECK_HIP(hipStreamSynchronize(s));
+    DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    DRS_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(drs_uf_tl), sizeof(h)));
+    const double sc = h[10] ? 1.0 / (double)h[10] : 0.0;
+    fprintf(stderr, "upfuse Cc=%d Ch=%d LH=%d fuse=%d: %.1f us, %llu steps/block, wave0 alive %llu ticks = %.2f GHz, %.0f ticks/step\n", d.Cc, d.Ch,
+            d.LH, d.fuse_out ? 1 : 0, ms * 1e3, h[10], h[11], h[11] / (ms * 1e6), h[11] * sc);
+    for (int w = 0; w < 2; ++w) {
+      const unsigned long long* t = h + 16 * w;
+      fprintf(stderr, "   C%d (px%d): epi+top %.0f WLwait %.0f | grp: pre %.0f CLwait %.0f pass0 %.0f rel %.0f | pass1+tail %.0f WRrel %.0f\n", 4 * w, w,
+              t[7] * sc, t[4] * sc, t[0] * sc, t[1] * sc, t[2] * sc, t[3] * sc, t[5] * sc, t[6] * sc);
+    }
+    const unsigned long long* t = h + 32;
+    fprintf(stderr, "   M0: loads/other %.0f CRwait %.0f vmwait %.0f store %.0f | WRwait %.0f vmwait %.0f winstore %.0f\n", t[0] * sc, t[1] * sc,
+            t[2] * sc, t[3] * sc, t[4] * sc, t[5] * sc, t[6] * sc);
+  }
+#endif
   return DRS_OK;
 }
 
