@@ -183,6 +183,10 @@ struct UpFuseDesc {
   float* out2; int out2_cs, out2_co;   // optional second SP output: out + post2[n][c]
   const float* post2; int post2_cs;
   const float* fuse_w; const float* fuse_b; float* fuse_out; int fuse_dim;  // Ch == 32: fp32 NCHW projection (the UNet's `output`)
+  // fuse_acc: fuse_out already holds the PROJECTED att-half (the projection is linear: fuse_w (comp + att_half + b) =
+  // fuse_w comp + fuse_w att_half + ...), written by the att-half convolution's own fused-projection epilogue: this kernel
+  // adds its part.  12.6 MB instead of the 134 MB of 32-channel partial sums per forward at 256 x 256; `res` is null then.
+  int fuse_acc;
   const void* zero_line;
   unsigned* fault;
 };
@@ -191,13 +195,16 @@ struct UpFuseEdgeDesc {
   const float* in; int in_cs, in_co; int N, LH, LW, Cc, Ch;
   const float* rt; const float* rl; const float* bt;
   float* eh; float* ev;
+  const void* wimg;       // MFMA operand image of rt / rl (drs_upfuse_edge_image_bytes)
+  const void* zero_line;
 };
 bool drs_upfuse_supported(int Cc, int Ch, int LH, int LW);
 size_t drs_upfuse_weight_bytes(int Cc, int Ch);       // composite operand image
 size_t drs_upfuse_aux_floats(int Cc, int Ch);         // rt | rl | bt | bias, in this order
 // v_w: up_convs.i.weight (Ch, Cc + Ch, 3, 3); v_b: its bias; t_w: ups.i.transform.weight (Cc, Cc, 3, 3); t_b: its bias
+size_t drs_upfuse_edge_image_bytes(int Cc, int Ch);  // rt | rl as MFMA operands (edge kernel)
 int drs_launch_upfuse_pack(const float* v_w, const float* v_b, const float* t_w, const float* t_b, int Cc, int Ch, void* dst_w,
-                           float* dst_aux, hipStream_t s);
+                           float* dst_aux, void* dst_edge, hipStream_t s);
 int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s);
 int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s);
 int drs_launch_nchw_to_sp(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);

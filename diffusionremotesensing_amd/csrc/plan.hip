@@ -224,7 +224,7 @@ extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, f
 // ------------------------------------------------------------------------------------------------
 static size_t upfused_sizes(int N, int Cc, int Ch, int LH, int LW, size_t* o) {
   // o[0] h (SP), o[1] att (SP), o[2] att-half partial sums, o[3] result (SP), o[4] composite image, o[5] aux, o[6] att-half
-  // weights, o[7] att-half bias, o[8] eh, o[9] ev, o[10] zero line + fault word, o[11] projection output staging (unused)
+  // weights, o[7] att-half bias, o[8] eh, o[9] ev, o[10] zero line + fault word, o[11] edge operand image
   const size_t hi = (size_t)N * 4 * LH * LW;
   size_t b = 0;
   o[0] = b; b += align_up((size_t)N * LH * LW * Cc * 4);
@@ -238,6 +238,7 @@ static size_t upfused_sizes(int N, int Cc, int Ch, int LH, int LW, size_t* o) {
   o[8] = b; b += align_up((size_t)N * 2 * 2 * LW * Ch * 4);
   o[9] = b; b += align_up((size_t)N * 2 * 2 * LH * Ch * 4);
   o[10] = b; b += 512;
+  o[11] = b; b += align_up(drs_upfuse_edge_image_bytes(Cc, Ch));
   return b + 256;
 }
 extern "C" size_t drs_upconv_fused_workspace_bytes(int N, int Cc, int Ch, int LH, int LW) {
@@ -264,9 +265,9 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
   DRS_CHECK_HIP(hipMemsetAsync(base + o[10], 0, 512, s));
   if ((rc = drs_launch_nchw_to_sp(h, (float*)(base + o[0]), N, Cc, LH, LW, s))) return rc;
   if ((rc = drs_launch_nchw_to_sp(att, (float*)(base + o[1]), N, Ch, OH, OW, s))) return rc;
-  if ((rc = drs_launch_upfuse_pack(v_w, v_b, t_w, t_b, Cc, Ch, base + o[4], (float*)(base + o[5]), s))) return rc;
+  if ((rc = drs_launch_upfuse_pack(v_w, v_b, t_w, t_b, Cc, Ch, base + o[4], (float*)(base + o[5]), base + o[11], s))) return rc;
   if ((rc = drs_launch_pack_conv_mfma(v_w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + o[6], (float*)(base + o[7]), Ch,
-                                      Ch, 9, 0, DRS_IMPL_MFMA_BF16X3, s, 0, 0, 0, 0, 1, Cc + Ch, Cc)))
+                                      Ch, 9, 0, DRS_IMPL_MFMA_BF16X3, s, 0, 0, 0, 0, fuse_w ? 0 : 1, Cc + Ch, Cc)))
     return rc;
   const float* aux = (const float*)(base + o[5]);
   const size_t mat = (size_t)Cc * Ch;
@@ -277,12 +278,17 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
     e.N = N; e.LH = LH; e.LW = LW; e.Cc = Cc; e.Ch = Ch;
     e.rt = aux; e.rl = aux + 5 * mat; e.bt = aux + 11 * mat;
     e.eh = (float*)(base + o[8]); e.ev = (float*)(base + o[9]);
+    e.wimg = base + o[11]; e.zero_line = base + o[10];
     if ((rc = drs_launch_upfuse_edges(e, s))) return rc;
   }
   {
     TapConv d = conv_desc((const float*)(base + o[1]), N, OH, OW, Ch, Ch, 0, (const float*)(base + o[6]), (const float*)(base + o[7]),
                           (float*)(base + o[2]), Ch, Ch, 0, 3, 3, 1, 1);
     d.in_sp = d.out_sp = 1; d.zero_line = base + o[10]; d.fault = fault;
+    if (fuse_w) {  // projected att-half straight into y (the plan's stage 2)
+      d.out = nullptr; d.out_sp = 0;
+      d.fuse_w = fuse_w; d.fuse_b = (const float*)(base + o[7]); d.fuse_out = y; d.fuse_dim = fuse_dim;
+    }
     if ((rc = drs_launch_tapconv_mfma(d, DRS_IMPL_MFMA_BF16X3, s))) return rc;
   }
   {
@@ -295,6 +301,7 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
     u.eh = (const float*)(base + o[8]); u.ev = (const float*)(base + o[9]);
     u.zero_line = base + o[10]; u.fault = fault;
     if (fuse_w) {
+      u.res = nullptr; u.fuse_acc = 1;
       u.fuse_w = fuse_w; u.fuse_b = fuse_b; u.fuse_out = y; u.fuse_dim = fuse_dim;
     } else {
       u.out = (float*)(base + o[3]); u.out_cs = Ch; u.out_co = 0;
@@ -355,7 +362,7 @@ struct DecStage {
   // ups.i.transform composed with the x-half of up_convs.i (upfuse_sp.hip): composite operand image, edge / bias weights,
   // and the att-half of up_convs.i packed as its own Ch -> Ch 3x3 convolution (no bias: it is in the composite's)
   bool upfuse = false;
-  size_t uf_w_off = 0, uf_aux_off = 0, ah_w_off = 0, ah_b_off = 0;
+  size_t uf_w_off = 0, uf_aux_off = 0, uf_edge_off = 0, ah_w_off = 0, ah_b_off = 0;
   int t_PA = -1;                  // att-half partial sums (SP), B x Ch x 2lh x 2lw
   size_t o_eh = 0, o_ev = 0;      // workspace: edge vectors of this forward
 };
@@ -620,6 +627,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     if (d.upfuse) {
       d.uf_w_off = cur; cur += align_up(drs_upfuse_weight_bytes(Cc, Ch));
       d.uf_aux_off = cur; cur += align_up(drs_upfuse_aux_floats(Cc, Ch) * 4);
+      d.uf_edge_off = cur; cur += align_up(drs_upfuse_edge_image_bytes(Cc, Ch));
       d.ah_w_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(Ch, Ch, 9, DRS_IMPL_MFMA_BF16X3));
       d.ah_b_off = cur; cur += align_up((size_t)Ch * 4);
     }
@@ -686,8 +694,10 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
       DecStage& d = p->dec[i];
       if (!d.upfuse) continue;
       const int lh = H >> (3 - i), lw = W >> (3 - i), Ch = kUp[i + 1];
-      d.t_PA = p->T("up_convs." + std::to_string(i) + ".att_half", ws, B, Ch, 2 * lh, 2 * lw);
-      mark(d.t_PA);
+      if (i < 2) {  // (stage 2 hands its att-half over projected, through the output tensor)
+        d.t_PA = p->T("up_convs." + std::to_string(i) + ".att_half", ws, B, Ch, 2 * lh, 2 * lw);
+        mark(d.t_PA);
+      }
       d.o_eh = ws; ws += align_up((size_t)B * 2 * (2 * lw) * Ch * 4);
       d.o_ev = ws; ws += align_up((size_t)B * 2 * (2 * lh) * Ch * 4);
     }
@@ -836,11 +846,12 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     if (!d.upfuse) continue;
     const int Cc = kUp[i], Ch = kUp[i + 1];
     if ((rc = drs_launch_upfuse_pack(F(d.upconv.w), F(d.upconv.b), F(d.transform.w), F(d.transform.b), Cc, Ch, base + d.uf_w_off,
-                                     (float*)(base + d.uf_aux_off), s)))
+                                     (float*)(base + d.uf_aux_off), base + d.uf_edge_off, s)))
       return rc;
-    // att-half: input channels [Cc, Cc + Ch) of up_convs.i, SP output rows, zero bias
+    // att-half: input channels [Cc, Cc + Ch) of up_convs.i, zero bias; SP output rows in stages 0 / 1, plain MFMA rows in
+    // stage 2, whose att-half goes through the fused output projection instead of being stored
     if ((rc = drs_launch_pack_conv_mfma(F(d.upconv.w), nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + d.ah_w_off,
-                                        (float*)(base + d.ah_b_off), Ch, Ch, 9, 0, impl, s, 0, 0, 0, 0, 1, Cc + Ch, Cc)))
+                                        (float*)(base + d.ah_b_off), Ch, Ch, 9, 0, impl, s, 0, 0, 0, 0, i < 2 ? 1 : 0, Cc + Ch, Cc)))
       return rc;
   }
   for (PlanarConv* L : plan->planars) {
@@ -1237,6 +1248,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         e.N = B; e.LH = lh; e.LW = lw; e.Cc = Cc; e.Ch = Ch;
         e.rt = aux; e.rl = aux + 5 * mat; e.bt = aux + 11 * mat;
         e.eh = eh; e.ev = ev;
+        e.wimg = pk + st.uf_edge_off; e.zero_line = zero_line;
         const double epix = (double)B * 2.0 * (lh + lw);
         prof_begin(plan, "up_convs." + std::to_string(i) + ".edges", 2.0 * epix * 2.5 * Cc * Ch, 4.0 * epix * (Cc + 4.0 * Ch), s);
         rc = drs_launch_upfuse_edges(e, s);
@@ -1246,8 +1258,18 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       if (concurrent) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));  // the attention half of cat.i is complete
       {
         TapConv d = conv_desc(cat, B, 2 * lh, 2 * lw, Ch, Cc + Ch, Cc, (const float*)(pk + st.ah_w_off),
-                              (const float*)(pk + st.ah_b_off), TP(st.t_PA), Ch, Ch, 0, 3, 3, 1, 1);
-        d.in_sp = d.out_sp = 1; d.zero_line = zero_line; d.fault = plan->fault_ptr;
+                              (const float*)(pk + st.ah_b_off), i < 2 ? TP(st.t_PA) : nullptr, Ch, Ch, 0, 3, 3, 1, 1);
+        d.in_sp = 1; d.out_sp = 1; d.zero_line = zero_line; d.fault = plan->fault_ptr;
+        if (i == 2) {
+          // the `output` projection is linear: the att-half is projected HERE (its own fused-projection epilogue, zero bias)
+          // into the caller's output tensor and the composite kernel adds its part: 12.6 MB written and read back instead
+          // of the 134 MB of 32-channel partial sums
+          d.out = nullptr; d.out_sp = 0;
+          d.fuse_w = (const float*)(pk + plan->o_out_w);
+          d.fuse_b = (const float*)(pk + st.ah_b_off);  // zeros
+          d.fuse_out = out;
+          d.fuse_dim = c.out_dim;
+        }
         prof_begin(plan, "up_convs." + std::to_string(i) + ".att", conv_flops(d), conv_bytes(d), s);
         rc = drs_launch_tapconv_mfma(d, c.impl, s);
         prof_end(plan, s);
@@ -1259,10 +1281,11 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         u.N = B; u.LH = lh; u.LW = lw; u.Cc = Cc; u.Ch = Ch;
         u.w = pk + st.uf_w_off;
         u.bias = aux + 11 * mat + 9 * Ch;
-        u.res = TP(st.t_PA); u.res_cs = Ch; u.res_co = 0;
+        if (i < 2) { u.res = TP(st.t_PA); u.res_cs = Ch; u.res_co = 0; }
         u.eh = eh; u.ev = ev;
         u.zero_line = zero_line; u.fault = plan->fault_ptr;
         if (i == 2) {  // output 1x1 conv (:379) rides in the epilogue; the 32-channel tensor is never written
+          u.res = nullptr; u.fuse_acc = 1;
           u.fuse_w = (const float*)(pk + plan->o_out_w);
           u.fuse_b = (const float*)(pk + plan->o_out_b);
           u.fuse_out = out;

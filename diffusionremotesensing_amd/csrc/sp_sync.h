@@ -58,6 +58,14 @@ __device__ __forceinline__ void sp_poll_lds(sp_flag_ptr f, unsigned target, unsi
   }
   asm volatile("" ::: "memory");
 }
+// Release without draining the LDS queue: the LDS executes one wave's operations in order, so an add issued after the
+// fragment reads (or the staging writes) of a buffer is PERFORMED after them, whatever is still in flight towards the
+// registers.  One lane adds; the compiler barrier keeps the memory operations of the source on their side.
+__device__ __forceinline__ void sp_release(sp_flag_ptr f, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void sp_bump(sp_flag_ptr f) {
   __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

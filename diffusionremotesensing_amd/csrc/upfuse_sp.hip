@@ -116,16 +116,17 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
 
   if (mover) {
     // ===================== movers =====================
-    // global -> registers -> LDS, everything a group / a window ahead of the consumers (conv_sp_movers.inc has the
-    // measurements behind this form).  Protocol of step k (window buffer k & 1; group q = 5 k + g in ring slot q % 3):
-    //   loads: group 0, window, group 1;  then, each store as soon as its destination is free and its loads have landed:
-    //   wait CR[slot(q0)] -> store group 0 -> CL;  load group 2
-    //   wait WR[k & 1] (the consumers left the buffer in step k - 2) -> store window -> WL
-    //   wait CR -> store group 1 -> CL; load group 3 | group 2; load group 4 | group 3 | group 4
+    // global -> registers -> LDS (conv_sp_movers.inc has the measurements behind this form).  Step k uses window buffer
+    // k & 1 and the ring slots q % 3 of its groups q = 5 k + g.  A mover iteration:
+    //   loads of groups 0, 1 | per group g: wait CR[slot] (the four consumers of the group that used the slot before hold
+    //   it in registers) -> counted vmcnt -> store -> CL[slot]; the loads of group g + 2 follow into the freed registers
+    //   between groups 3 and 4: the WINDOW OF STEP k + 1 (loads after group 3's, store once WR[(k+1) & 1] says the consumers
+    //   have left that buffer in step k - 1): it lands a whole step before its first reader polls WL.
     //   consumer (rw, px) of step k: wait WL[k & 1]; for its groups: wait CL[slot] -> read 3 taps -> MFMA pass py0 (reads the
     //   other 2 taps under its tail) -> CR[slot] -> MFMA pass py1;  after the last group WR[k & 1] -> epilogue of the item
     // A slot's CR counts 4 releases per group (the four waves of the group's x-phase), its CL 4 landings (the four movers).
-    // Every wait is for an event whose own prerequisites lie strictly earlier in this order: no cycle.
+    // Every wait is for an event whose own prerequisites lie strictly earlier in this order: no cycle.  Releases are plain
+    // LDS adds issued behind the reads / writes they publish (in-order LDS queue: sp_sync.h), never a queue drain.
     const int pw = wid - 8;
     __builtin_amdgcn_s_setprio(3);
     const char* zero = reinterpret_cast<const char*>(d.zero_line) + (lane & 15) * 16;
@@ -148,6 +149,50 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
     const int nwin = pw == 0 ? NPW : NPW - 1;
     const char* wg = reinterpret_cast<const char*>(d.w);
     const unsigned my_piece = (unsigned)(pw * WPC) * 1024u + (unsigned)lane * 16u;
+    // window of step (n_, ty_, tx_, chunk c_) -> registers
+    auto win_load = [&](int n_, int ty_, int tx_, int c_) __attribute__((always_inline)) {
+      if (ty_ >= 1 && ty_ + TH + 1 <= d.LH && tx_ >= 1 && tx_ + TW + 1 <= d.LW) {
+        // fast path: every window pixel inside the image
+        const char* base = reinterpret_cast<const char*>(d.in) +
+                           ((((long long)n_ * d.LH + (ty_ - 1)) * d.LW + (tx_ - 1)) * d.in_cs + d.in_co) * 4 + c_ * 128;
+#pragma unroll
+        for (int i = 0; i < NPW - 1; ++i) ww[i] = *reinterpret_cast<const u32x4*>(base + (unsigned)off1[i]);
+        if (pw == 0) ww[NPW - 1] = *reinterpret_cast<const u32x4*>(tail_ok ? base + (unsigned)off1[NPW - 1] : zero);
+      } else {
+        // border tiles: per-lane validity; anything outside the image reads the zero line
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          if (i < nwin) {
+            const int p = (pw + 4 * i) * 8 + l_px;
+            const int py = (p * 3641) >> 16, px = p - py * IW;
+            const int iy = ty_ - 1 + py, ix = tx_ - 1 + px;
+            const bool ok = p < G::NPIX && iy >= 0 && iy < d.LH && ix >= 0 && ix < d.LW;
+            const char* src = reinterpret_cast<const char*>(d.in) +
+                              ((((long long)n_ * d.LH + iy) * d.LW + ix) * d.in_cs + d.in_co) * 4 + c_ * 128 + l_off1;
+            ww[i] = *reinterpret_cast<const u32x4*>(ok ? src : zero);
+          }
+      }
+    };
+    // registers -> window buffer kk & 1, once the consumers have left it (step kk - 2); `after` as in store_grp
+    auto win_store = [&](int kk, int after) __attribute__((always_inline)) {
+      UF_STAMP(0);
+      if (kk >= 2) sp_poll(sWR + (kk & 1), 8u * (unsigned)(kk >> 1), d.fault);
+      UF_STAMP(4);
+      sp_wait_vm(after);
+      UF_STAMP(5);
+      char* buf = sWin + (kk & 1) * WBUF + lane * 16;
+#pragma unroll
+      for (int i = 0; i < NPW; ++i)
+        if (i < nwin) *reinterpret_cast<u32x4*>(buf + (pw + 4 * i) * 1024) = ww[i];
+      sp_release(sWL + (kk & 1), lane);
+      UF_STAMP(6);
+    };
+    {  // the first window; every later one is fetched and stored a whole step ahead, in the shadow of the previous step
+      int n_, ty_, tx_, n0_;
+      item_of(0, n_, ty_, tx_, n0_);
+      win_load(n_, ty_, tx_, 0);
+      win_store(0, 0);
+    }
     for (int k = 0; k < S; ++k) {
       if (++c == nck) c = 0;
       if (c == 0) item_of(++ord, n, ty0, tx0, n0);
@@ -167,55 +212,26 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         char* dst = sW + slot * SLOT + my_piece;
 #pragma unroll
         for (int i = 0; i < WPC; ++i) *reinterpret_cast<u32x4*>(dst + i * 1024) = wr[set][i];
-        sp_wait_lds();
-        if (lane == 0) sp_bump(sCL + slot);
+        sp_release(sCL + slot, lane);
         UF_STAMP(3);
       };
+      const bool more = k + 1 < S;
+      const int nw2 = more ? nwin : 0;  // window loads of step k + 1, issued between the loads of groups 3 and 4
       load_grp(0, 0);
-      // ---- window loads ----
-      if (ty0 >= 1 && ty0 + TH + 1 <= d.LH && tx0 >= 1 && tx0 + TW + 1 <= d.LW) {
-        // fast path: every window pixel inside the image
-        const char* base = reinterpret_cast<const char*>(d.in) +
-                           ((((long long)n * d.LH + (ty0 - 1)) * d.LW + (tx0 - 1)) * d.in_cs + d.in_co) * 4 + c * 128;
-#pragma unroll
-        for (int i = 0; i < NPW - 1; ++i) ww[i] = *reinterpret_cast<const u32x4*>(base + (unsigned)off1[i]);
-        if (pw == 0) ww[NPW - 1] = *reinterpret_cast<const u32x4*>(tail_ok ? base + (unsigned)off1[NPW - 1] : zero);
-      } else {
-        // border tiles: per-lane validity; anything outside the image reads the zero line
-#pragma unroll
-        for (int i = 0; i < NPW; ++i)
-          if (i < nwin) {
-            const int p = (pw + 4 * i) * 8 + l_px;
-            const int py = (p * 3641) >> 16, px = p - py * IW;
-            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-            const bool ok = p < G::NPIX && iy >= 0 && iy < d.LH && ix >= 0 && ix < d.LW;
-            const char* src = reinterpret_cast<const char*>(d.in) +
-                              ((((long long)n * d.LH + iy) * d.LW + ix) * d.in_cs + d.in_co) * 4 + c * 128 + l_off1;
-            ww[i] = *reinterpret_cast<const u32x4*>(ok ? src : zero);
-          }
-      }
       load_grp(1, 1);
-      store_grp(0, 0, nwin + WPC);
+      store_grp(0, 0, WPC);
       load_grp(2, 0);
-      UF_STAMP(0);
-      if (k >= 2) sp_poll(sWR + (k & 1), 8u * (unsigned)(k >> 1), d.fault);
-      UF_STAMP(4);
-      sp_wait_vm(2 * WPC);
-      UF_STAMP(5);
-      {
-        char* buf = sWin + (k & 1) * WBUF + lane * 16;
-#pragma unroll
-        for (int i = 0; i < NPW; ++i)
-          if (i < nwin) *reinterpret_cast<u32x4*>(buf + (pw + 4 * i) * 1024) = ww[i];
-        sp_wait_lds();
-        if (lane == 0) sp_bump(sWL + (k & 1));
-      }
-      UF_STAMP(6);
       store_grp(1, 1, WPC);
       load_grp(3, 1);
-      store_grp(2, 0, WPC);
+      if (more) {
+        int c2 = c + 1, n2 = n, ty2 = ty0, tx2 = tx0, n02 = n0;
+        if (c2 == nck) { c2 = 0; item_of(ord + 1, n2, ty2, tx2, n02); }
+        win_load(n2, ty2, tx2, c2);
+      }
+      store_grp(2, 0, WPC + nw2);
       load_grp(4, 0);
-      store_grp(3, 1, WPC);
+      store_grp(3, 1, nw2 + WPC);
+      if (more) win_store(k + 1, WPC);
       store_grp(4, 0, 0);
     }
   } else {
@@ -271,8 +287,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         }
       }
       UF_STAMP(2);
-      sp_wait_lds();  // all five taps are in registers: the ring slot may be refilled
-      if (lane == 0) sp_bump(sCR + slot);
+      sp_release(sCR + slot, lane);  // all five taps have been read: the ring slot may be refilled
       UF_STAMP(3);
       // pass py1: ty 1 (wf[0]) and ty 2 (wf[1]) over window rows 1..5
 #pragma unroll
@@ -323,8 +338,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         do_group(buf, 2, q0 + 4u);
       }
       UF_STAMP(5);
-      sp_wait_lds();  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
-      if (lane == 0) sp_bump(sWR + (k & 1));
+      sp_release(sWR + (k & 1), lane);  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
       UF_STAMP(6);
       if (c == nck - 1) {
         // ---------------- item epilogue ----------------
@@ -348,8 +362,11 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         float bias8[8];
         load8(d.bias + c8, bias8);
         // att-half partial sums of this lane's pixels, added into the accumulators BEFORE the first store of the item (one
-        // in-order counter for loads and stores: a load issued behind a store is complete only once that store is)
+        // in-order counter for loads and stores: a load issued behind a store is complete only once that store is).  All
+        // sixteen loads are in flight together (the fragment registers of the step loop are free by now): left to itself the
+        // compiler issues them pair by pair with a full wait after each, eight memory round trips per item.
         if (d.res) {
+          u32x4 rh[RPW][2], rl[RPW][2];
 #pragma unroll
           for (int r = 0; r < RPW; ++r)
 #pragma unroll
@@ -357,11 +374,20 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
               const int oy = 2 * min(myb + r, d.LH - 1) + py;
               const char* g = reinterpret_cast<const char*>(d.res) +
                               ((((size_t)n * OH + oy) * OW + ox_own) * d.res_cs + d.res_co + n0) * 4 + kg_e * 16;
+              rh[r][py] = *reinterpret_cast<const u32x4*>(g);
+              rl[r][py] = *reinterpret_cast<const u32x4*>(g + 64);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
               float rv[8];
-              drs_sp_join8(*reinterpret_cast<const u32x4*>(g), *reinterpret_cast<const u32x4*>(g + 64), rv);
+              drs_sp_join8(rh[r][py], rl[r][py], rv);
 #pragma unroll
               for (int j = 0; j < 4; ++j) { acc[r][py][0][j] += rv[j]; acc[r][py][1][j] += rv[4 + j]; }
             }
+          __builtin_amdgcn_sched_barrier(0);
         }
         float post2_8[8];
 #pragma unroll
@@ -383,7 +409,23 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         } else {
           if (d.out2) load8(d.post2 + (size_t)n * d.post2_cs + c8, post2_8);
         }
+        UF_STAMP(8);
         const int lane_b = (lo ? 0 : 64) + kg_e * 16;
+        // fused projection on top of the projected att-half already in fuse_out: its values, loaded before the first store
+        float prev[FUSE ? RPW : 1][2][4];
+        if constexpr (FUSE) {
+          const size_t plane = (size_t)OH * OW;
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                prev[r][py][j] = 0.f;
+                if (d.fuse_acc && own_ok && kg_e == 0 && j < d.fuse_dim && myb + r < d.LH)
+                  prev[r][py][j] = d.fuse_out[((size_t)n * d.fuse_dim + j) * plane + (size_t)(2 * (myb + r) + py) * OW + ox_own];
+              }
+        }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
           const int my = myb + r;
@@ -417,7 +459,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
                   float* o = d.fuse_out + (size_t)n * d.fuse_dim * plane + (size_t)oy * OW + ox_own;
 #pragma unroll
                   for (int j = 0; j < 4; ++j)
-                    if (j < d.fuse_dim) o[(size_t)j * plane] = y[j] + fb[j];
+                    if (j < d.fuse_dim) o[(size_t)j * plane] = y[j] + fb[j] + prev[r][py][j];
                 }
               } else {
                 // SP stores in full 128-byte lines: lanes lr < 8 write hi slots, lanes lr >= 8 lo slots, of cells pl and pl + 8
@@ -441,6 +483,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
             }
           }
         }
+        UF_STAMP(9);
       }
     }
     };
@@ -555,92 +598,150 @@ __device__ __forceinline__ float uf_sp_value(const char* base, int ci) {  // ele
   const char* g = base + (ci >> 5) * 128 + (ci & 31) * 2;
   return (float)*reinterpret_cast<const __bf16*>(g) + (float)*reinterpret_cast<const __bf16*>(g + 64);
 }
-// One block = (image n, kind: 0 = first row | 1 = first column, segment of 4 cells = 8 output positions along the edge).
-// 1024 threads = Ch output channels x KS slices of the input channels; the slices' partial sums meet in LDS and are added
-// in a fixed order (bit-reproducible: no atomics).  Row blocks also write the last row's bias terms and, in segment 0, the
-// corner (0, 0) with its column -1 paths; column blocks write the last column's bias terms and the corner (OH-1, 0).
-constexpr int UF_ESEG = 4;
-__global__ __launch_bounds__(1024) void upfuse_edges_kernel(UpFuseEdgeDesc d) {
-  extern __shared__ __attribute__((aligned(16))) float esm[];
-  const int OH = 2 * d.LH, OW = 2 * d.LW, Ch = d.Ch, Cc = d.Cc;
-  const int seg = blockIdx.x, kind = blockIdx.y, n = blockIdx.z;
-  const int L = kind ? d.LH : d.LW;  // cells along this edge
-  const int m0 = seg * UF_ESEG;
+// MFMA form.  One wave = (kind: 0 = first row | 1 = first column, image n, segment of 16 cells = 32 output positions along
+// the edge, group of 32 output channels): a 1-D composite convolution with the weights as A operand (edge operand image:
+// [kind][chunk][tap 7][k-group][Ch][8 x bf16], hi image then lo image; taps 0..4 = (p0: t 0,1,2), (p1: t 1,2); row blocks:
+// tap 5 = rl0, tap 6 = rl[(0,2)] for the corner's column -1 paths) and SP slots of h straight from global memory as B
+// operand (cells m-1, m, m+1 of the edge; lanes outside the image read zeros).  Operands of chunk c + 1 are in flight
+// while chunk c is multiplied.  256 waves per stage, one per CU.
+struct UfEdgeFrags { PolicyBF16X3::Frag w[7][2], b[3], cb[2]; };
+__global__ __launch_bounds__(64) void upfuse_edges_mfma_kernel(UpFuseEdgeDesc d, const char* __restrict__ wimg, size_t img_bytes,
+                                                               const char* __restrict__ zero16) {
+  using P = PolicyBF16X3;
+  const int OH = 2 * d.LH, OW = 2 * d.LW, Ch = d.Ch;
+  const int nck = d.Cc >> 5;
+  const int lane = threadIdx.x, lr = lane & 15, kg = lane >> 4;
+  const int cgs = Ch >> 5;
+  const int cg = blockIdx.x % cgs, seg = blockIdx.x / cgs, kind = blockIdx.y, n = blockIdx.z;
+  const int L = kind ? d.LH : d.LW;
+  const int m0 = seg * 16;
   if (m0 >= L) return;
-  const int tid = threadIdx.x;
-  const int KS = 1024 / Ch, co = tid % Ch, ks = tid / Ch;
-  float* hs = esm;                     // [7][Cc]: cells m0-1 .. m0+4 of the edge, then pixel (1, 0) (corner term)
-  float* part = esm + 7 * Cc;          // [KS][9][Ch]
-  const size_t mat = (size_t)Cc * Ch;
-  auto pixel = [&](int y, int x) {
-    return reinterpret_cast<const char*>(d.in) + ((((size_t)n * d.LH + y) * d.LW + x) * d.in_cs + d.in_co) * 4;
-  };
-  for (int i = tid; i < 7 * Cc; i += 1024) {
-    const int cell = i / Cc, ci = i - cell * Cc;
-    int y, x;
-    bool ok;
-    if (cell < 6) {
-      const int m = m0 - 1 + cell;
-      ok = m >= 0 && m < L;
-      y = kind ? m : 0; x = kind ? 0 : m;
-    } else {
-      ok = d.LH > 1; y = 1; x = 0;
-    }
-    hs[i] = ok ? uf_sp_value(pixel(ok ? y : 0, ok ? x : 0), ci) : 0.f;
-  }
-  __syncthreads();
   const bool corner = kind == 0 && seg == 0;
-  float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const float* W = (kind ? d.rl : d.rt) + co;
-  for (int ci = ks; ci < Cc; ci += KS) {
-    const float* w = W + (size_t)ci * Ch;
-    const float w0 = w[0], w1 = w[mat], w2 = w[2 * mat], w3 = w[3 * mat], w4 = w[4 * mat];
-    float h[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) h[c] = hs[c * Cc + ci];
-#pragma unroll
-    for (int a = 0; a < UF_ESEG; ++a) {
-      acc[2 * a] += w0 * h[a] + w1 * h[a + 1] + w2 * h[a + 2];   // even position: cells m-1, m, m+1
-      acc[2 * a + 1] += w3 * h[a + 1] + w4 * h[a + 2];           // odd position: cells m, m+1
-    }
-    if (corner)  // output (0, 0): paths through column -1 that do not pass row -1: rl0 x h[0][0] + rl[(0, 2)] x h[1][0]
-      acc[8] += d.rl[5 * mat + (size_t)ci * Ch + co] * h[1] + d.rl[2 * mat + (size_t)ci * Ch + co] * hs[6 * Cc + ci];
-  }
-#pragma unroll
-  for (int j = 0; j < 9; ++j) part[(ks * 9 + j) * Ch + co] = acc[j];
-  __syncthreads();
-  auto biasdelta = [&](int oy, int ox, int c) {
-    float v = 0.f;
-    for (int kvy = 0; kvy < 3; ++kvy)
-      for (int kvx = 0; kvx < 3; ++kvx)
-        if ((oy == 0 && kvy == 0) || (oy == OH - 1 && kvy == 2) || (ox == 0 && kvx == 0) || (ox == OW - 1 && kvx == 2))
-          v -= d.bt[(kvy * 3 + kvx) * Ch + c];
-    return v;
+  const int NTAP = corner ? 7 : 5;
+  auto pixel = [&](int y, int x) {
+    return reinterpret_cast<const char*>(d.in) + ((((size_t)n * d.LH + y) * d.LW + x) * d.in_cs + d.in_co) * 4 + kg * 16;
   };
-  for (int idx = tid; idx < 8 * Ch; idx += 1024) {
-    const int j = idx / Ch, c = idx - j * Ch;
-    const int pos = 2 * m0 + j;
-    if (pos >= 2 * L) continue;
-    float D = 0.f, Dc = 0.f;
-    for (int k = 0; k < KS; ++k) {
-      D += part[(k * 9 + j) * Ch + c];
-      if (corner && j == 0) Dc += part[(k * 9 + 8) * Ch + c];
+  const char* bsrc[3];
+  bool bok[3];
+#pragma unroll
+  for (int sft = 0; sft < 3; ++sft) {
+    const int m = m0 + lr + sft - 1;
+    bok[sft] = m >= 0 && m < L;
+    bsrc[sft] = bok[sft] ? pixel(kind ? m : 0, kind ? 0 : m) : zero16;
+  }
+  // corner operands: pixel (0, 0) and pixel (1, 0), lane lr == 0 only
+  const bool c0ok = corner && lr == 0, c1ok = corner && lr == 0 && d.LH > 1;
+  const char* csrc0 = c0ok ? pixel(0, 0) : zero16;
+  const char* csrc1 = c1ok ? pixel(1, 0) : zero16;
+  // weights: lane (lr, kg) -> row cg*32 + t*16 + lr of k-group kg
+  const char* wbase = wimg + ((size_t)kind * nck * 7 * 4 * Ch + (size_t)kg * Ch + cg * 32 + lr) * 16;
+  auto issue = [&](int c, UfEdgeFrags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tap = 0; tap < 7; ++tap)
+      if (tap < NTAP)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) f.w[tap][t] = P::load(wbase, img_bytes, (((size_t)c * 7 + tap) * 4 * Ch + t * 16) * 16);
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft) {
+      const char* p = bsrc[sft] + (bok[sft] ? c * 128 : 0);
+      f.b[sft] = typename P::Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + (bok[sft] ? 64 : 0))};
     }
-    if (kind == 0) {
-      const int ox = pos;
-      d.eh[(((size_t)n * 2 + 0) * OW + ox) * Ch + c] = biasdelta(0, ox, c) - D - Dc;
-      if (ox != 0 && OH > 1) d.eh[(((size_t)n * 2 + 1) * OW + ox) * Ch + c] = biasdelta(OH - 1, ox, c);
-    } else {
-      const int oy = pos;
-      if (oy == 0) continue;  // the row block owns output row 0
-      const float v = biasdelta(oy, 0, c) - D;
-      if (oy == OH - 1) {
-        d.eh[(((size_t)n * 2 + 1) * OW + 0) * Ch + c] = v;
-      } else {
-        d.ev[(((size_t)n * 2 + 0) * OH + oy) * Ch + c] = v;
-        d.ev[(((size_t)n * 2 + 1) * OH + oy) * Ch + c] = biasdelta(oy, OW - 1, c);
+    if (corner) {
+      const char* p0 = csrc0 + (c0ok ? c * 128 : 0);
+      const char* p1 = csrc1 + (c1ok ? c * 128 : 0);
+      f.cb[0] = typename P::Frag{*reinterpret_cast<const bf16x8*>(p0), *reinterpret_cast<const bf16x8*>(p0 + (c0ok ? 64 : 0))};
+      f.cb[1] = typename P::Frag{*reinterpret_cast<const bf16x8*>(p1), *reinterpret_cast<const bf16x8*>(p1 + (c1ok ? 64 : 0))};
+    }
+  };
+  f32x4 acc[2][2], accc[2];  // [phase][tile]; corner term (even phase, position 0)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[0][t] = acc[1][t] = accc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mult = [&](const UfEdgeFrags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      acc[0][t] = P::mma(f.w[0][t], f.b[0], acc[0][t]);  // even position 2m: cells m-1, m, m+1
+      acc[0][t] = P::mma(f.w[1][t], f.b[1], acc[0][t]);
+      acc[0][t] = P::mma(f.w[2][t], f.b[2], acc[0][t]);
+      acc[1][t] = P::mma(f.w[3][t], f.b[1], acc[1][t]);  // odd position 2m+1: cells m, m+1
+      acc[1][t] = P::mma(f.w[4][t], f.b[2], acc[1][t]);
+      if (corner) {
+        accc[t] = P::mma(f.w[5][t], f.cb[0], accc[t]);
+        accc[t] = P::mma(f.w[6][t], f.cb[1], accc[t]);
       }
     }
+  };
+  UfEdgeFrags fa, fb;
+  issue(0, fa);
+  for (int c = 0; c < nck; c += 2) {
+    if (c + 1 < nck) issue(c + 1, fb);
+    mult(fa);
+    if (c + 2 < nck) issue(c + 2, fa);
+    if (c + 1 < nck) mult(fb);
+  }
+  auto biasdelta4 = [&](int oy, int ox, int c0, float (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = 0.f;
+    for (int kvy = 0; kvy < 3; ++kvy)
+      for (int kvx = 0; kvx < 3; ++kvx)
+        if ((oy == 0 && kvy == 0) || (oy == OH - 1 && kvy == 2) || (ox == 0 && kvx == 0) || (ox == OW - 1 && kvx == 2)) {
+          const float4 b = *reinterpret_cast<const float4*>(d.bt + (kvy * 3 + kvx) * Ch + c0);
+          v[0] -= b.x; v[1] -= b.y; v[2] -= b.z; v[3] -= b.w;
+        }
+  };
+  const int m = m0 + lr;
+  if (m >= L) return;
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int pos = 2 * m + ph;
+      const int c0 = cg * 32 + t * 16 + kg * 4;
+      float bd[4], o[4];
+      if (kind == 0) {
+        const int ox = pos;
+        biasdelta4(0, ox, c0, bd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = bd[j] - acc[ph][t][j] - ((ph == 0 && corner) ? accc[t][j] : 0.f);  // (accc is zero but in lane 0)
+        *reinterpret_cast<float4*>(d.eh + (((size_t)n * 2 + 0) * OW + ox) * Ch + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (ox != 0) {
+          biasdelta4(OH - 1, ox, c0, bd);
+          *reinterpret_cast<float4*>(d.eh + (((size_t)n * 2 + 1) * OW + ox) * Ch + c0) = make_float4(bd[0], bd[1], bd[2], bd[3]);
+        }
+      } else {
+        const int oy = pos;
+        if (oy == 0) continue;  // the row wave owns output row 0
+        biasdelta4(oy, 0, c0, bd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = bd[j] - acc[ph][t][j];
+        if (oy == OH - 1) {
+          *reinterpret_cast<float4*>(d.eh + (((size_t)n * 2 + 1) * OW + 0) * Ch + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          *reinterpret_cast<float4*>(d.ev + (((size_t)n * 2 + 0) * OH + oy) * Ch + c0) = make_float4(o[0], o[1], o[2], o[3]);
+          biasdelta4(oy, OW - 1, c0, bd);
+          *reinterpret_cast<float4*>(d.ev + (((size_t)n * 2 + 1) * OH + oy) * Ch + c0) = make_float4(bd[0], bd[1], bd[2], bd[3]);
+        }
+      }
+    }
+}
+
+// fp32 edge weights (aux: rt | rl) -> the MFMA operand image of upfuse_edges_mfma_kernel
+__global__ void upfuse_edge_pack_kernel(const float* __restrict__ aux, int Cc, int Ch, char* __restrict__ dst, size_t img_bytes) {
+  const int nck = Cc >> 5;
+  const size_t mat = (size_t)Cc * Ch;
+  const size_t nslots = (size_t)2 * nck * 7 * 4 * Ch;
+  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(s % Ch);
+    const int q = (int)((s / Ch) & 3);
+    const int tap = (int)((s / ((size_t)Ch * 4)) % 7);
+    const int ck = (int)((s / ((size_t)Ch * 28)) % nck);
+    const int kind = (int)(s / ((size_t)Ch * 28 * nck));
+    const float* src = nullptr;  // [ci][co] matrix
+    if (tap < 5) src = aux + (size_t)(kind ? 5 + tap : tap) * mat;
+    else if (kind == 0) src = aux + (size_t)(5 + (tap == 5 ? 5 : 2)) * mat;  // rl0, rl[(0, 2)]
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = src ? src[(size_t)(ck * 32 + q * 8 + e) * Ch + co] : 0.f;
+    PolicyBF16X3::cvt_store(dst, img_bytes, s * 16, x);
   }
 }
 
@@ -669,7 +770,7 @@ size_t drs_upfuse_weight_bytes(int Cc, int Ch) { return (size_t)(Ch / 32) * (Cc 
 size_t drs_upfuse_aux_floats(int Cc, int Ch) { return (size_t)11 * Cc * Ch + (size_t)10 * Ch; }
 
 int drs_launch_upfuse_pack(const float* v_w, const float* v_b, const float* t_w, const float* t_b, int Cc, int Ch, void* dst_w,
-                           float* dst_aux, hipStream_t s) {
+                           float* dst_aux, void* dst_edge, hipStream_t s) {
   DRS_REQUIRE(Cc % 32 == 0 && Ch % 32 == 0, DRS_ERR_SHAPE, "upfuse_pack: Cc=%d Ch=%d", Cc, Ch);
   const size_t nslots = drs_upfuse_weight_bytes(Cc, Ch) / 32;
   int blocks = (int)((nslots + 127) / 128);
@@ -682,17 +783,24 @@ int drs_launch_upfuse_pack(const float* v_w, const float* v_b, const float* t_w,
   float* bt = dst_aux + (size_t)11 * Cc * Ch;
   hipLaunchKernelGGL(upfuse_bias_kernel, dim3((Ch + 127) / 128), dim3(128), 0, s, v_b, Ch, bt, bt + 9 * Ch);
   DRS_CHECK_HIP(hipGetLastError());
+  {
+    const size_t img = drs_upfuse_edge_image_bytes(Cc, Ch) / 2;
+    hipLaunchKernelGGL(upfuse_edge_pack_kernel, dim3((unsigned)((img / 16 + 255) / 256)), dim3(256), 0, s, dst_aux, Cc, Ch,
+                       (char*)dst_edge, img);
+    DRS_CHECK_HIP(hipGetLastError());
+  }
   return DRS_OK;
 }
 
+size_t drs_upfuse_edge_image_bytes(int Cc, int Ch) { return (size_t)2 * 2 * (Cc / 32) * 7 * 4 * Ch * 16; }
+
 int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s) {
   if ((size_t)d.N * d.LH * d.LW == 0) return DRS_OK;
-  DRS_REQUIRE(d.Ch >= 32 && d.Ch <= 1024 && 1024 % d.Ch == 0 && d.Cc % 32 == 0, DRS_ERR_SHAPE, "upfuse_edges: Cc=%d Ch=%d", d.Cc,
-              d.Ch);
-  const size_t lds = ((size_t)7 * d.Cc + (size_t)9 * 1024) * 4;
-  DRS_REQUIRE(lds <= 64 * 1024, DRS_ERR_SHAPE, "upfuse_edges: Cc=%d too wide", d.Cc);
-  const int segs = drs_cdiv(d.LH > d.LW ? d.LH : d.LW, UF_ESEG);
-  hipLaunchKernelGGL(upfuse_edges_kernel, dim3(segs, 2, d.N), dim3(1024), lds, s, d);
+  DRS_REQUIRE(d.Ch % 32 == 0 && d.Cc % 32 == 0 && d.wimg && d.zero_line, DRS_ERR_SHAPE, "upfuse_edges: Cc=%d Ch=%d", d.Cc, d.Ch);
+  const int segs = drs_cdiv(d.LH > d.LW ? d.LH : d.LW, 16);
+  hipLaunchKernelGGL(upfuse_edges_mfma_kernel, dim3(segs * (d.Ch / 32), 2, d.N), dim3(64), 0, s, d,
+                     reinterpret_cast<const char*>(d.wimg), drs_upfuse_edge_image_bytes(d.Cc, d.Ch) / 2,
+                     reinterpret_cast<const char*>(d.zero_line));
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -706,6 +814,7 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
               DRS_ERR_SHAPE, "upfuse: out2");
   DRS_REQUIRE(!d.fuse_out || (d.Ch == 32 && d.fuse_dim >= 1 && d.fuse_dim <= 4 && d.fuse_w && d.fuse_b && !d.out && !d.out2),
               DRS_ERR_SHAPE, "upfuse: fused projection needs Ch == 32, fuse_dim <= 4 and no wide output");
+  DRS_REQUIRE(!d.fuse_acc || (d.fuse_out && !d.res), DRS_ERR_ARG, "upfuse: fuse_acc takes the att-half from fuse_out, not from res");
   DRS_REQUIRE((d.eh == nullptr) == (d.ev == nullptr), DRS_ERR_ARG, "upfuse: edge vectors");
   if ((size_t)d.N * d.LH * d.LW == 0) return DRS_OK;
   const int tiles_y = drs_cdiv(d.LH, 16), tiles_x = drs_cdiv(d.LW, 16), nck = d.Cc / 32;
@@ -747,8 +856,8 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
             d.LH, d.fuse_out ? 1 : 0, ms * 1e3, h[10], h[11], h[11] / (ms * 1e6), h[11] * sc);
     for (int w = 0; w < 2; ++w) {
       const unsigned long long* t = h + 16 * w;
-      fprintf(stderr, "   C%d (px%d): epi+top %.0f WLwait %.0f | grp: pre %.0f CLwait %.0f pass0 %.0f rel %.0f | pass1+tail %.0f WRrel %.0f\n", 4 * w, w,
-              t[7] * sc, t[4] * sc, t[0] * sc, t[1] * sc, t[2] * sc, t[3] * sc, t[5] * sc, t[6] * sc);
+      fprintf(stderr, "   C%d (px%d): top %.0f WLwait %.0f | grp: pre %.0f CLwait %.0f pass0 %.0f rel %.0f | pass1+tail %.0f WRrel %.0f | epi: loads %.0f rest %.0f\n", 4 * w, w,
+              t[7] * sc, t[4] * sc, t[0] * sc, t[1] * sc, t[2] * sc, t[3] * sc, t[5] * sc, t[6] * sc, t[8] * sc, t[9] * sc);
     }
     const unsigned long long* t = h + 32;
     fprintf(stderr, "   M0: loads/other %.0f CRwait %.0f vmwait %.0f store %.0f | WRwait %.0f vmwait %.0f winstore %.0f\n", t[0] * sc, t[1] * sc,
