@@ -107,8 +107,9 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
     typename P::Frag gfr[NC];
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
-      const float4 b0 = *reinterpret_cast<const float4*>(sB + cc * 32 + kg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(sB + cc * 32 + kg * 8 + 4);
+      const float* bsrc = d.b_gate_img ? d.b_gate_img + (size_t)n * Ch + cc * 32 + kg * 8 : sB + cc * 32 + kg * 8;
+      const float4 b0 = *reinterpret_cast<const float4*>(bsrc);
+      const float4 b1 = *reinterpret_cast<const float4*>(bsrc + 4);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       float v[8];
 #pragma unroll
@@ -273,11 +274,12 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
       }
     }
     {
-      const float4 b0 = *reinterpret_cast<const float4*>(sB + cg * 32 + kg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(sB + cg * 32 + kg * 8 + 4);
-      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
+        const float* bsrc = d.b_gate_img ? d.b_gate_img + (size_t)nn[b] * Ch + cg * 32 + kg * 8 : sB + cg * 32 + kg * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(bsrc);
+        const float4 b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -433,6 +435,18 @@ int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
   return DRS_OK;
 }
 
+// per-image gating bias for a stage input stored as x + vec[n] (drs_common.h: AttnGateDesc::b_gate_img)
+__global__ void gate_bias_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ vec,
+                                 int vec_stride, float* __restrict__ out, int N, int Cc, int Ch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * Ch) return;
+  const int n = i / Ch, co = i - n * Ch;
+  const float* v = vec + (size_t)n * vec_stride;
+  float a = 0.f;
+  for (int ci = 0; ci < Cc; ++ci) a += w[(size_t)ci * Ch + co] * v[ci];
+  out[i] = b[co] - a;
+}
+
 }  // namespace
 
 size_t drs_attn_gate_lds_bytes(int Cc, int Ch) {
@@ -465,4 +479,12 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
   }
   const size_t lds = drs_attn_gate_lds_bytes(d.Cc, d.Ch);
   return d.Ch == 32 ? attn_launch<2>(d, lds, s) : attn_launch<4>(d, lds, s);
+}
+
+int drs_launch_gate_bias(const float* w, const float* b, const float* vec, int vec_stride, float* out, int N, int Cc, int Ch,
+                         hipStream_t s) {
+  if (N * Ch == 0) return DRS_OK;
+  hipLaunchKernelGGL(gate_bias_kernel, dim3((N * Ch + 127) / 128), dim3(128), 0, s, w, b, vec, vec_stride, out, N, Cc, Ch);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
 }

@@ -521,7 +521,7 @@ static int launch_p(const TapConv& d, const MfmaGeom& g, int bn, int rpw, int mo
 }
 
 int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
-  DRS_REQUIRE(d.in && d.w && (d.out || d.fuse_out), DRS_ERR_ARG, "tapconv_mfma: null tensor");
+  DRS_REQUIRE(d.in && d.w && (d.out || d.fuse_out || d.out2), DRS_ERR_ARG, "tapconv_mfma: null tensor");
   DRS_REQUIRE(drs_tapconv_mfma_supported(d, impl), DRS_ERR_SHAPE, "tapconv_mfma: unsupported shape");
   if ((size_t)d.N * d.TH * d.TW == 0) return DRS_OK;
   MfmaGeom g; int bn, rpw, mode; size_t lds;

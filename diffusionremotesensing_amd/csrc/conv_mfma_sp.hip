@@ -335,7 +335,7 @@ bool drs_tapconv_sp_supported(const TapConv& d, int impl) {
                 !(d.Cin2 % 32 == 0 || (d.Cin2 == 16 && d.in2_cs == 16)) || d.H2 != d.TH || d.W2 != d.TW))
     return false;
   if (d.fuse_out) return d.Cout == 32 && !d.in2 && !d.out2 && !d.out_sp && d.fuse_dim <= 4 && !d.post_add && !d.relu_pre && !d.relu_post;
-  if (!d.out || !d.out_sp || (d.out_co & 31) || (d.out_cs & 31)) return false;
+  if ((!d.out && !d.out2) || !d.out_sp || (d.out_co & 31) || (d.out_cs & 31)) return false;  // (out2 alone: a producer whose consumers only read x + temb)
   if (d.out2 && (!d.post2 || (d.out2_co & 31) || (d.out2_cs & 31) || (d.post2_cs & 3))) return false;
   if (d.post_add && (d.post_cs & 3)) return false;
   return true;

@@ -153,12 +153,19 @@ struct AttnGateDesc {
   // packed operand images (conv_mfma.hip: [chunk][tap][k-group][Ch][8 x bf16], hi image then lo image, output rows in SP
   // permutation), biases in logical channel order
   const void* w_gate; const float* b_gate;
+  // optional per-image gating bias (N x Ch): the stage input given in `x` is x + relu(time_mlp(t)) (the only copy its
+  // producer stores), and the row vector the gating convolution does not want is taken out through its bias:
+  // b_gate_img[n][co] = b_gate[co] - sum_ci Wg[co][ci] * temb[n][ci]   (drs_launch_gate_bias)
+  const float* b_gate_img;
   const void* w_wg;   const float* b_wg;
   const void* w_wx;   const float* b_wx;   // 4 taps (ky*2 + kx)
   const float* w_psi; const float* b_psi;  // Ch floats + 1
   const void* w_res;  const float* b_res;
 };
 bool drs_attn_gate_supported(int Cc, int Ch);
+// out[n][co] = b[co] - sum_ci w[ci][co] * vec[n * vec_stride + ci]   (w: fp32 [Cc][Ch], BatchNorm folded)
+int drs_launch_gate_bias(const float* w, const float* b, const float* vec, int vec_stride, float* out, int N, int Cc, int Ch,
+                         hipStream_t s);
 int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s);
 
 // ---- ups.i.transform composed with the x-half of up_convs.i (upfuse_sp.hip) -------------------------------------------------

@@ -359,6 +359,9 @@ struct DecStage {
   // fused attention gate (attn_gate_sp.hip): w_g and w_x once more with the SP output-row permutation
   bool fused_gate = false;
   size_t fz_wg_off = 0, fz_wx_off = 0;
+  // the stage input is stored ONLY as x + relu(time_mlp(t)) (what ups.i.conv reads) when the fused gate can take the row
+  // vector out through a per-image bias: fp32 BatchNorm-folded gating weights [Cc][Ch] + bias, per-forward bias table
+  size_t gf_w_off = 0, gf_b_off = 0, o_gbias = 0;
   // ups.i.transform composed with the x-half of up_convs.i (upfuse_sp.hip): composite operand image, edge / bias weights,
   // and the att-half of up_convs.i packed as its own Ch -> Ch 3x3 convolution (no bias: it is in the composite's)
   bool upfuse = false;
@@ -616,6 +619,8 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     if (d.fused_gate) {
       d.fz_wg_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(d.wg.Cout, d.wg.Cin, 1, DRS_IMPL_MFMA_BF16X3));
       d.fz_wx_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(d.wx.Cout, d.wx.Cin, 4, DRS_IMPL_MFMA_BF16X3));
+      d.gf_w_off = cur; cur += align_up((size_t)d.gate.Cout * d.gate.Cin * 4);
+      d.gf_b_off = cur; cur += align_up((size_t)d.gate.Cout * 4);
     }
   }
   for (int i = 0; i < 3; ++i) {
@@ -692,6 +697,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     auto mark = [&](int t) { p->tensors[t].sp = true; };
     for (int i = 0; i < 3; ++i) {
       DecStage& d = p->dec[i];
+      if (d.fused_gate) { d.o_gbias = ws; ws += align_up((size_t)B * kUp[i + 1] * 4); }
       if (!d.upfuse) continue;
       const int lh = H >> (3 - i), lw = W >> (3 - i), Ch = kUp[i + 1];
       if (i < 2) {  // (stage 2 hands its att-half over projected, through the output tensor)
@@ -839,6 +845,11 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
       return rc;
     if ((rc = drs_launch_pack_conv_mfma(F(d.wx.w), F(d.wx.b), nullptr, nullptr, nullptr, nullptr, 0.f, base + d.fz_wx_off,
                                         (float*)(base + d.wx.b_off), d.wx.Cout, d.wx.Cin, 4, 0, impl, s, 0, 0, 0, 0, 1)))
+      return rc;
+    // fp32 [Cc][Ch] gating weights, BatchNorm folded (per-image bias of a stage input stored as x + temb)
+    if ((rc = drs_launch_pack_conv(F(d.gate.w), F(d.gate.b), F(d.gate.bn), F(d.gate.bn + 1), F(d.gate.bn + 2), F(d.gate.bn + 3),
+                                   plan->cfg.bn_eps, (float*)(base + d.gf_w_off), (float*)(base + d.gf_b_off), d.gate.Cout,
+                                   d.gate.Cin, 1, 0, 0, s)))
       return rc;
   }
   for (int i = 0; i < 3; ++i) {
@@ -1011,6 +1022,21 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                                 temb, plan->temb_total, B, 100, labels ? (const float*)(pk + plan->o_label) : nullptr,
                                 (const long long*)labels, label_batch, plan->cfg.num_classes, st_mlp));
   prof_end(plan, s);
+  // Stage inputs that are stored only as x + relu(time_mlp(t)) (below): the fused gate takes the row vector out again
+  // through a per-image bias, b'[n] = b - Wg temb[n] (16 x Ch dot products per stage, next to the time MLPs).
+  bool xt_only[3] = {false, false, false};
+  if (plan->sp && !train && !(c.flags & DRS_PLAN_KEEP_ALL)) {
+    static const int xt_env = getenv("DRS_XT_ONLY") ? atoi(getenv("DRS_XT_ONLY")) : 1;
+    for (int i = 0; i < 3 && xt_env; ++i) {
+      const DecStage& st = plan->dec[i];
+      // producer: the bottleneck's conv2 on the wave-specialised SP kernel (16-row patches), or the composite kernel of stage i - 1
+      const bool producer = i == 0 ? (H >> 3) > 8 && (W >> 3) > 8 : plan->dec[i - 1].upfuse;
+      xt_only[i] = st.fused_gate && producer;
+      if (xt_only[i])
+        RUN(drs_launch_gate_bias((const float*)(pk + st.gf_w_off), (const float*)(pk + st.gf_b_off), temb + st.mlp.temb_off,
+                                 plan->temb_total, (float*)((char*)ws + st.o_gbias), B, kUp[i], kUp[i + 1], st_mlp));
+    }
+  }
   if (mlp_side) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, st_mlp));
 
   // --- LR conditioning branch: RRDB -> bicubic -> conv (reference :345-353), constant per sampling chain ---
@@ -1116,6 +1142,12 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       if (sp && i == 3) {  // second output: x + relu(time_mlp(t)) of the first UpConvBlock (its conv then needs no input add)
         d.out2 = TP(plan->t_XT[0]); d.out2_cs = co; d.out2_co = 0;
         d.post2 = temb + plan->dec[0].mlp.temb_off; d.post2_cs = plan->temb_total;
+        if (xt_only[0]) {  // both readers of the bottleneck output take x + temb: the plain copy is not written
+          TapConv probe = d;
+          probe.out = nullptr;
+          if (drs_tapconv_sp_supported(probe, c.impl)) d.out = nullptr;
+          else xt_only[0] = false;
+        }
       }
       RUN(conv_bn(rb.conv2, d));
     }
@@ -1161,7 +1193,8 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     if (fuse_gate) {
       // gating signal + attention gate in ONE launch (attn_gate_sp.hip): g, g1, p and psi never reach HBM
       AttnGateDesc a = {};
-      a.x = xcur; a.x_cs = Cc; a.x_co = 0;
+      a.x = xt_only[i] ? TP(plan->t_XT[i]) : xcur; a.x_cs = Cc; a.x_co = 0;
+      a.b_gate_img = xt_only[i] ? (const float*)((char*)ws + st.o_gbias) : nullptr;
       a.xres = xres; a.r_cs = Ch; a.r_co = 0;
       a.out = cat; a.out_cs = Cc + Ch; a.out_co = Cc;
       a.psi_out = nullptr;
@@ -1292,8 +1325,8 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
           u.fuse_dim = c.out_dim;
           fused_output = true;
         } else {
-          u.out = TP(plan->t_X[i]); u.out_cs = Ch; u.out_co = 0;
-          u.out2 = TP(plan->t_XT[i + 1]); u.out2_cs = Ch; u.out2_co = 0;  // second output for the next stage's UpConvBlock
+          if (!xt_only[i + 1]) { u.out = TP(plan->t_X[i]); u.out_cs = Ch; u.out_co = 0; }
+          u.out2 = TP(plan->t_XT[i + 1]); u.out2_cs = Ch; u.out2_co = 0;  // x + temb of the next stage's UpConvBlock
           u.post2 = temb + plan->dec[i + 1].mlp.temb_off; u.post2_cs = plan->temb_total;
         }
         const double opix = (double)B * 4.0 * lh * lw;

@@ -806,11 +806,11 @@ int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s) {
 }
 
 int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
-  DRS_REQUIRE(d.in && d.w && d.bias && d.zero_line && (d.out || d.fuse_out), DRS_ERR_ARG, "upfuse: null tensor");
+  DRS_REQUIRE(d.in && d.w && d.bias && d.zero_line && (d.out || d.out2 || d.fuse_out), DRS_ERR_ARG, "upfuse: null tensor");
   DRS_REQUIRE(d.Cc % 32 == 0 && d.Ch % 32 == 0 && (d.in_cs & 31) == 0 && (d.in_co & 31) == 0, DRS_ERR_SHAPE, "upfuse: channels");
   DRS_REQUIRE(!d.res || ((d.res_cs & 31) == 0 && (d.res_co & 31) == 0), DRS_ERR_SHAPE, "upfuse: res slice");
   DRS_REQUIRE(!d.out || ((d.out_cs & 31) == 0 && (d.out_co & 31) == 0), DRS_ERR_SHAPE, "upfuse: out slice");
-  DRS_REQUIRE(!d.out2 || (d.out && d.post2 && (d.out2_cs & 31) == 0 && (d.out2_co & 31) == 0 && (d.post2_cs & 3) == 0),
+  DRS_REQUIRE(!d.out2 || (d.post2 && (d.out2_cs & 31) == 0 && (d.out2_co & 31) == 0 && (d.post2_cs & 3) == 0),
               DRS_ERR_SHAPE, "upfuse: out2");
   DRS_REQUIRE(!d.fuse_out || (d.Ch == 32 && d.fuse_dim >= 1 && d.fuse_dim <= 4 && d.fuse_w && d.fuse_b && !d.out && !d.out2),
               DRS_ERR_SHAPE, "upfuse: fused projection needs Ch == 32, fuse_dim <= 4 and no wide output");

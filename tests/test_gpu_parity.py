@@ -632,16 +632,18 @@ def test_full_length_chain_is_deterministic(dev, model):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DRS_SP": "0"}, {"DRS_SP": "0", "DRS_WS": "0"}, {"DRS_SPK": "0"}, {"DRS_FUSE_GATE": "0"},
-                                 {"DRS_CONCURRENT": "1"}, {"DRS_D3K": "0", "DRS_S2K": "0"}, {"DRS_UPFUSE": "0"}],
+                                 {"DRS_CONCURRENT": "1"}, {"DRS_D3K": "0", "DRS_S2K": "0"}, {"DRS_UPFUSE": "0"},
+                                 {"DRS_XT_ONLY": "0"}],
                          ids=["fp32-activations+ws", "fp32-activations+lockstep", "sp+lockstep", "sp-unfused-gate", "sp-two-streams",
-                              "sp-without-direct-kernels", "sp-unfused-up"])
+                              "sp-without-direct-kernels", "sp-unfused-up", "sp-plain-stage-inputs"])
 def test_conv_kernel_variants_in_subprocess(env):
     """The kernel families of the eval split-bf16 plan are chosen once per process.  Default = SP-format activations with
     the wave-specialised SP kernel and the fused attention gate, serial stages; the switches select the older paths that
     the training / fp32 plans and small shapes still use: DRS_SP=0 fp32 channels-last activations (wave-specialised
     fp32-input kernel, DRS_WS=0: lock-step kernel only), DRS_SPK=0 SP format on the lock-step kernel, DRS_FUSE_GATE=0 the
     five-launch attention gate, DRS_CONCURRENT=1 two-stream decoder stages, DRS_UPFUSE=0 the ConvTranspose + up_conv pair
-    instead of the composite up-sampling kernel, DRS_D3K=0 / DRS_S2K=0 the plan without the direct-operand kernels (3x3 on the
+    instead of the composite up-sampling kernel, DRS_XT_ONLY=0 decoder stage inputs stored twice (x and x + temb) instead of
+    x + temb with a per-image gating bias, DRS_D3K=0 / DRS_S2K=0 the plan without the direct-operand kernels (3x3 on the
     32-channel layers, stride-2 and transposed convolutions).  All must reproduce the same goldens.  Own process, because
     the switches are read once."""
     import os
