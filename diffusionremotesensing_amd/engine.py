@@ -66,6 +66,11 @@ class HipUNetEngine:
         # training steps run the exact-fp32 MFMA kernels by default: gradients pass through ~25 BatchNorm backward
         # cancellations and the split-bf16 rounding (1e-5 per op) grows to ~4e-3 on the deepest (LR encoder) gradients
         self.train_impl = _lib.IMPL_BY_NAME[os.environ.get("DRS_TRAIN_IMPL", "mfma_f32")]
+        if self.train_impl == _lib.IMPL_MFMA_BF16X3:
+            import warnings
+            warnings.warn("DRS_TRAIN_IMPL=mfma_bf16x3: split-bf16 training is outside the gradient bar (worst gradient-norm "
+                          "deviation 1.26e-3 on the full-size configs[2] step against 1e-3); the exact-fp32 MFMA kernels are "
+                          "the parity-grade training path")
         # least-recently-used cache of plans: every distinct (batch, lr batch, H, W, mag, impl, train) owns a workspace
         # (~1.6 GB at batch 16, 256x256); train + validation + preview + tiler shapes would otherwise pile up
         self._plans = collections.OrderedDict()

@@ -11,7 +11,8 @@ from conftest import golden_inputs, rel_errors, replay_noise_source
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-3
+TOL = 1e-3  # BASELINE.json north_star: the bar the path is allowed; the tests hold the kernels to what they deliver:
+TOL_BF16X3 = 1e-4  # eval forwards, block taps, operators of the default split-bf16 kernels (measured 1e-5 .. 2e-5)
 TOL_F32 = 2e-5
 # mfma_f16 (single fp16 MFMA per product) measured 1.1e-3 max-rel / 8e-4 rel-L2 on these weights: outside the 1e-3
 # bar, so it is NOT the shipped default and not in the default test list; DRS_TEST_IMPLS=...,mfma_f16 runs it against
@@ -23,7 +24,13 @@ IMPLS = [i for i in os.environ.get("DRS_TEST_IMPLS", "direct,mfma_f32,mfma_bf16x
 def _tol(impl):
     if impl == "mfma_f16":
         return TOL_F16_OPT_IN
-    return TOL_F32 if impl in ("direct", "mfma_f32") else TOL
+    return TOL_F32 if impl in ("direct", "mfma_f32") else TOL_BF16X3
+
+
+def _tol_train(impl):
+    """Train-mode forwards (batch statistics): split-bf16 is not the training default and is only
+    held to the north_star bar there."""
+    return TOL if impl == "mfma_bf16x3" else _tol(impl)
 
 
 @pytest.fixture(scope="module")
@@ -305,7 +312,7 @@ def test_weight_updates_are_picked_up(dev, seeded_sd):
         ema.step_ema(ema_model, m, step_start_ema=5)
         y1 = ema_model(x.to(dev), t.to(dev), lr.to(dev), 2)
         sd = {k: v.cpu() for k, v in ema_model.state_dict().items()}
-        _assert_close(y1, U.unet_forward(sd, x, t, lr, 2), TOL_F32 if IMPLS[-1] in ("direct", "mfma_f32") else TOL, "ema")
+        _assert_close(y1, U.unet_forward(sd, x, t, lr, 2), _tol(IMPLS[-1]), "ema")
         y2 = m(x.to(dev), t.to(dev), lr.to(dev), 2)
     assert not torch.equal(y0, y2)
 
@@ -408,7 +415,7 @@ def test_train_mode_forward_golden(dev, seeded_sd, golden, impl):
     x, t, lr = golden_inputs("g5", 4, 4, 3, 32, 2, 1500)
     with torch.no_grad():
         out = m(x.to(dev), t.to(dev), lr.to(dev), 2)
-    _assert_close(out, torch.from_numpy(golden["g5_out"]), _tol(impl) if impl != "direct" else 5e-5, "g5 train output")
+    _assert_close(out, torch.from_numpy(golden["g5_out"]), _tol_train(impl) if impl != "direct" else 5e-5, "g5 train output")
     noise = synthetic.tensor_normal("g5.noise", (4, 3, 32, 32))
     loss = torch.nn.functional.mse_loss(out.cpu(), noise).item()
     assert abs(loss - float(golden["g5_loss"])) <= 2e-3 * float(golden["g5_loss"])

@@ -10,14 +10,19 @@ from conftest import rel_errors, replay_noise_source
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-3
+TOL = 1e-3  # north_star bar; eval forwards of the default split-bf16 kernels are held to what they deliver:
+TOL_BF16X3 = 1e-4
 TOL_F32 = 2e-5
 IMPLS = [i for i in os.environ.get("DRS_TEST_IMPLS", "direct,mfma_f32,mfma_bf16x3").split(",") if i]
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _tol(impl):
-    return TOL_F32 if impl in ("direct", "mfma_f32") else TOL
+    return TOL_F32 if impl in ("direct", "mfma_f32") else TOL_BF16X3
+
+
+def _tol_train(impl):
+    return TOL if impl == "mfma_bf16x3" else _tol(impl)
 
 
 def _assert_close(got, want, tol, what=""):
@@ -107,7 +112,7 @@ def test_sar_train_step_golden(dev, seeded_sd_sar, vgolden, impl):
     pred = m(x, t, sar)
     loss = torch.nn.MSELoss()(pred, noise)
     loss.backward()
-    _assert_close(pred.detach(), torch.from_numpy(vgolden["g8t_out"]), _tol(impl), "g8t output")
+    _assert_close(pred.detach(), torch.from_numpy(vgolden["g8t_out"]), _tol_train(impl), "g8t output")
     assert abs(loss.item() - float(vgolden["g8t_loss"])) <= 2e-3 * float(vgolden["g8t_loss"])
     # split-bf16 is not the training default (engine.train_impl = mfma_f32): its rounding grows through the BatchNorm
     # backward chain and reaches 2% on the 2-channel SAR-encoder gradients, the deepest in the graph
@@ -178,7 +183,7 @@ def test_generation_train_step_golden(dev, seeded_sd_gen, vgolden, impl):
     pred = m(x, t, y)
     loss = torch.nn.MSELoss()(pred, noise)
     loss.backward()
-    _assert_close(pred.detach(), torch.from_numpy(vgolden["g9t_out"]), _tol(impl), "g9t output")
+    _assert_close(pred.detach(), torch.from_numpy(vgolden["g9t_out"]), _tol_train(impl), "g9t output")
     rtol = 2e-4 if impl == "mfma_f32" else 1e-2
     names = open(os.path.join(HERE, "golden", "g9_param_names.txt")).read().split()
     params = dict(m.named_parameters())

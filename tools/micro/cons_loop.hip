@@ -60,6 +60,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 512 : 256, 1) void cons(float* out, 
   };
   Frag wf[3][2];
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz reference clock
   if constexpr (VARIANT == 0) {
     for (int k = 0; k < steps; ++k) {
       const char* buf = sWin + (k & 1) * WBUF;
@@ -155,9 +156,10 @@ __global__ __launch_bounds__(VARIANT == 0 ? 512 : 256, 1) void cons(float* out, 
 #pragma unroll
     for (int t = 0; t < 2; ++t) s += acc[r][t];
   out[(size_t)blockIdx.x * blockDim.x + tid] = s[0] + s[1] + s[2] + s[3];
-  if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+  if (tid == 0) { ticks[blockIdx.x] = t1 - t0; ticks[256 + blockIdx.x] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
+static int g_reps = 3;
 template <int V, int PF>
 void run(const char* name, int blocks, int steps, float* out, unsigned long long* ticks, int data) {
   auto kern = cons<V, PF>;
@@ -166,26 +168,28 @@ void run(const char* name, int blocks, int steps, float* out, unsigned long long
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
-  for (int rep = 0; rep < 3; ++rep) {
+  // MI355X_MICROARCH.md, DVFS give-back item 6: the clock under load is read after seconds of back-to-back launches
+  for (int rep = 0; rep < g_reps; ++rep) {
     hipEventRecord(e0, 0);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(V == 0 ? 512 : 256), lds, 0, out, steps, ticks, data);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     hipEventElapsedTime(&ms, e0, e1);
   }
-  unsigned long long h[256];
-  hipMemcpy(h, ticks, 8 * blocks, hipMemcpyDeviceToHost);
-  double avg = 0;
-  for (int i = 0; i < blocks; ++i) avg += h[i];
-  avg /= blocks;
-  printf("%-28s blocks %3d: %7.0f ticks/step (%.0f %% of the MFMA rate), %.1f us, %.2f GHz, %s\n", name, blocks, avg / steps,
-         100.0 * 6912 * steps / avg, ms * 1e3, avg / (ms * 1e6), hipGetErrorString(hipGetLastError()));
+  unsigned long long h[512];
+  hipMemcpy(h, ticks, 8 * 512, hipMemcpyDeviceToHost);
+  double avg = 0, clk = 0;
+  for (int i = 0; i < blocks; ++i) { avg += h[i]; clk += (double)h[i] / (double)h[256 + i] * 0.1; }  // in-kernel clock, GHz
+  avg /= blocks; clk /= blocks;
+  printf("%-28s blocks %3d: %7.0f ticks/step (%.0f %% of the MFMA rate), %.1f us, %.2f GHz (event), %.3f GHz (s_memtime / s_memrealtime), %s\n",
+         name, blocks, avg / steps, 100.0 * 6912 * steps / avg, ms * 1e3, avg / (ms * 1e6), clk, hipGetErrorString(hipGetLastError()));
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* out; unsigned long long* ticks;
-  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&ticks, 8 * 256);
-  const int steps = 64;
+  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&ticks, 8 * 512);
+  const int steps = argc > 1 ? atoi(argv[1]) : 64;
+  if (argc > 2) g_reps = atoi(argv[2]);
   for (int data : {0, 1})
     for (int blocks : {8, 256}) {
       printf("data %d\n", data);
