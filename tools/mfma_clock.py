@@ -27,16 +27,20 @@ for line in out.splitlines():
     m = re.match(r"(.+?)\s+blocks\s+(\d+):\s+(\d+) ticks/step \((\d+) % of the MFMA rate\), ([\d.]+) us, ([\d.]+) GHz \(event\), "
                  r"([\d.]+) GHz", line)
     if m:
+        us_step = float(m.group(5)) / 4096
+        clk = float(m.group(7))
+        # (the in-kernel tick count is wave 0's: with two waves per SIMD the older wave finishes early, so the rate is taken
+        # from the launch's wall time at the in-kernel clock instead)
         rows.append({"variant": m.group(1).strip(), "operands": "random mantissas" if data else "near-constant", "cus": int(m.group(2)),
-                     "ticks_per_step": int(m.group(3)), "mfma_rate_pct": int(m.group(4)), "clock_ghz_event": float(m.group(6)),
-                     "clock_ghz_in_kernel": float(m.group(7))})
+                     "us_per_step": round(us_step, 4), "clock_ghz_in_kernel": clk,
+                     "ticks_per_step_wall": round(us_step * clk * 1e3), "mfma_rate": round(6912 / (us_step * clk * 1e3), 3)})
 full = [r for r in rows if r["cus"] == 256 and r["operands"].startswith("random")]
 res = {"source": "tools/micro/cons_loop.hip via tools/mfma_clock.py", "steps_per_launch": 4096, "launches": 120,
        "rows": rows,
        "power_limited_ceiling": None}
 if full:
     clk = min(r["clock_ghz_in_kernel"] for r in full)
-    rate = max(r["mfma_rate_pct"] for r in full) / 100.0
+    rate = max(r["mfma_rate"] for r in full)
     res["power_limited_ceiling"] = {
         "clock_ghz": clk, "mfma_rate": rate,
         "mfma_work_pflops": round(2.5 * rate * clk / 2.4, 3),
