@@ -389,6 +389,45 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
             }
           __builtin_amdgcn_sched_barrier(0);
         }
+        // edge vectors of border tiles, also into the accumulators before the first store (a load behind a store would wait
+        // for that store to reach memory: eight drains per item in the waves that own an image column).  First / last
+        // output row: wave-uniform, at most two row-phases of a wave.  First / last output column: one lane of a border
+        // tile's waves, all eight row-phases: fetched four at a time.
+        if (d.eh) {
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+              const int oy = 2 * (myb + r) + py;
+              if (myb + r < d.LH && (oy == 0 || oy == OH - 1)) {
+                float e8[8];
+                load8(d.eh + (((size_t)n * 2 + (oy ? 1 : 0)) * OW + ox_own) * d.Ch + c8, e8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[r][py][0][j] += e8[j]; acc[r][py][1][j] += e8[4 + j]; }
+              }
+            }
+          if (own_ok && (ox_own == 0 || ox_own == OW - 1)) {
+            const float* evp = d.ev + ((size_t)n * 2 + (ox_own ? 1 : 0)) * OH * d.Ch + c8;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              float e8[4][8];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int r = half * 2 + (q >> 1), py = q & 1;
+                const int oy = min(2 * (myb + r) + py, OH - 1);
+                load8(evp + (size_t)oy * d.Ch, e8[q]);
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int r = half * 2 + (q >> 1), py = q & 1;
+                const int oy = 2 * (myb + r) + py;
+                const float k = (myb + r < d.LH && oy > 0 && oy < OH - 1) ? 1.f : 0.f;  // (rows 0 / OH-1 took the row vectors)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[r][py][0][j] += k * e8[q][j]; acc[r][py][1][j] += k * e8[q][4 + j]; }
+              }
+            }
+          }
+        }
         float post2_8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) post2_8[j] = 0.f;
@@ -409,6 +448,11 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         } else {
           if (d.out2) load8(d.post2 + (size_t)n * d.post2_cs + c8, post2_8);
         }
+        // Every load of the epilogue is consumed HERE, unconditionally: a value that is only used inside the `row is inside
+        // the image` branches below leaves its load formally pending on the other path, and the compiler then drains the
+        // whole vector-memory counter (the item's STORES included) in front of the next step's first fragment read.
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(bias8[j]), "v"(post2_8[j]));
         UF_STAMP(8);
         const int lane_b = (lo ? 0 : 64) + kg_e * 16;
         // fused projection on top of the projected att-half already in fuse_out: its values, loaded before the first store
@@ -425,6 +469,13 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
                 if (d.fuse_acc && own_ok && kg_e == 0 && j < d.fuse_dim && myb + r < d.LH)
                   prev[r][py][j] = d.fuse_out[((size_t)n * d.fuse_dim + j) * plane + (size_t)(2 * (myb + r) + py) * OW + ox_own];
               }
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)  // (consumed unconditionally, like the constants above: no load may stay formally pending)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) asm volatile("" :: "v"(prev[r][py][0]), "v"(prev[r][py][1]), "v"(prev[r][py][2]), "v"(prev[r][py][3]));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fb[j]));
+          asm volatile("" :: "v"(wfr.hi), "v"(wfr.lo));
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
@@ -436,19 +487,6 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
               float v[8];
 #pragma unroll
               for (int j = 0; j < 4; ++j) { v[j] = acc[r][py][0][j] + bias8[j]; v[4 + j] = acc[r][py][1][j] + bias8[4 + j]; }
-              if (d.eh) {
-                if (oy == 0 || oy == OH - 1) {  // first / last output row (wave-uniform)
-                  float e8[8];
-                  load8(d.eh + (((size_t)n * 2 + (oy ? 1 : 0)) * OW + ox_own) * d.Ch + c8, e8);
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) v[j] += e8[j];
-                } else if (ox_own == 0 || ox_own == OW - 1) {  // first / last output column (one lane of a border tile)
-                  float e8[8];
-                  load8(d.ev + (((size_t)n * 2 + (ox_own ? 1 : 0)) * OH + oy) * d.Ch + c8, e8);
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) v[j] += e8[j];
-                }
-              }
               if constexpr (FUSE) {
                 u32x4 h, l;
                 drs_sp_split8(v, h, l);
