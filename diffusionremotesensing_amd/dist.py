@@ -88,6 +88,7 @@ class _PendingReduce:
     def __init__(self, work, flat, n_grad, slots, world, need_div):
         self.work, self.flat, self.n_grad, self.slots, self.world, self.need_div = work, flat, n_grad, slots, world, need_div
         self.done = False
+        self.created_grads = []  # parameters whose .grad this wait() created (unused on this rank, used on another)
 
     def wait(self):
         if self.done:
@@ -105,6 +106,7 @@ class _PendingReduce:
                     continue  # unused everywhere: .grad stays None on every rank, Adam skips it everywhere (like DDP)
                 if p.grad is None:
                     p.grad = view  # unused here, used elsewhere: the averaged gradient, so that Adam steps identically
+                    self.created_grads.append(p)
                 elif copy_back:
                     p.grad.copy_(view)
         else:
@@ -138,11 +140,15 @@ def allreduce_gradients(module, async_op=False):
     if buf is not None:
         flat, n_grad, entries, has_flags = buf
         slots = []
+        aliased = False
         for p, view in entries:
             if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
                 slots = None  # gradients were accumulated elsewhere: take the generic path
                 break
+            aliased = aliased or p.grad is not None
             slots.append((p, view, False))
+        if slots is not None and not aliased:
+            slots = None  # no gradient of THIS step lives in the engine's buffer (it is the previous backward's): generic path
         if slots is not None and has_flags:
             flags = torch.tensor([0.0 if p.grad is None else 1.0 for p, _ in entries], dtype=torch.float32)
             flat[n_grad:].copy_(flags.pin_memory() if flat.is_cuda else flags, non_blocking=True)

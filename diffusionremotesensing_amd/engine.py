@@ -290,6 +290,17 @@ class HipUNetEngine:
         flat, total, slots, has_flags = self._grad_buffer
         return flat, total, [(p, flat[off:off + k].view_as(p)) for p, off, k in slots], has_flags
 
+    def check_faults(self):
+        """Synchronise and raise if a wave of the wave-specialised kernels gave up on an LDS counter during a forward of the
+        last plan (drs_unet_check_faults: a protocol bug reports itself instead of hanging or faulting the device)."""
+        plan = getattr(self, "_last_plan", None)
+        if plan is None or plan.signature is None:
+            return
+        with torch.cuda.device(plan.device):
+            st = plan.lib.drs_unet_check_faults(plan.handle, C.c_void_p(plan.packed.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream(plan.device).cuda_stream))
+        _lib.check(st, "drs_unet_check_faults")
+
     # -- per-op timing (bench.py roofline) ------------------------------------------------------
     def profile_forward(self, x, timestep, lr_img, magnification_factor, iters=5, **kw):
         """Run `iters` forwards with HIP events around every op of the schedule (recorded on the launch stream)

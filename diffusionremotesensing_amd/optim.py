@@ -86,7 +86,7 @@ class FusedAdam(torch.optim.Optimizer):
             ring["event"][k] = ev
             b1, b2 = group["betas"]
             if grad_ready is not None:
-                grad_ready()
+                self._late_wait(grad_ready)
                 grad_ready = None
             with torch.cuda.device(dev):
                 st = lib.drs_adam_multi(C.c_void_p(devt.data_ptr()), n, max(r[4] for r in rows), float(group["lr"]),
@@ -97,5 +97,19 @@ class FusedAdam(torch.optim.Optimizer):
             # that everything keyed on `_version` (the engine's packed-weight cache) sees the update
             torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
         if grad_ready is not None:
-            grad_ready()
+            self._late_wait(grad_ready)
         return loss
+
+    @staticmethod
+    def _late_wait(grad_ready):
+        """The exchange's wait, AFTER the pointer table was built.  A gradient that the wait itself creates (parameter unused
+        on this rank, used on another: dist._PendingReduce.created_grads) has no row in that table: this rank would skip the
+        update the other ranks apply and the replicas would drift apart silently.  Parameters that can be unused per rank
+        must carry `_drs_maybe_unused` (then the wait runs first); anything else is reported, not ignored."""
+        grad_ready()
+        owner = getattr(grad_ready, "__self__", None)
+        created = getattr(owner, "created_grads", None)
+        if created:
+            raise RuntimeError(f"FusedAdam: the gradient exchange created .grad for {len(created)} parameter(s) after the "
+                               "update table was built; mark parameters that may be unused on some ranks with "
+                               "`p._drs_maybe_unused = True` so that the exchange is waited for first")

@@ -144,6 +144,18 @@ def test_upconv_fused_matches_convtranspose_cat_conv(dev, case):
         _assert_close(gotp, F.conv2d(want, f_w, f_b), TOL_UPFUSE, f"upconv_fused {case} fused projection")
 
 
+def test_no_protocol_faults_after_a_full_size_forward(dev, model):
+    """The wave-specialised kernels bound every LDS-counter poll; a wave that runs out records it in the plan's fault word
+    and ends (csrc/sp_sync.h).  A healthy forward at the headline size leaves the word clear."""
+    from diffusionremotesensing_amd import synthetic
+    model.hip_engine().set_impl("mfma_bf16x3")
+    x, t, lr = golden_inputs("faults", 16, 16, 3, 256, 2, 1500)
+    with torch.no_grad():
+        y = model(x.to(dev), t.to(dev), lr.to(dev), 2)
+    model.hip_engine().check_faults()
+    assert torch.isfinite(y).all()
+
+
 def test_upconv_fused_rejects_bad_shapes(dev):
     from diffusionremotesensing_amd import hip_ops
     z = lambda *s: torch.zeros(*s, device=dev)
