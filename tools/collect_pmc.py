@@ -39,7 +39,7 @@ if ops_file and os.path.exists(ops_file):
                     e = disp[int(row["Dispatch_Id"])]
                     e[row["Counter_Name"]] += float(row["Counter_Value"])
                     e["kernel"] = re.sub(r"\(.*", "", row["Kernel_Name"].replace("(anonymous namespace)::", ""))[:120]
-    mine = [v for _, v in sorted(disp.items()) if re.search(r"tapconv|stem_kernel|time_mlp|attn_gate|conv3x3_direct|conv_s2_sp|convt_sp", v["kernel"])]
+    mine = [v for _, v in sorted(disp.items()) if re.search(r"tapconv|stem_kernel|time_mlp|attn_gate|conv3x3_direct|conv_s2_sp|convt_sp|upfuse_sp_kernel|upfuse_edges", v["kernel"])]
     if len(mine) >= len(names):
         last = mine[-len(names):]  # the last forward re-uses the cached conditioning branch: exactly the listed ops
         per_op = [{"op": n, "kernel": v["kernel"], "hbm_read_bytes": 2 * v["FETCH_SIZE"] * 1024,
