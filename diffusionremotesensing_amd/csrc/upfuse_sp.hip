@@ -54,7 +54,8 @@ struct UfGeom {
   static constexpr int TAPS = 5, NGRP = 5, NSLOT = 3;
   static constexpr int W_IMAGE = TAPS * 4 * 32 * 16;  // one operand image (hi or lo) of a group: [tap][k-group][32 channels] slots
   static constexpr int SLOT = 2 * W_IMAGE;            // 20 KB
-  static constexpr int LDS = 2 * WBUF + NSLOT * SLOT + 64;
+  static constexpr int CONST = 2048;                  // per-launch epilogue constants: bias[Ch <= 256] | fuse_w[4][32] | fuse_b[4]
+  static constexpr int LDS = 2 * WBUF + NSLOT * SLOT + 64 + CONST;
 };
 
 // column groups (tx, px) and their taps (py, ty), in streaming order
@@ -68,7 +69,7 @@ __host__ __device__ constexpr bool uf_pair(int p, int t, int kv, int kw) { retur
 __host__ __device__ constexpr int uf_perm(int nn) { return ((nn & 15) >> 2) * 8 + (nn >> 4) * 4 + (nn & 3); }
 
 template <bool FUSE>
-__global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int tiles_y, int tiles_x, int nck) {
+__global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int tiles_y, int tiles_x, int nck, int debug) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   using G = UfGeom;
@@ -106,6 +107,14 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
     n_ = it / tiles_y;
   };
   if (tid < 10) __hip_atomic_store(sCR + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // epilogue constants that do not depend on the item: staged once (a global load at the start of every item epilogue is a
+  // memory round trip with the matrix pipe of its SIMD idle)
+  float* sConst = reinterpret_cast<float*>(sW + G::NSLOT * SLOT + 64);
+  for (int i = tid; i < d.Ch; i += 768) sConst[i] = d.bias[i];
+  if constexpr (FUSE) {
+    if (tid < 128) sConst[256 + tid] = d.fuse_w[(size_t)min(tid >> 5, d.fuse_dim - 1) * d.Ch + (tid & 31)];
+    if (tid < 4) sConst[384 + tid] = d.fuse_b[min(tid, d.fuse_dim - 1)];
+  }
   sp_wait_lds();
   sp_barrier();
   int c = -1, ord = -1, n = 0, ty0 = 0, tx0 = 0, n0 = 0;  // current step: chunk, item ordinal, item coordinates (cells)
@@ -360,12 +369,16 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
           v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         };
         float bias8[8];
-        load8(d.bias + c8, bias8);
+        load8(sConst + c8, bias8);
         // att-half partial sums of this lane's pixels, added into the accumulators BEFORE the first store of the item (one
         // in-order counter for loads and stores: a load issued behind a store is complete only once that store is).  All
         // sixteen loads are in flight together (the fragment registers of the step loop are free by now): left to itself the
         // compiler issues them pair by pair with a full wait after each, eight memory round trips per item.
+#ifdef DRS_SP_TIMELINE
+        if (d.res && !(debug & 2)) {
+#else
         if (d.res) {
+#endif
           u32x4 rh[RPW][2], rl[RPW][2];
 #pragma unroll
           for (int r = 0; r < RPW; ++r)
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         if constexpr (FUSE) {
           // A operand of the projection: row lr = fuse_w[lr][this lane's 8 channels] (rows >= fuse_dim are zero)
           float w8[8];
-          load8(d.fuse_w + (size_t)min(lr_e, d.fuse_dim - 1) * d.Ch + c8, w8);
+          load8(sConst + 256 + min(lr_e, 3) * 32 + c8, w8);
           const float keep = lr_e < d.fuse_dim ? 1.f : 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) w8[j] *= keep;
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
           drs_sp_split8(w8, h, l);
           wfr = typename P::Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) fb[j] = d.fuse_b[min(j, d.fuse_dim - 1)];
+          for (int j = 0; j < 4; ++j) fb[j] = sConst[384 + j];
         } else {
           if (d.out2) load8(d.post2 + (size_t)n * d.post2_cs + c8, post2_8);
         }
@@ -492,6 +505,9 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
                 drs_sp_split8(v, h, l);
                 const typename P::Frag vf{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
                 const f32x4 y = P::mma(wfr, vf, f32x4{0.f, 0.f, 0.f, 0.f});  // lanes of k-group 0: outputs 0..3 of pixel lr
+#ifdef DRS_SP_TIMELINE
+                if (debug & 1) { asm volatile("" :: "v"(y)); } else
+#endif
                 if (own_ok && kg_e == 0) {
                   const size_t plane = (size_t)OH * OW;
                   float* o = d.fuse_out + (size_t)n * d.fuse_dim * plane + (size_t)oy * OW + ox_own;
@@ -507,6 +523,9 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
                   drs_sp_split8(w8, H, L);
                   const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo
                   char* g = reinterpret_cast<char*>(base) + (pix0 * cs + co + n0) * 4 + lane_b;
+#ifdef DRS_SP_TIMELINE
+                  if (debug & 1) { asm volatile("" :: "v"(H), "v"(L), "v"(got)); return; }
+#endif
                   if (ok0) *reinterpret_cast<u32x4*>(g) = lo ? H : got;
                   if (ok1) *reinterpret_cast<u32x4*>(g + (size_t)16 * cs * 4) = lo ? got : L;
                 };
@@ -802,7 +821,7 @@ __global__ void nchw_to_sp_kernel(const float* __restrict__ src, char* __restric
 
 bool drs_upfuse_supported(int Cc, int Ch, int LH, int LW) {
   static const int env = getenv("DRS_UPFUSE") ? atoi(getenv("DRS_UPFUSE")) : 1;
-  return env && Cc % 32 == 0 && Ch % 32 == 0 && Cc >= 32 && Ch >= 32 && LH > 8 && LW > 8;
+  return env && Cc % 32 == 0 && Ch % 32 == 0 && Cc >= 32 && Ch >= 32 && Ch <= 256 && LH > 8 && LW > 8;
 }
 size_t drs_upfuse_weight_bytes(int Cc, int Ch) { return (size_t)(Ch / 32) * (Cc / 32) * UfGeom::NGRP * UfGeom::SLOT; }
 size_t drs_upfuse_aux_floats(int Cc, int Ch) { return (size_t)11 * Cc * Ch + (size_t)10 * Ch; }
@@ -845,7 +864,8 @@ int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s) {
 
 int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
   DRS_REQUIRE(d.in && d.w && d.bias && d.zero_line && (d.out || d.out2 || d.fuse_out), DRS_ERR_ARG, "upfuse: null tensor");
-  DRS_REQUIRE(d.Cc % 32 == 0 && d.Ch % 32 == 0 && (d.in_cs & 31) == 0 && (d.in_co & 31) == 0, DRS_ERR_SHAPE, "upfuse: channels");
+  DRS_REQUIRE(d.Cc % 32 == 0 && d.Ch % 32 == 0 && d.Ch <= 256 && (d.in_cs & 31) == 0 && (d.in_co & 31) == 0, DRS_ERR_SHAPE,
+              "upfuse: channels");
   DRS_REQUIRE(!d.res || ((d.res_cs & 31) == 0 && (d.res_co & 31) == 0), DRS_ERR_SHAPE, "upfuse: res slice");
   DRS_REQUIRE(!d.out || ((d.out_cs & 31) == 0 && (d.out_co & 31) == 0), DRS_ERR_SHAPE, "upfuse: out slice");
   DRS_REQUIRE(!d.out2 || (d.post2 && (d.out2_cs & 31) == 0 && (d.out2_co & 31) == 0 && (d.post2_cs & 3) == 0),
@@ -868,10 +888,11 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
   long long blocks = num_cu;  // one 12-wave block per CU
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
+  static const int dbg = getenv("DRS_DEBUG_FLAGS") ? atoi(getenv("DRS_DEBUG_FLAGS")) : 0;  // timeline builds: 1 no stores, 2 no residual loads
   if (d.fuse_out)
-    hipLaunchKernelGGL(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
+    hipLaunchKernelGGL(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
   else
-    hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
+    hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
   DRS_CHECK_HIP(hipGetLastError());
 #ifdef DRS_SP_TIMELINE
   {
@@ -881,9 +902,9 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
     DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
     DRS_CHECK_HIP(hipEventRecord(e0, s));
     if (d.fuse_out)  // timed repeat (same result)
-      hipLaunchKernelGGL(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
+      hipLaunchKernelGGL(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
     else
-      hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck);
+      hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
     DRS_CHECK_HIP(hipEventRecord(e1, s));
     DRS_CHECK_HIP(hipStreamSynchronize(s));
     DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
