@@ -185,7 +185,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
             if (wr == ky + RPW - 1) {
-              if (ky == 0) sp_poll(sCL + col + 1, ltarget, d.fault);
+              if (ky == 0) sp_poll_lds(sCL + col + 1, ltarget, d.fault);
 #pragma unroll
               for (int t = 0; t < NT; ++t)
                 wf[ky][t] = P::load(wbase, W_IMAGE, (size_t)((((col + 1) * 3 + ky) * 4 * BNB) + t * 16) * 16);
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
       const char* buf = sWin + (k & 1) * WBUF;
       const unsigned ltarget = 4u * (unsigned)(k + 1);  // four movers per column and step
       SP_STAMP(7);
-      sp_poll(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1), d.fault);  // window k is in its buffer
-      sp_poll(sCL, ltarget, d.fault);                                   // ... and weight column 0 of k
+      sp_poll_lds(sWL + (k & 1), 4u * (unsigned)((k >> 1) + 1), d.fault);  // window k is in its buffer
+      sp_poll_lds(sCL, ltarget, d.fault);                                   // ... and weight column 0 of k
       SP_STAMP(0);
       read_wf(0);
       sp_wait_lds();

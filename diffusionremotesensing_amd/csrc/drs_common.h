@@ -255,6 +255,9 @@ struct WgradDesc {
 int drs_launch_wgrad(const WgradDesc& d, hipStream_t s);
 bool drs_wgrad_mfma_supported(const WgradDesc& d);
 int drs_launch_wgrad_mfma(const WgradDesc& d, float* partial, size_t partial_bytes, hipStream_t s);
+// the same on the bf16 matrix pipe, operands split hi + lo (wgrad_mfma_bf16.hip); DRS_TRAIN_WGRAD_IMPL=mfma_f32 disables it
+bool drs_wgrad_mfma_bf16_supported(const WgradDesc& d);
+int drs_launch_wgrad_mfma_bf16(const WgradDesc& d, float* partial, size_t partial_bytes, hipStream_t s);
 int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, long long pix_per_image, int per_image,
                       int out_stride, float* out, hipStream_t s);
 int drs_launch_relu_mask(float* g, int g_cs, int g_co, const float* y, int y_cs, int y_co, int C, long long npix,

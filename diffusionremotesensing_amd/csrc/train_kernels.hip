@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradDesc d, int chunk) {
 int drs_launch_wgrad(const WgradDesc& d, hipStream_t s) {
   const long long P = (long long)d.N * d.TH * d.TW;
   if (P == 0) return DRS_OK;
+  if (d.partial && drs_wgrad_mfma_bf16_supported(d)) return drs_launch_wgrad_mfma_bf16(d, d.partial, d.partial_bytes, s);
   if (d.partial && drs_wgrad_mfma_supported(d)) return drs_launch_wgrad_mfma(d, d.partial, d.partial_bytes, s);
   if (d.dbias) {  // the direct kernel has no fused bias gradient
     int rc = drs_launch_colsum(d.B, d.b_cs, d.b_co, d.Cb, (long long)d.N * d.BH * d.BW, (long long)d.BH * d.BW, 0, 0, d.dbias, s);

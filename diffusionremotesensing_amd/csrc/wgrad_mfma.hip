@@ -255,6 +255,25 @@ int launch_nt(const WgradMfmaArgs& a, size_t partial_bytes, int* nslices, hipStr
 
 }  // namespace
 
+// fold the partial slices of a weight-gradient launch into dW (+ the bias gradient): shared by the fp32 and the split-bf16 form
+int drs_wgrad_reduce(const float* partial, long long slice_stride, int nslices, int Cf, int Cv, int ntaps, const int* wtap, int of,
+                     int ov, int T_total, float* dW, float* dbias, hipStream_t s) {
+  ReduceArgs r = {};
+  r.partial = partial; r.slice_stride = slice_stride; r.nslices = nslices; r.Cf = Cf; r.Cv = Cv; r.NT = ntaps;
+  for (int t = 0; t < ntaps; ++t) r.wtap[t] = wtap[t];
+  r.of = of; r.ov = ov; r.T_total = T_total; r.dW = dW;
+  r.dbias = dbias;
+  const long long numel = slice_stride;
+  const unsigned gx = (unsigned)((numel + 255) / 256);
+  // enough blocks to pull the partials at HBM speed: aim at >= 1024 blocks in all
+  int gy = (int)std::min<long long>(nslices, std::max<long long>(1, 1024 / gx));
+  const int spy = (nslices + gy - 1) / gy;
+  gy = (nslices + spy - 1) / spy;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, s, r, spy);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
 bool drs_wgrad_mfma_supported(const WgradDesc& d) {
   // channel counts: multiples of 16, or a few-channel image side (<= 4 channels, scalar staging into a 16-wide tile)
   if ((d.Ca % 16 && d.Ca > 4) || (d.Cb % 16 && d.Cb > 4)) return false;
@@ -316,18 +335,6 @@ int drs_launch_wgrad_mfma(const WgradDesc& d, float* partial, size_t partial_byt
   }
   if (rc == -1) { DrsErr::set("wgrad_mfma: workspace of %zu bytes / LDS too small for this layer", partial_bytes); return DRS_ERR_WORKSPACE; }
   if (rc) return rc;
-  ReduceArgs r = {};
-  r.partial = partial; r.slice_stride = a.slice_stride; r.nslices = nslices; r.Cf = a.Cf; r.Cv = a.Cv; r.NT = d.ntaps;
-  for (int t = 0; t < d.ntaps; ++t) r.wtap[t] = d.wtap[t];
-  r.of = of; r.ov = ov; r.T_total = d.T_total; r.dW = d.dW;
-  r.dbias = a.bias ? d.dbias : nullptr;
-  const long long numel = a.slice_stride;
-  const unsigned gx = (unsigned)((numel + 255) / 256);
-  // enough blocks to pull the partials at HBM speed: aim at >= 1024 blocks in all
-  int gy = (int)std::min<long long>(nslices, std::max<long long>(1, 1024 / gx));
-  const int spy = (nslices + gy - 1) / gy;
-  gy = (nslices + spy - 1) / spy;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, s, r, spy);
-  DRS_CHECK_HIP(hipGetLastError());
-  return DRS_OK;
+  return drs_wgrad_reduce(partial, a.slice_stride, nslices, a.Cf, a.Cv, d.ntaps, d.wtap, of, ov, d.T_total, d.dW,
+                          a.bias ? d.dbias : nullptr, s);
 }
