@@ -96,44 +96,84 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBf16Args g) {
     }
   };
 
-  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-    const int tx0 = (tile % g.tiles_x) * CT;
-    const int ty0 = ((tile / g.tiles_x) % g.tiles_y) * RT;
-    const int n = tile / (g.tiles_x * g.tiles_y);
-    __syncthreads();  // every wave is done reading the previous tile
-    // ---- stage F: RT x CT positions, CHF channels (zero outside the domain), converted to bf16 hi | lo ----
-    for (int i = tid; i < RT * CT * QF; i += 256) {
-      const int q = i % QF, p = i / QF;
-      const int y = ty0 + p / CT, x = tx0 + p % CT, c = f0 + q * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (y < g.TH && x < g.TW && c < g.Cf)
-        v = *reinterpret_cast<const f32x4*>(g.F + (((long long)n * g.TH + y) * g.TW + x) * g.f_cs + g.f_co + c);
-      s16x4 h, l;
-      split4(v, h, l);
-      const int off = (q >> 2) * F_TILE_BYTES + row_off(p) + (q & 3) * 8;
-      *reinterpret_cast<s16x4*>(sFh + off) = h;
-      *reinterpret_cast<s16x4*>(sFl + off) = l;
+  // Staging, software-pipelined: the global loads of the NEXT tile are issued before this tile's MFMAs and converted /
+  // written to LDS after them (registers carry them across; a tile's loads are a memory round trip that nothing else on
+  // the CU would cover at 2 blocks per CU).  Layers with an input add / gate or a window beyond the prefetch registers
+  // (stride-2 taps) stage in place instead.
+  constexpr int NPF = (RT * CT * QF + 255) / 256, NPV = 7;
+  const int wtotal = g.WR * g.WC * QV;
+  const bool pipe = !g.v_add && !g.v_gate && wtotal <= NPV * 256;
+  f32x4 pf[NPF], pv[NPV];
+  auto tile_coords = [&](int tile, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
+    tx0 = (tile % g.tiles_x) * CT;
+    ty0 = ((tile / g.tiles_x) % g.tiles_y) * RT;
+    n = tile / (g.tiles_x * g.tiles_y);
+  };
+  auto load_f = [&](int i, int n, int ty0, int tx0) __attribute__((always_inline)) {
+    const int q = i % QF, p = i / QF;
+    const int y = ty0 + p / CT, x = tx0 + p % CT, c = f0 + q * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < RT * CT * QF && y < g.TH && x < g.TW && c < g.Cf)
+      v = *reinterpret_cast<const f32x4*>(g.F + (((long long)n * g.TH + y) * g.TW + x) * g.f_cs + g.f_co + c);
+    return v;
+  };
+  auto load_v = [&](int i, int n, int ty0, int tx0) __attribute__((always_inline)) {
+    const int q = i % QV, p = i / QV;
+    const int wy = (int)__umulhi((unsigned)p, g.wc_magic), wx = p - wy * g.WC;
+    const int y = ty0 * g.sv + g.ymin + wy, x = tx0 * g.sv + g.xmin + wx, c = v0 + q * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < wtotal && y >= 0 && y < g.VH && x >= 0 && x < g.VW && c < g.Cv) {
+      v = *reinterpret_cast<const f32x4*>(g.V + (((long long)n * g.VH + y) * g.VW + x) * g.v_cs + g.v_co + c);
+      if (g.v_add) v += *reinterpret_cast<const f32x4*>(g.v_add + (long long)n * g.v_add_cs + c);
+      if (g.v_gate) v *= g.v_gate[((long long)n * (g.VH >> 1) + (y >> 1)) * (g.VW >> 1) + (x >> 1)];
     }
-    // ---- stage the V window: WR x WC pixels, CHV channels (zero outside the image: the convolution's padding) ----
-    const int ybase = ty0 * g.sv + g.ymin, xbase = tx0 * g.sv + g.xmin;
-    const int wtotal = g.WR * g.WC * QV;
-    for (int i = tid; i < wtotal; i += 256) {
-      const int q = i % QV, p = i / QV;
-      const int wy = (int)__umulhi((unsigned)p, g.wc_magic), wx = p - wy * g.WC;
-      const int y = ybase + wy, x = xbase + wx, c = v0 + q * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (y >= 0 && y < g.VH && x >= 0 && x < g.VW && c < g.Cv) {
-        v = *reinterpret_cast<const f32x4*>(g.V + (((long long)n * g.VH + y) * g.VW + x) * g.v_cs + g.v_co + c);
-        if (g.v_add) v += *reinterpret_cast<const f32x4*>(g.v_add + (long long)n * g.v_add_cs + c);
-        if (g.v_gate) v *= g.v_gate[((long long)n * (g.VH >> 1) + (y >> 1)) * (g.VW >> 1) + (x >> 1)];
-      }
-      s16x4 h, l;
-      split4(v, h, l);
-      const int off = (q >> 2) * g.vt_bytes + row_off(p) + (q & 3) * 8;
-      *reinterpret_cast<s16x4*>(sVh + off) = h;
-      *reinterpret_cast<s16x4*>(sVl + off) = l;
+    return v;
+  };
+  auto store_f = [&](int i, const f32x4& v) __attribute__((always_inline)) {
+    if (i >= RT * CT * QF) return;
+    const int q = i % QF, p = i / QF;
+    s16x4 h, l;
+    split4(v, h, l);
+    const int off = (q >> 2) * F_TILE_BYTES + row_off(p) + (q & 3) * 8;
+    *reinterpret_cast<s16x4*>(sFh + off) = h;
+    *reinterpret_cast<s16x4*>(sFl + off) = l;
+  };
+  auto store_v = [&](int i, const f32x4& v) __attribute__((always_inline)) {
+    if (i >= wtotal) return;
+    const int q = i % QV, p = i / QV;
+    s16x4 h, l;
+    split4(v, h, l);
+    const int off = (q >> 2) * g.vt_bytes + row_off(p) + (q & 3) * 8;
+    *reinterpret_cast<s16x4*>(sVh + off) = h;
+    *reinterpret_cast<s16x4*>(sVl + off) = l;
+  };
+  auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    int n, ty0, tx0;
+    tile_coords(tile, n, ty0, tx0);
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) pf[u] = load_f(tid + u * 256, n, ty0, tx0);
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) pv[u] = load_v(tid + u * 256, n, ty0, tx0);
+  };
+  if (pipe && (int)blockIdx.x < g.ntiles) prefetch(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    int n, ty0, tx0;
+    tile_coords(tile, n, ty0, tx0);
+    __syncthreads();  // every wave is done reading the previous tile
+    if (pipe) {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) store_f(tid + u * 256, pf[u]);
+#pragma unroll
+      for (int u = 0; u < NPV; ++u) store_v(tid + u * 256, pv[u]);
+    } else {
+      // ---- stage F: RT x CT positions, CHF channels (zero outside the domain), converted to bf16 hi | lo ----
+      for (int i = tid; i < RT * CT * QF; i += 256) store_f(i, load_f(i, n, ty0, tx0));
+      // ---- stage the V window: WR x WC pixels, CHV channels (zero outside the image: the convolution's padding) ----
+      for (int i = tid; i < wtotal; i += 256) store_v(i, load_v(i, n, ty0, tx0));
     }
     __syncthreads();
+    if (pipe && tile + (int)gridDim.x < g.ntiles) prefetch(tile + gridDim.x);
     // ---- two K-steps of 32 positions: k = 8 kq + e  <->  position (row 2 s + (kq >> 1), x = (kq & 1) * 8 + e) ----
 #pragma unroll
     for (int s = 0; s < 2; ++s) {

@@ -678,15 +678,19 @@ def test_conv_kernel_variants_in_subprocess(env):
 
 
 @pytest.mark.gpu
-def test_split_bf16_data_gradients_keep_fp32_grade_accuracy():
-    """DRS_TRAIN_BWD_IMPL=mfma_bf16x3: data-gradient convolutions on split-bf16 next to an exact-fp32 forward and exact
-    fp32 weight gradients.  The gradient error of split-bf16 TRAINING comes from the forward activations (amplified by
-    the BatchNorm-backward cancellations), not from the backward products: with an fp32 forward the golden gradient
-    test holds at its fp32 tolerance (2e-4; 4e-5 measured).  Own process: the switch is read once."""
+@pytest.mark.parametrize("env", [{"DRS_TRAIN_BWD_IMPL": "mfma_f32", "DRS_TRAIN_WGRAD_IMPL": "mfma_f32"},
+                                 {"DRS_TRAIN_BWD_IMPL": "mfma_f32"}, {"DRS_TRAIN_WGRAD_IMPL": "mfma_f32"}],
+                         ids=["exact-fp32-backward", "exact-data-gradients", "exact-weight-gradients"])
+def test_backward_product_arithmetic_variants(env):
+    """Training default: exact-fp32 forward, backward PRODUCTS (data gradients: csrc/train_bwd.inc, weight gradients:
+    csrc/wgrad_mfma_bf16.hip) on split bf16 with fp32 accumulation - the golden gradient test holds at its fp32 tolerance
+    (2e-4) and the full-size configs[2] step at 1e-3 either way, because the gradient error of split-bf16 TRAINING comes from
+    the forward activations (amplified by the BatchNorm-backward cancellations), not from the backward products.  The
+    switches restore the exact-fp32 products; all combinations must pass the same tests.  Own process: read once."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DRS_TRAIN_BWD_IMPL="mfma_bf16x3")
+    env = dict(os.environ, **env)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-m", "gpu", "-k",
            "test_train_step_gradients_golden and mfma_f32"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900,
