@@ -435,16 +435,31 @@ int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
   return DRS_OK;
 }
 
-// per-image gating bias for a stage input stored as x + vec[n] (drs_common.h: AttnGateDesc::b_gate_img)
-__global__ void gate_bias_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ vec,
-                                 int vec_stride, float* __restrict__ out, int N, int Cc, int Ch) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * Ch) return;
-  const int n = i / Ch, co = i - n * Ch;
+// per-image gating bias for a stage input stored as x + vec[n] (drs_common.h: AttnGateDesc::b_gate_img).  One block per
+// (image, 64 output channels): 4 slices of the input channels x 64 channels, loads unrolled (independent), partial sums
+// through LDS in a fixed order.
+__global__ __launch_bounds__(256) void gate_bias_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                        const float* __restrict__ vec, int vec_stride, float* __restrict__ out,
+                                                        int N, int Cc, int Ch) {
+  __shared__ float part[4][64];
+  const int n = blockIdx.y, co = blockIdx.x * 64 + (threadIdx.x & 63), ks = threadIdx.x >> 6;
   const float* v = vec + (size_t)n * vec_stride;
   float a = 0.f;
-  for (int ci = 0; ci < Cc; ++ci) a += w[(size_t)ci * Ch + co] * v[ci];
-  out[i] = b[co] - a;
+  if (co < Ch) {
+    const int per = (Cc + 3) / 4, c0 = ks * per, c1 = min(Cc, c0 + per);
+    int ci = c0;
+    for (; ci + 8 <= c1; ci += 8) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(ci + u) * Ch + co];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += wv[u] * v[ci + u];
+    }
+    for (; ci < c1; ++ci) a += w[(size_t)ci * Ch + co] * v[ci];
+  }
+  part[ks][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (ks == 0 && co < Ch) out[(size_t)n * Ch + co] = b[co] - (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
 }
 
 }  // namespace
@@ -484,7 +499,7 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
 int drs_launch_gate_bias(const float* w, const float* b, const float* vec, int vec_stride, float* out, int N, int Cc, int Ch,
                          hipStream_t s) {
   if (N * Ch == 0) return DRS_OK;
-  hipLaunchKernelGGL(gate_bias_kernel, dim3((N * Ch + 127) / 128), dim3(128), 0, s, w, b, vec, vec_stride, out, N, Cc, Ch);
+  hipLaunchKernelGGL(gate_bias_kernel, dim3((Ch + 63) / 64, N), dim3(256), 0, s, w, b, vec, vec_stride, out, N, Cc, Ch);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -417,7 +417,7 @@ struct drs_plan {
   size_t o_dtemb = 0, o_scratch = 0, o_wgrad = 0;
   // second stream of the eval forward: the attention branch of a decoder stage runs next to the up-sampling branch
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gbias = nullptr;
 
   int P(const std::string& name, int64_t numel) {
     params.push_back({name, numel});
@@ -778,6 +778,7 @@ extern "C" void drs_unet_plan_destroy(drs_plan* plan) {
     (void)hipStreamSynchronize(plan->side);
     (void)hipEventDestroy(plan->ev_fork);
     (void)hipEventDestroy(plan->ev_join);
+    (void)hipEventDestroy(plan->ev_gbias);
     (void)hipStreamDestroy(plan->side);
   }
   delete plan;
@@ -1005,6 +1006,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     DRS_CHECK_HIP(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
     DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
     DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
+    DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_gbias, hipEventDisableTiming));
   }
 
   // --- time embeddings for the 7 blocks (reference :338-339 + every time_mlp) ---
@@ -1024,6 +1026,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
   prof_end(plan, s);
   // Stage inputs that are stored only as x + relu(time_mlp(t)) (below): the fused gate takes the row vector out again
   // through a per-image bias, b'[n] = b - Wg temb[n] (16 x Ch dot products per stage, next to the time MLPs).
+  if (mlp_side) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, st_mlp));  // (the encoder only needs the embeddings; the bias tables are for the decoder's gates)
   bool xt_only[3] = {false, false, false};
   if (plan->sp && !train && !(c.flags & DRS_PLAN_KEEP_ALL)) {
     static const int xt_env = getenv("DRS_XT_ONLY") ? atoi(getenv("DRS_XT_ONLY")) : 1;
@@ -1037,7 +1040,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
                                  plan->temb_total, (float*)((char*)ws + st.o_gbias), B, kUp[i], kUp[i + 1], st_mlp));
     }
   }
-  if (mlp_side) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, st_mlp));
+  if (mlp_side) DRS_CHECK_HIP(hipEventRecord(plan->ev_gbias, st_mlp));
 
   // --- LR conditioning branch: RRDB -> bicubic -> conv (reference :345-353), constant per sampling chain ---
   if (has_cond && !reuse_cond) {
@@ -1160,6 +1163,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     }
   }
 
+  if (mlp_side) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_gbias, 0));  // per-image gating biases (side stream) are ready
   // --- decoder (reference :372-377) ---
   // Eval plans run the attention branch of a stage (gating, w_g, w_x, psi, result: HBM-bound 1x1 / 2x2 kernels) on a
   // second stream NEXT TO the up-sampling branch (3x3 conv + ConvTranspose: MFMA / LDS-bound): both only read the stage

@@ -20,5 +20,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o t -- python3 bench.py --workload
 python3 tools/rocpd_stats.py $(find /tmp/kt2 -name "t_results.db" | head -1) 40 --csv > $O/train_kernel_stats.csv || exit 1
 python3 bench.py --workload train --steps 10 --warmup 2 > $O/bench_train.json 2>> $O/kt2.log
 python3 tools/latency_regime.py --steps 50 --json $O/latency_regime.json > $O/latency_regime.txt 2>&1 || exit 1
+python3 tools/per_op_table.py > $O/per_op_table.txt 2>&1 || exit 1
+python3 tools/diag_grads.py > $O/diag_grads.txt 2>&1 || true
+python3 tools/mfma_clock.py $O/mfma_clock.json > $O/mfma_clock.log 2>&1 || true
 python3 bench.py > $O/bench_final.json 2> $O/bench_final.log
 tail -c 600 $O/bench_final.json
