@@ -178,8 +178,8 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
         u32x4 h, l;
         drs_sp_split8(v, h, l);
         if (valid) {
-          *reinterpret_cast<u32x4*>(o + cc * 128) = h;
-          *reinterpret_cast<u32x4*>(o + cc * 128 + 64) = l;
+          drs_store16(o + cc * 128, h);
+          drs_store16(o + cc * 128 + 64, l);
         }
       }
     }
@@ -409,8 +409,8 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
           if (valid[b]) {
             const size_t pix = ((size_t)nn[b] * OH + 2 * yy[b] + (t4 >> 1)) * OW + 2 * px[b] + (t4 & 1);
             char* o = reinterpret_cast<char*>(d.out) + (pix * d.out_cs + d.out_co + cg * 32) * 4 + kg * 16;
-            *reinterpret_cast<u32x4*>(o) = h;
-            *reinterpret_cast<u32x4*>(o + 64) = l;
+            drs_store16(o, h);
+            drs_store16(o + 64, l);
           }
         }
       }

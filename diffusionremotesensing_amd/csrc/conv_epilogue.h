@@ -3,6 +3,23 @@
 #pragma once
 #include "mfma_policy.h"
 
+// 16-byte activation store.  DRS_WT_STORES=1 makes it WRITE-THROUGH (`sc1`): the idea was that a kernel which leaves its
+// output dirty in the XCDs' L2s pays for the write-back at the kernel boundary (MI355X_MICROARCH.md, row "boundary").
+// Measured A/B on one box (tools/build_variant.sh, round 3): 681.5 steps/s written through against 686.3 with plain stores
+// - the dropped L2 lines cost the next kernel more than the boundary saves - so plain stores are the default.  (An asm
+// store is invisible to hipcc's vmcnt bookkeeping and ends with s_nop 1 so that its data registers are read before the
+// next instruction may overwrite them: cdna_hip_programming.md 5.7.)
+#ifndef DRS_WT_STORES
+#define DRS_WT_STORES 0
+#endif
+__device__ __forceinline__ void drs_store16(void* p, const u32x4& v) {
+#if DRS_WT_STORES
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
+
 // ---- epilogue of RPW rows x NT channel tiles held in MFMA layout ---------------------------------------------------
 // Lane (lr, kg) holds channels t*16 + kg*4 .. +3 of pixel lr for every n-tile t.  Pairs of n-tiles are exchanged
 // between lanes lr and lr^8 (one DPP row rotate) so that each store instruction covers 8 pixels x 32 channels =
@@ -186,7 +203,7 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
         char* g = reinterpret_cast<char*>(base) + (opix * cs + co) * 4 + (lo ? 0 : 64) + kg * 16;
         // pass 0: lanes lr < 8 own the pixel (own hi), lanes lr >= 8 store the received lo of pixel lr - 8;
         // pass 1: lanes lr < 8 store the received hi of pixel lr + 8, lanes lr >= 8 own the pixel (own lo)
-        *reinterpret_cast<u32x4*>(g) = (h == 0) ? (lo ? H : got) : (lo ? got : L);
+        drs_store16(g, (h == 0) ? (lo ? H : got) : (lo ? got : L));
       }
     }
   };
@@ -304,8 +321,8 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
         u32x4 H, L;
         drs_sp_split8(w8, H, L);
         const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo
-        if (ok0) *reinterpret_cast<u32x4*>(g) = lo ? H : got;
-        if (ok1) *reinterpret_cast<u32x4*>(g + hb) = lo ? got : L;
+        if (ok0) drs_store16(g, lo ? H : got);
+        if (ok1) drs_store16(g + hb, lo ? got : L);
       };
       if (o1) put(o1 + r * row1, h1, v);
       if constexpr (OUT2) {

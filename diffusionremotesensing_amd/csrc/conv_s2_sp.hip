@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_sp_kernel(TapConv d, int nck, 
         if (tx < d.OW) {
           const size_t opix = ((size_t)n * d.OH + y) * d.OW + tx;
           char* gp = reinterpret_cast<char*>(d.out) + (opix * d.out_cs + d.out_co + n0 + pr * 32) * 4 + (lo ? 0 : 64) + kg * 16;
-          *reinterpret_cast<u32x4*>(gp) = (h == 0) ? (lo ? H : got) : (lo ? got : L);
+          drs_store16(gp, (h == 0) ? (lo ? H : got) : (lo ? got : L));
         }
       }
     }
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void convt_sp_kernel(TapConv d, int nck, un
         for (int h = 0; h < 2; ++h) {
           const size_t opix = orow + 2 * (x0 + pl + 8 * h) + (ph & 1);
           char* gp = reinterpret_cast<char*>(d.out) + (opix * d.out_cs + d.out_co + n0 + pr * 32) * 4 + (lo ? 0 : 64) + kg * 16;
-          *reinterpret_cast<u32x4*>(gp) = (h == 0) ? (lo ? H : got) : (lo ? got : L);
+          drs_store16(gp, (h == 0) ? (lo ? H : got) : (lo ? got : L));
         }
       }
   };

@@ -526,8 +526,8 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
 #ifdef DRS_SP_TIMELINE
                   if (debug & 1) { asm volatile("" :: "v"(H), "v"(L), "v"(got)); return; }
 #endif
-                  if (ok0) *reinterpret_cast<u32x4*>(g) = lo ? H : got;
-                  if (ok1) *reinterpret_cast<u32x4*>(g + (size_t)16 * cs * 4) = lo ? got : L;
+                  if (ok0) drs_store16(g, lo ? H : got);
+                  if (ok1) drs_store16(g + (size_t)16 * cs * 4, lo ? got : L);
                 };
                 if (d.out) put(d.out, d.out_cs, d.out_co, v);
                 if (d.out2) {
