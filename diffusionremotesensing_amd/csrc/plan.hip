@@ -776,9 +776,10 @@ extern "C" void drs_unet_plan_destroy(drs_plan* plan) {
   if (!plan) return;
   if (plan->side) {
     (void)hipStreamSynchronize(plan->side);
-    (void)hipEventDestroy(plan->ev_fork);
-    (void)hipEventDestroy(plan->ev_join);
-    (void)hipEventDestroy(plan->ev_gbias);
+    // (a failing destroy would leave a sticky HIP error for the caller's next runtime call to trip over)
+    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+    if (plan->ev_gbias) (void)hipEventDestroy(plan->ev_gbias);
     (void)hipStreamDestroy(plan->side);
   }
   delete plan;
