@@ -205,7 +205,9 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
   }
   if (threadIdx.x == 0) sB[4 * Ch] = d.b_psi[0];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave-uniform values are marked as such: every address below is a scalar base + one 32-bit lane offset, otherwise the
+  // 64-bit lane addresses of the whole pipeline get computed up front and spill)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lr = lane & 15, kg = lane >> 4;
   const int cg = wave & 3, pb2 = wave >> 2;
   const int ncx = d.Cc / 32;
@@ -214,14 +216,19 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
   const long long nblk16 = (long long)d.N * d.LH * bw;
   const long long nitems = (nblk16 + 3) / 4;
   const int OW = 2 * d.LW, OH = 2 * d.LH;
-  auto wfrag = [&](const void* base, size_t img, int slot) {  // slot = ((chunk * taps + tap) * 4 + kg) * Ch + channel
-    const char* g = reinterpret_cast<const char*>(base) + (size_t)slot * 16;
-    return typename P::Frag{*reinterpret_cast<const bf16x8*>(g), *reinterpret_cast<const bf16x8*>(g + img)};
+  const unsigned lane_w = (unsigned)((kg * Ch + lr) * 16);
+  auto wfrag = [&](const void* base, size_t img, int uslot) {  // uslot (uniform) = (chunk * taps + tap) * 4 * Ch + first channel
+    const char* g = reinterpret_cast<const char*>(base) + (size_t)uslot * 16;
+    return typename P::Frag{*reinterpret_cast<const bf16x8*>(g + lane_w), *reinterpret_cast<const bf16x8*>(g + img + lane_w)};
   };
   auto gslot = [&](int pbl, int cc, int img) { return sG + ((((pbl * NG + cc) * 2 + img) * 4 + kg) * 16 + lr) * 16; };
   for (long long it = blockIdx.x; it < nitems; it += gridDim.x) {
     int nn[2], yy[2], px[2];
     bool valid[2];
+    const char* xrow[2];   // (uniform) x_res row 2 * yy of image nn, channel offset applied
+    const char* grow[2];   // (uniform) stage-input row yy
+    char* orow[2];         // (uniform) output row 2 * yy, this wave's channel group
+    unsigned xoff[2], goff[2], ooff[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const long long q = it * 4 + pb2 * 2 + b;
@@ -232,46 +239,68 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
       const int pr = xb * 16 + lr;
       valid[b] = q < nblk16 && pr < d.LW;
       px[b] = pr < d.LW ? pr : d.LW - 1;
+      xrow[b] = reinterpret_cast<const char*>(d.xres) + ((((size_t)nn[b] * OH + 2 * yy[b]) * OW) * d.r_cs + d.r_co) * 4;
+      grow[b] = reinterpret_cast<const char*>(d.x) + ((((size_t)nn[b] * d.LH + yy[b]) * d.LW) * d.x_cs + d.x_co) * 4;
+      orow[b] = reinterpret_cast<char*>(d.out) + ((((size_t)nn[b] * OH + 2 * yy[b]) * OW) * d.out_cs + d.out_co + cg * 32) * 4;
+      xoff[b] = (unsigned)(2 * px[b] * d.r_cs * 4 + kg * 16);
+      goff[b] = (unsigned)(px[b] * d.x_cs * 4 + kg * 16);
+      ooff[b] = (unsigned)(2 * px[b] * d.out_cs * 4 + kg * 16);
     }
     auto xres_frag = [&](int b, int t, int cc) {
-      const size_t pix = ((size_t)nn[b] * OH + 2 * yy[b] + (t >> 1)) * OW + 2 * px[b] + (t & 1);
-      const char* g = reinterpret_cast<const char*>(d.xres) + (pix * d.r_cs + d.r_co) * 4 + cc * 128 + kg * 16;
-      return typename P::Frag{*reinterpret_cast<const bf16x8*>(g), *reinterpret_cast<const bf16x8*>(g + 64)};
+      const char* g = xrow[b] + (size_t)((t >> 1) * OW + (t & 1)) * d.r_cs * 4 + cc * 128;
+      return typename P::Frag{*reinterpret_cast<const bf16x8*>(g + xoff[b]), *reinterpret_cast<const bf16x8*>(g + xoff[b] + 64)};
     };
-    // ---- gating signal: this wave's 32 channels of g = relu(Wg x + bg) for its two pixel blocks ----
+    // Every operand of this kernel comes straight from L2 / HBM (a wave has 12 MFMAs of work per 4 KB it loads) and a block
+    // has ONE item: the launch is as long as the chain of memory round trips of a wave.  The whole item is therefore one
+    // software pipeline of "steps" (one 32-channel chunk of one operand pair: 2 weight + 2 activation fragments, 32
+    // registers): the loads of step s + 1 are issued before the MFMAs of step s, across the phase boundaries as well, and
+    // the gated result convolution W' x_res runs in the SAME steps as w_x(x_res) on the fragments that one loaded (its
+    // 64 accumulators wait for psi in registers; its weights come with each step: held for the whole item they spill).
+    struct Step { typename P::Frag w[2], a[2], r[2]; };  // r: result weights of the chunk (x_res steps only)
+    Step buf[2];
+    auto load_gate = [&](Step& st, int c) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(d.w_gate, gate_img, c * 4 * Ch + cg * 32 + t * 16);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        st.a[b] = typename P::Frag{*reinterpret_cast<const bf16x8*>(grow[b] + c * 128 + goff[b]),
+                                   *reinterpret_cast<const bf16x8*>(grow[b] + c * 128 + goff[b] + 64)};
+    };
+    auto load_wg = [&](Step& st, int cc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(d.w_wg, wg_img, cc * 4 * Ch + cg * 32 + t * 16);
+    };
+    auto load_x = [&](Step& st, int t4, int cc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(d.w_wx, wx_img, (cc * 4 + t4) * 4 * Ch + cg * 32 + t * 16);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) st.a[b] = xres_frag(b, t4, cc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) st.r[t] = wfrag(d.w_res, wg_img, cc * 4 * Ch + cg * 32 + t * 16);
+    };
     f32x4 acc[2][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-      const char* xg[2];
+    auto mma_step = [&](const Step& st) __attribute__((always_inline)) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
-        xg[b] = reinterpret_cast<const char*>(d.x) + ((((size_t)nn[b] * d.LH + yy[b]) * d.LW + px[b]) * d.x_cs + d.x_co) * 4 + kg * 16;
-      // Every operand of this kernel comes straight from L2 / HBM and a wave has 12 MFMAs of work per 4 KB: what counts is
-      // how many loads are in flight.  Operands are fetched in groups of 2 chunks (8 fragments, 64 registers) issued
-      // back to back; the MFMAs then consume them in issue order (counted waits).
-      for (int c0 = 0; c0 < ncx; c0 += 2) {
-        typename P::Frag wa[2][2], xa[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) wa[i][t] = wfrag(d.w_gate, gate_img, ((c0 + i) * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-            xa[i][b] = typename P::Frag{*reinterpret_cast<const bf16x8*>(xg[b] + (c0 + i) * 128),
-                                        *reinterpret_cast<const bf16x8*>(xg[b] + (c0 + i) * 128 + 64)};
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[i][t], xa[i][b], acc[b][t]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(st.w[t], st.a[b], acc[b][t]);
+    };
+    // ---- gating signal: this wave's 32 channels of g = relu(Wg x + bg) for its two pixel blocks (ncx is even) ----
+    load_gate(buf[0], 0);
+    for (int c0 = 0; c0 < ncx; c0 += 2) {
+      load_gate(buf[1], c0 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(buf[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c0 + 2 < ncx) load_gate(buf[0], c0 + 2);
+      else load_wg(buf[0], 0);  // first step of the next phase (its activations come from LDS)
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(buf[1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     {
 #pragma unroll
@@ -293,48 +322,41 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
       }
     }
     __syncthreads();
-    // ---- p = relu(w_g(g) + w_x(x_res) + biases), this wave's 32 channels ----
+    // ---- p = relu(w_g(g) + w_x(x_res) + biases) and the ungated result W' x_res, this wave's 32 channels ----
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-      typename P::Frag wa[NG][2];
+    f32x4 att[4][2][2];
 #pragma unroll
-      for (int cc = 0; cc < NG; ++cc)
+    for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) wa[cc][t] = wfrag(d.w_wg, wg_img, (cc * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) att[t4][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NG + 4 * NG; ++s) {  // steps 0 .. NG-1: w_g(g); then (pixel t4, chunk cc) of x_res
+      Step& cur = buf[s & 1];
+      Step& nxt = buf[(s + 1) & 1];
+      if (s + 1 < NG) load_wg(nxt, s + 1);
+      else if (s + 1 < 5 * NG) load_x(nxt, (s + 1 - NG) / NG, (s + 1 - NG) % NG);
       __builtin_amdgcn_sched_barrier(0);
+      if (s < NG) {
 #pragma unroll
-      for (int cc = 0; cc < NG; ++cc)
+        for (int b = 0; b < 2; ++b)
+          cur.a[b] = typename P::Frag{*reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, s, 0)),
+                                      *reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, s, 1))};
+        mma_step(cur);
+      } else {
+        const int t4 = (s - NG) / NG;
+        mma_step(cur);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const typename P::Frag gf{*reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, cc, 0)),
-                                    *reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, cc, 1))};
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[cc][t], gf, acc[b][t]);
-        }
+          for (int t = 0; t < 2; ++t) att[t4][b][t] = P::mma(cur.r[t], cur.a[b], att[t4][b][t]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    for (int t4 = 0; t4 < 4; ++t4)
-      for (int c0 = 0; c0 < NG; c0 += 2) {
-        typename P::Frag wa[2][2], xf[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) wa[i][t] = wfrag(d.w_wx, wx_img, (((c0 + i) * 4 + t4) * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
-#pragma unroll
-          for (int b = 0; b < 2; ++b) xf[i][b] = xres_frag(b, t4, c0 + i);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wa[i][t], xf[i][b], acc[b][t]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
     {
       const int ch = cg * 32 + kg * 8;
       float wp[8], bsum[8];
@@ -370,50 +392,24 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
       const float4 b0 = *reinterpret_cast<const float4*>(sB + 3 * Ch + cg * 32 + kg * 8);
       const float4 b1 = *reinterpret_cast<const float4*>(sB + 3 * Ch + cg * 32 + kg * 8 + 4);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      typename P::Frag wr[NG][2];  // the result weights of this wave's channels: the same for all four pixels
 #pragma unroll
-      for (int cc = 0; cc < NG; ++cc)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) wr[cc][t] = wfrag(d.w_res, wg_img, (cc * 4 + kg) * Ch + cg * 32 + t * 16 + lr);
-      for (int t4 = 0; t4 < 4; ++t4) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c0 = 0; c0 < NG; c0 += 2) {
-          typename P::Frag xf[2][2];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) xf[i][b] = xres_frag(b, t4, c0 + i);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-              for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(wr[c0 + i][t], xf[i][b], acc[b][t]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           float v[8];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            v[j] = psi[b] * acc[b][0][j] + bb[j];
-            v[4 + j] = psi[b] * acc[b][1][j] + bb[4 + j];
+            v[j] = psi[b] * att[t4][b][0][j] + bb[j];
+            v[4 + j] = psi[b] * att[t4][b][1][j] + bb[4 + j];
           }
           u32x4 h, l;
           drs_sp_split8(v, h, l);
           if (valid[b]) {
-            const size_t pix = ((size_t)nn[b] * OH + 2 * yy[b] + (t4 >> 1)) * OW + 2 * px[b] + (t4 & 1);
-            char* o = reinterpret_cast<char*>(d.out) + (pix * d.out_cs + d.out_co + cg * 32) * 4 + kg * 16;
+            char* o = orow[b] + (size_t)((t4 >> 1) * OW + (t4 & 1)) * d.out_cs * 4 + ooff[b];
             drs_store16(o, h);
             drs_store16(o + 64, l);
           }
         }
-      }
     }
     __syncthreads();  // sG / sPsi are rewritten by the next item
   }
@@ -472,7 +468,7 @@ size_t drs_attn_gate_lds_bytes(int Cc, int Ch) {
 bool drs_attn_gate_supported(int Cc, int Ch) {
   static const bool env = !(getenv("DRS_FUSE_GATE") && atoi(getenv("DRS_FUSE_GATE")) == 0);
   if (!env) return false;
-  if (Ch == 128) return Cc % 32 == 0;  // wide variant: weights streamed from L2
+  if (Ch == 128) return Cc % 64 == 0;  // wide variant: weights streamed from L2, two input chunks per pipeline turn
   return (Ch == 32 || Ch == 64) && Cc % 64 == 0 && drs_attn_gate_lds_bytes(Cc, Ch) <= 160 * 1024;
 }
 
