@@ -191,6 +191,7 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
 // [32 * (w & 3), + 32) of pixel blocks {2 * (w >> 2), + 1}.  Weight fragments come straight from global memory (every CU reads the
 // same 0.5 MB: L2-resident; the two waves of a channel group share them through L1), activations as above; the gating
 // signal crosses the channel groups through a 32 KB LDS image in operand-slot order, the psi partial sums through 1 KB.
+template <int NCX>  // 32-channel chunks of the stage input (compile time: the whole item is one unrolled pipeline)
 __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) {
   using P = PolicyBF16X3;
   constexpr int Ch = 128, NG = 4;
@@ -210,25 +211,37 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lr = lane & 15, kg = lane >> 4;
   const int cg = wave & 3, pb2 = wave >> 2;
-  const int ncx = d.Cc / 32;
+  constexpr int ncx = NCX;
   const size_t gate_img = (size_t)ncx * 4 * Ch * 16, wg_img = (size_t)NG * 4 * Ch * 16, wx_img = (size_t)NG * 16 * Ch * 16;
   const int bw = (d.LW + 15) / 16;
   const long long nblk16 = (long long)d.N * d.LH * bw;
   const long long nitems = (nblk16 + 3) / 4;
   const int OW = 2 * d.LW, OH = 2 * d.LH;
   const unsigned lane_w = (unsigned)((kg * Ch + lr) * 16);
-  auto wfrag = [&](const void* base, size_t img, int uslot) {  // uslot (uniform) = (chunk * taps + tap) * 4 * Ch + first channel
-    const char* g = reinterpret_cast<const char*>(base) + (size_t)uslot * 16;
-    return typename P::Frag{*reinterpret_cast<const bf16x8*>(g + lane_w), *reinterpret_cast<const bf16x8*>(g + img + lane_w)};
+  // Addressing: every load is  scalar base (opaque copy, global address space) + ONE 32-bit lane offset.  Left to itself
+  // the compiler re-associates base + lane + constant into a 64-bit lane address (or a scalar pair) PER FRAGMENT, hoists
+  // all of them out of the item loop and spills them; and behind a plain asm copy it no longer sees the address space: a
+  // flat load counts on the LDS counter as well, which turns every counted wait into a full drain.
+  typedef const __attribute__((address_space(1))) char* gptr;
+  typedef const __attribute__((address_space(1))) bf16x8* gfrag;
+  auto uni = [](const void* q) __attribute__((always_inline)) {
+    gptr g = (gptr)q;
+    asm volatile("" : "+s"(g));
+    return g;
+  };
+  const gptr gw_gate = uni(d.w_gate), gw_wg = uni(d.w_wg), gw_wx = uni(d.w_wx), gw_res = uni(d.w_res);
+  // (lw: the step's opaque copy of lane_w, or lane_w + constant is loop-invariant for every fragment: ~100 hoisted registers)
+  auto wfrag = [&](gptr base, size_t img, int uslot, unsigned lw) {  // uslot (uniform) = (chunk * taps + tap) * 4 * Ch + first channel
+    const unsigned o = lw + (unsigned)uslot * 16u;
+    return typename P::Frag{*(gfrag)(base + o), *(gfrag)(base + (o + (unsigned)img))};
   };
   auto gslot = [&](int pbl, int cc, int img) { return sG + ((((pbl * NG + cc) * 2 + img) * 4 + kg) * 16 + lr) * 16; };
   for (long long it = blockIdx.x; it < nitems; it += gridDim.x) {
     int nn[2], yy[2], px[2];
     bool valid[2];
-    const char* xrow[2];   // (uniform) x_res row 2 * yy of image nn, channel offset applied
-    const char* grow[2];   // (uniform) stage-input row yy
-    char* orow[2];         // (uniform) output row 2 * yy, this wave's channel group
-    unsigned xoff[2], goff[2], ooff[2];
+    gptr xrow[2], grow[2];  // (uniform) x_res row 2 * yy of image nn, stage-input row yy: channel offsets applied
+    char* orow[2];          // (uniform) output row 2 * yy, this wave's channel group
+    unsigned xoff[2][4], goff[2], ooff[2];  // lane offsets: the four x_res pixels under the lane's pixel, its input pixel
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const long long q = it * 4 + pb2 * 2 + b;
@@ -239,16 +252,16 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
       const int pr = xb * 16 + lr;
       valid[b] = q < nblk16 && pr < d.LW;
       px[b] = pr < d.LW ? pr : d.LW - 1;
-      xrow[b] = reinterpret_cast<const char*>(d.xres) + ((((size_t)nn[b] * OH + 2 * yy[b]) * OW) * d.r_cs + d.r_co) * 4;
-      grow[b] = reinterpret_cast<const char*>(d.x) + ((((size_t)nn[b] * d.LH + yy[b]) * d.LW) * d.x_cs + d.x_co) * 4;
+      xrow[b] = uni(reinterpret_cast<const char*>(d.xres) + ((((size_t)nn[b] * OH + 2 * yy[b]) * OW) * d.r_cs + d.r_co) * 4);
+      grow[b] = uni(reinterpret_cast<const char*>(d.x) + ((((size_t)nn[b] * d.LH + yy[b]) * d.LW) * d.x_cs + d.x_co) * 4);
       orow[b] = reinterpret_cast<char*>(d.out) + ((((size_t)nn[b] * OH + 2 * yy[b]) * OW) * d.out_cs + d.out_co + cg * 32) * 4;
-      xoff[b] = (unsigned)(2 * px[b] * d.r_cs * 4 + kg * 16);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xoff[b][t] = (unsigned)(((t >> 1) * OW + 2 * px[b] + (t & 1)) * d.r_cs * 4 + kg * 16);
       goff[b] = (unsigned)(px[b] * d.x_cs * 4 + kg * 16);
       ooff[b] = (unsigned)(2 * px[b] * d.out_cs * 4 + kg * 16);
     }
     auto xres_frag = [&](int b, int t, int cc) {
-      const char* g = xrow[b] + (size_t)((t >> 1) * OW + (t & 1)) * d.r_cs * 4 + cc * 128;
-      return typename P::Frag{*reinterpret_cast<const bf16x8*>(g + xoff[b]), *reinterpret_cast<const bf16x8*>(g + xoff[b] + 64)};
+      return typename P::Frag{*(gfrag)(xrow[b] + (xoff[b][t] + (unsigned)(cc * 128))), *(gfrag)(xrow[b] + (xoff[b][t] + (unsigned)(cc * 128 + 64)))};
     };
     // Every operand of this kernel comes straight from L2 / HBM (a wave has 12 MFMAs of work per 4 KB it loads) and a block
     // has ONE item: the launch is as long as the chain of memory round trips of a wave.  The whole item is therefore one
@@ -258,25 +271,30 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
     // 64 accumulators wait for psi in registers; its weights come with each step: held for the whole item they spill).
     struct Step { typename P::Frag w[2], a[2], r[2]; };  // r: result weights of the chunk (x_res steps only)
     Step buf[2];
+    auto opaque = [](unsigned v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
     auto load_gate = [&](Step& st, int c) __attribute__((always_inline)) {
+      const unsigned lw = opaque(lane_w);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(d.w_gate, gate_img, c * 4 * Ch + cg * 32 + t * 16);
+      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(gw_gate, gate_img, c * 4 * Ch + cg * 32 + t * 16, lw);
 #pragma unroll
       for (int b = 0; b < 2; ++b)
-        st.a[b] = typename P::Frag{*reinterpret_cast<const bf16x8*>(grow[b] + c * 128 + goff[b]),
-                                   *reinterpret_cast<const bf16x8*>(grow[b] + c * 128 + goff[b] + 64)};
+      {
+        st.a[b] = typename P::Frag{*(gfrag)(grow[b] + (goff[b] + (unsigned)(c * 128))), *(gfrag)(grow[b] + (goff[b] + (unsigned)(c * 128 + 64)))};
+      }
     };
     auto load_wg = [&](Step& st, int cc) __attribute__((always_inline)) {
+      const unsigned lw = opaque(lane_w);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(d.w_wg, wg_img, cc * 4 * Ch + cg * 32 + t * 16);
+      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(gw_wg, wg_img, cc * 4 * Ch + cg * 32 + t * 16, lw);
     };
     auto load_x = [&](Step& st, int t4, int cc) __attribute__((always_inline)) {
+      const unsigned lw = opaque(lane_w);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(d.w_wx, wx_img, (cc * 4 + t4) * 4 * Ch + cg * 32 + t * 16);
+      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(gw_wx, wx_img, (cc * 4 + t4) * 4 * Ch + cg * 32 + t * 16, lw);
 #pragma unroll
       for (int b = 0; b < 2; ++b) st.a[b] = xres_frag(b, t4, cc);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) st.r[t] = wfrag(d.w_res, wg_img, cc * 4 * Ch + cg * 32 + t * 16);
+      for (int t = 0; t < 2; ++t) st.r[t] = wfrag(gw_res, wg_img, cc * 4 * Ch + cg * 32 + t * 16, lw);
     };
     f32x4 acc[2][2];
 #pragma unroll
@@ -289,26 +307,32 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(st.w[t], st.a[b], acc[b][t]);
     };
-    // ---- gating signal: this wave's 32 channels of g = relu(Wg x + bg) for its two pixel blocks (ncx is even) ----
+    // ---- gating signal: this wave's 32 channels of g = relu(Wg x + bg) for its two pixel blocks ----
+    // (its bias first: the oldest loads of the item, long landed when the phase ends.  Both candidates are global: a
+    // pointer that may be global or LDS makes the loads flat, and a flat load waits for everything in flight)
+    float gbias[2][8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float* bsrc = (d.b_gate_img ? d.b_gate_img + (size_t)nn[b] * Ch : d.b_gate) + cg * 32 + kg * 8;
+      const float4 b0 = *reinterpret_cast<const float4*>(bsrc);
+      const float4 b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+      gbias[b][0] = b0.x; gbias[b][1] = b0.y; gbias[b][2] = b0.z; gbias[b][3] = b0.w;
+      gbias[b][4] = b1.x; gbias[b][5] = b1.y; gbias[b][6] = b1.z; gbias[b][7] = b1.w;
+    }
     load_gate(buf[0], 0);
-    for (int c0 = 0; c0 < ncx; c0 += 2) {
-      load_gate(buf[1], c0 + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < ncx; ++c) {
+      if (c + 1 < ncx) load_gate(buf[(c + 1) & 1], c + 1);
+      else load_wg(buf[(c + 1) & 1], 0);  // first step of the next phase (its activations come from LDS)
       __builtin_amdgcn_sched_barrier(0);
-      mma_step(buf[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c0 + 2 < ncx) load_gate(buf[0], c0 + 2);
-      else load_wg(buf[0], 0);  // first step of the next phase (its activations come from LDS)
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(buf[1]);
+      mma_step(buf[c & 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
     {
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const float* bsrc = d.b_gate_img ? d.b_gate_img + (size_t)nn[b] * Ch + cg * 32 + kg * 8 : sB + cg * 32 + kg * 8;
-        const float4 b0 = *reinterpret_cast<const float4*>(bsrc);
-        const float4 b1 = *reinterpret_cast<const float4*>(bsrc + 4);
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float* bb = gbias[b];
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -336,8 +360,8 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
         for (int t = 0; t < 2; ++t) att[t4][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NG + 4 * NG; ++s) {  // steps 0 .. NG-1: w_g(g); then (pixel t4, chunk cc) of x_res
-      Step& cur = buf[s & 1];
-      Step& nxt = buf[(s + 1) & 1];
+      Step& cur = buf[(ncx + s) & 1];
+      Step& nxt = buf[(ncx + s + 1) & 1];
       if (s + 1 < NG) load_wg(nxt, s + 1);
       else if (s + 1 < 5 * NG) load_x(nxt, (s + 1 - NG) / NG, (s + 1 - NG) % NG);
       __builtin_amdgcn_sched_barrier(0);
@@ -468,7 +492,7 @@ size_t drs_attn_gate_lds_bytes(int Cc, int Ch) {
 bool drs_attn_gate_supported(int Cc, int Ch) {
   static const bool env = !(getenv("DRS_FUSE_GATE") && atoi(getenv("DRS_FUSE_GATE")) == 0);
   if (!env) return false;
-  if (Ch == 128) return Cc % 64 == 0;  // wide variant: weights streamed from L2, two input chunks per pipeline turn
+  if (Ch == 128) return Cc == 256 || Cc == 128;  // wide variant: weights streamed from L2, pipeline unrolled over the input chunks
   return (Ch == 32 || Ch == 64) && Cc % 64 == 0 && drs_attn_gate_lds_bytes(Cc, Ch) <= 160 * 1024;
 }
 
@@ -480,11 +504,12 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
   if ((long long)d.N * d.LH * d.LW == 0) return DRS_OK;
   if (d.Ch == 128) {
     int num_cu = 0;
-    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(attn_gate_wide_kernel), 0, &num_cu);
+    auto kern = d.Cc == 256 ? attn_gate_wide_kernel<8> : attn_gate_wide_kernel<4>;
+    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 0, &num_cu);
     if (rc) return rc;
     const long long nitems = ((long long)d.N * d.LH * ((d.LW + 15) / 16) + 3) / 4;
     const long long blocks = nitems < 4LL * num_cu ? nitems : 4LL * num_cu;
-    hipLaunchKernelGGL(attn_gate_wide_kernel, dim3((unsigned)blocks), dim3(512), 0, s, d);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, s, d);
     DRS_CHECK_HIP(hipGetLastError());
     return DRS_OK;
   }

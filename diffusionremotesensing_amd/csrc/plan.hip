@@ -418,6 +418,7 @@ struct drs_plan {
   // second stream of the eval forward: the attention branch of a decoder stage runs next to the up-sampling branch
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gbias = nullptr;
+  hipEvent_t ev_edge_in[3] = {nullptr, nullptr, nullptr}, ev_edge_out[3] = {nullptr, nullptr, nullptr};  // edge vectors of a composite stage: side stream
 
   int P(const std::string& name, int64_t numel) {
     params.push_back({name, numel});
@@ -780,6 +781,10 @@ extern "C" void drs_unet_plan_destroy(drs_plan* plan) {
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
     if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
     if (plan->ev_gbias) (void)hipEventDestroy(plan->ev_gbias);
+    for (int i = 0; i < 3; ++i) {
+      if (plan->ev_edge_in[i]) (void)hipEventDestroy(plan->ev_edge_in[i]);
+      if (plan->ev_edge_out[i]) (void)hipEventDestroy(plan->ev_edge_out[i]);
+    }
     (void)hipStreamDestroy(plan->side);
   }
   delete plan;
@@ -1008,6 +1013,10 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
     DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
     DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_gbias, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+      DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_edge_in[i], hipEventDisableTiming));
+      DRS_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_edge_out[i], hipEventDisableTiming));
+    }
   }
 
   // --- time embeddings for the 7 blocks (reference :338-339 + every time_mlp) ---
@@ -1194,6 +1203,8 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       if (concurrent) d.shared_cu = 1;
       return plan_conv(plan, L, d, sa);
     };
+    auto attention_branch = [&]() -> int {
+      int rc = DRS_OK;
     const bool fuse_gate = st.fused_gate && !(c.flags & DRS_PLAN_KEEP_ALL);
     if (fuse_gate) {
       // gating signal + attention gate in ONE launch (attn_gate_sp.hip): g, g1, p and psi never reach HBM
@@ -1257,6 +1268,10 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       if (concurrent) DRS_CHECK_HIP(hipEventRecord(plan->ev_join, sa));
     }
     }  // !fuse_gate
+      return rc;
+    };
+    auto upconv_block = [&]() -> int {
+      int rc = DRS_OK;
     {  // UpConvBlock: relu(BN(conv(x + relu(time_mlp(t)))))   (:199-205)
       TapConv d = conv_desc(xcur, B, lh, lw, Cc, Cc, 0, PW(st.conv), PB(st.conv), TP(plan->t_U[i]), Cc, Cc, 0, 3, 3, 1,
                             1);
@@ -1269,6 +1284,23 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       }
       d.shared_cu = concurrent ? 1 : 0;
       RUN(conv_bn(st.conv, d));
+    }
+      return rc;
+    };
+    // Order inside a stage.  A composite stage whose plan owns a side stream computes its edge vectors THERE, next to
+    // the attention gate: they only need ups.i.conv's output, are three tiny launches' worth of latency (35 us per
+    // forward on the main stream) and occupy a fraction of the CUs.  So: UpConvBlock conv, [edges || gate], att-half,
+    // composite.  Everything else keeps the reference's order (gate first).
+    static const int edges_env = getenv("DRS_EDGES_ASIDE") ? atoi(getenv("DRS_EDGES_ASIDE")) : 1;
+    const bool edges_aside = st.upfuse && mlp_side && !concurrent && edges_env != 0;
+    if (edges_aside) {
+      RUN(upconv_block());
+      DRS_CHECK_HIP(hipEventRecord(plan->ev_edge_in[i], s));
+      DRS_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_edge_in[i], 0));
+      RUN(attention_branch());
+    } else {
+      RUN(attention_branch());
+      RUN(upconv_block());
     }
     if (st.upfuse) {
       // ups.i.transform and the x-half of up_convs.i as ONE stride-2 transposed convolution of ups.i.conv's output
@@ -1289,9 +1321,10 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         e.wimg = pk + st.uf_edge_off; e.zero_line = zero_line;
         const double epix = (double)B * 2.0 * (lh + lw);
         prof_begin(plan, "up_convs." + std::to_string(i) + ".edges", 2.0 * epix * 2.5 * Cc * Ch, 4.0 * epix * (Cc + 4.0 * Ch), s);
-        rc = drs_launch_upfuse_edges(e, s);
+        rc = drs_launch_upfuse_edges(e, edges_aside ? plan->side : s);
         prof_end(plan, s);
         if (rc) return rc;
+        if (edges_aside) DRS_CHECK_HIP(hipEventRecord(plan->ev_edge_out[i], plan->side));
       }
       if (concurrent) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));  // the attention half of cat.i is complete
       {
@@ -1334,6 +1367,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
           u.out2 = TP(plan->t_XT[i + 1]); u.out2_cs = Ch; u.out2_co = 0;  // x + temb of the next stage's UpConvBlock
           u.post2 = temb + plan->dec[i + 1].mlp.temb_off; u.post2_cs = plan->temb_total;
         }
+        if (edges_aside) DRS_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_edge_out[i], 0));
         const double opix = (double)B * 4.0 * lh * lw;
         // executed work: 6.25 composite taps per output pixel; bytes: h + att-half partial sums + result (+ weights)
         prof_begin(plan, "up_convs." + std::to_string(i) + ".fused", 2.0 * opix * 6.25 * Cc * Ch,
