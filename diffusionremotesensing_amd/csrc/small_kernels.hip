@@ -2,6 +2,9 @@
 // changes at the boundary, the 3-channel planar convolutions of the LR encoder, the stem,
 // bicubic up-sampling, the fused time-embedding MLP and the diffusion element-wise updates.
 #include "drs_common.h"
+#include <algorithm>
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
 // Weight packing.  Folds an eval-mode BatchNorm (reference nn.BatchNorm2d, eps 1e-5:
@@ -226,74 +229,146 @@ int drs_launch_conv3x3_planar(const float* in, const float* w, const float* b, c
 // optional channels-last residual (the cached LR-conditioning term, broadcast over the batch when it
 // has batch 1).  conv0 and conv_upsampled_lr_img of the reference (:342,:353-355).
 // ---------------------------------------------------------------------------------------------
+// A wave owns 64 consecutive pixels of kStemRows consecutive rows (a lane = one column, one accumulator set per row): the
+// 27 x 16 weights are read from LDS once per column (broadcast reads were the kernel's largest cost at one pixel per lane)
+// and the (rows + 2) x 3 input values of a channel serve all rows.  A pixel's 64 output bytes (16 fp32, or 16 bf16 hi | 16 bf16
+// lo) and its 64 residual bytes cross a 4 KB per-wave LDS image, so every global load / store instruction of the
+// channels-last tensors covers 1 KB of CONSECUTIVE bytes (16 bytes per lane at a 64-byte stride touches each line four
+// times).
+#ifndef DRS_STEM_ROWS
+#define DRS_STEM_ROWS 4
+#define DRS_STEM_BPC 2
+#endif
+constexpr int kStemRows = DRS_STEM_ROWS;  // rows per lane
+__device__ __attribute__((aligned(16))) float stem_zero_line[4];  // (zero-initialised, never written)
 template <int COUT>
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
+__global__ __launch_bounds__(256, DRS_STEM_BPC) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ b, const float* __restrict__ res,
                                                    int res_batch, float* __restrict__ out, int N, int Cin, int H,
                                                    int W, int out_sp) {
-  __shared__ float sw[COUT * 4 * 9 + COUT];  // [tap][ci][co] + bias
+  static_assert(COUT == 16, "a pixel is 64 bytes in both output formats");
+  constexpr int R = kStemRows;
+  __shared__ __attribute__((aligned(16))) float sw[COUT * 4 * 9 + COUT];  // [tap][ci][co] + bias
+  __shared__ __attribute__((aligned(16))) char sT[4][64 * 64];            // per wave: 64 pixels x 64 bytes
   for (int i = threadIdx.x; i < COUT * Cin * 9; i += blockDim.x) {
     const int co = i / (Cin * 9), r = i % (Cin * 9), ci = r / 9, tap = r % 9;
     sw[(tap * Cin + ci) * COUT + co] = w[i];
   }
   if (threadIdx.x < COUT) sw[COUT * 4 * 9 + threadIdx.x] = b[threadIdx.x];
   __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* tb = sT[wave];
   const int64_t hw = (int64_t)H * W;
-  const int64_t total = (int64_t)N * hw;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
-    const int x = (int)(p % W);
-    const int y = (int)((p / W) % H);
-    const int n = (int)(p / hw);
-    float acc[COUT];
+  const int xbs = (W + 63) / 64, ygs = (H + R - 1) / R;
+  const int units = N * ygs * xbs;  // (the launcher checks that this fits 31 bits)
+  for (int u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
+    const int xb = u % xbs, yg = (u / xbs) % ygs, n = u / (xbs * ygs);
+    const int x0 = xb * 64, x = x0 + lane, y0 = yg * R;
+    const int npx = min(64, W - x0);  // valid pixels of the segment (wave-uniform)
+    float acc[R][COUT];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = sw[COUT * 4 * 9 + co];
+    for (int o = 0; o < R; ++o)
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[o][co] = sw[COUT * 4 * 9 + co];
+    // residual rows: 4 x 1 KB of consecutive bytes per row, lanes past the segment read the zero word
+    u32x4 rnext[4] = {};
+    auto load_res = [&](int o) __attribute__((always_inline)) {
+      const int y = min(y0 + o, H - 1);
+      const char* rp = reinterpret_cast<const char*>(res + (res_batch == 1 ? ((int64_t)y * W + x0) : ((int64_t)n * H + y) * W + x0) * COUT);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        rnext[j] = *reinterpret_cast<const u32x4*>((j * 1024 + lane * 16 < npx * 64) ? rp + j * 1024 + lane * 16
+                                                                                      : reinterpret_cast<const char*>(stem_zero_line));
+    };
+    if (res) load_res(0);
+#pragma unroll 1
     for (int ci = 0; ci < Cin; ++ci) {
       const float* ip = in + ((int64_t)n * Cin + ci) * hw;
+      float a[R + 2][3];
+      // (zero padding = the address of a zero word: a select on the loaded value makes the compiler load under a branch)
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = y + ky - 1;
-        if (iy < 0 || iy >= H) continue;
+      for (int r = 0; r < R + 2; ++r) {
+        const int iy = y0 - 1 + r;
+        const bool yok = iy >= 0 && iy < H;
+        const float* rowp = ip + (int64_t)iy * W;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const int ix = x + kx - 1;
-          if (ix < 0 || ix >= W) continue;
-          const float a = ip[(int64_t)iy * W + ix];
+          const int ix = x - 1 + kx;
+          a[r][kx] = *((yok && ix >= 0 && ix < W) ? rowp + ix : stem_zero_line);
+        }
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
           const float* wr = &sw[((ky * 3 + kx) * Cin + ci) * COUT];
+          float wv[COUT];
 #pragma unroll
-          for (int co = 0; co < COUT; ++co) acc[co] = fmaf(a, wr[co], acc[co]);
+          for (int co = 0; co < COUT; co += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(wr + co);
+            wv[co] = q.x; wv[co + 1] = q.y; wv[co + 2] = q.z; wv[co + 3] = q.w;
+          }
+#pragma unroll
+          for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[o][co] = fmaf(a[o + ky][kx], wv[co], acc[o][co]);
         }
-      }
     }
-    float* op = out + p * COUT;
-    if (res) {
-      const float* rp = res + (res_batch == 1 ? ((int64_t)y * W + x) : p) * COUT;
 #pragma unroll
-      for (int co = 0; co < COUT; ++co) acc[co] += rp[co];
-    }
-    if (out_sp) {  // SP format (drs_common.h): one group of [COUT x bf16 hi | COUT x bf16 lo] per pixel
-      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    for (int o = 0; o < R; ++o) {
+      const int y = y0 + o;
+      if (y >= H) break;  // (wave-uniform)
+      const int64_t p0 = ((int64_t)n * H + y) * W + x0;  // first pixel of the segment
+      if (res) {
+        const u32x4 rv[4] = {rnext[0], rnext[1], rnext[2], rnext[3]};
+        if (o + 1 < R) load_res(o + 1);  // (a row ahead: its latency hides behind this row's conversion and stores)
 #pragma unroll
-      for (int co = 0; co < COUT; co += 8) {
-        bf16x8_t h, l;
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(tb + j * 1024 + lane * 16) = rv[j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          h[j] = (__bf16)acc[co + j];
-          l[j] = (__bf16)(acc[co + j] - (float)h[j]);
+        for (int q = 0; q < 4; ++q) {
+          const float4 r4 = *reinterpret_cast<const float4*>(tb + lane * 64 + q * 16);
+          acc[o][q * 4] += r4.x; acc[o][q * 4 + 1] += r4.y; acc[o][q * 4 + 2] += r4.z; acc[o][q * 4 + 3] += r4.w;
         }
-        *reinterpret_cast<bf16x8_t*>(reinterpret_cast<char*>(op) + co * 2) = h;
-        *reinterpret_cast<bf16x8_t*>(reinterpret_cast<char*>(op) + COUT * 2 + co * 2) = l;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is rewritten below
       }
-    } else {
+      if (out_sp) {  // SP format (drs_common.h): one group of [COUT x bf16 hi | COUT x bf16 lo] per pixel
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #pragma unroll
-    for (int co = 0; co < COUT; co += 4)
-      *reinterpret_cast<float4*>(op + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+        for (int co = 0; co < COUT; co += 8) {
+          bf16x8_t h, l;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            h[j] = (__bf16)acc[o][co + j];
+            l[j] = (__bf16)(acc[o][co + j] - (float)h[j]);
+          }
+          *reinterpret_cast<bf16x8_t*>(tb + lane * 64 + co * 2) = h;
+          *reinterpret_cast<bf16x8_t*>(tb + lane * 64 + COUT * 2 + co * 2) = l;
+        }
+      } else {
+#pragma unroll
+        for (int co = 0; co < COUT; co += 4)
+          *reinterpret_cast<float4*>(tb + lane * 64 + co * 4) = make_float4(acc[o][co], acc[o][co + 1], acc[o][co + 2], acc[o][co + 3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      char* op = reinterpret_cast<char*>(out + p0 * COUT);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(tb + j * 1024 + lane * 16);
+        if (j * 1024 + lane * 16 < npx * 64) *reinterpret_cast<u32x4*>(op + j * 1024 + lane * 16) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next row rewrites the image)
     }
   }
 }
 int drs_launch_stem(const float* in_nchw, const float* w, const float* b, const float* res_nhwc, int res_batch,
                     float* out_nhwc, int N, int Cin, int Cout, int H, int W, hipStream_t s, int out_sp) {
   DRS_REQUIRE(Cout == 16 && Cin >= 1 && Cin <= 4, DRS_ERR_SHAPE, "stem: Cin=%d Cout=%d unsupported", Cin, Cout);
-  hipLaunchKernelGGL(stem_kernel<16>, dim3(ew_blocks((int64_t)N * H * W)), dim3(256), 0, s, in_nchw, w, b, res_nhwc,
+  const int64_t units = (int64_t)N * ((H + kStemRows - 1) / kStemRows) * ((W + 63) / 64);  // a wave per kStemRows rows x 64 columns
+  if (units == 0) return DRS_OK;
+  DRS_REQUIRE(units < (1LL << 31), DRS_ERR_SHAPE, "stem: %lld row segments", (long long)units);
+  const int64_t blocks = std::min<int64_t>((units + 3) / 4, 16384);
+  hipLaunchKernelGGL(stem_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, in_nchw, w, b, res_nhwc,
                      res_batch, out_nhwc, N, Cin, H, W, out_sp);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
