@@ -197,6 +197,22 @@ struct UpFuseDesc {
   const void* zero_line;
   unsigned* fault;
 };
+
+// The first encoder block (16 -> 32 -> 32 channels) as one launch (resblock0_sp.hip): h = relu(conv1(x)) + temb + skip(x)
+// lives in LDS only, out = relu(conv2(h) + shortcut(x)).  All convolutions BatchNorm-folded, operands in the packed
+// layouts of drs_launch_pack_conv_mfma (w1: the 64-channel conv1 | skip pair image of the direct kernel's pair flavour).
+struct ResBlock0Desc {
+  const float* x;                  // block input (SP, 16 channels: 64 bytes per pixel), N x H x W
+  const void* w1; const float* b1; // conv1 | skip: [image 2][tap 9][k-group 4][64] slots, biases [64]
+  const float* temb; int temb_cs;  // relu(time_mlp(t)) rows [N][32], row stride
+  const void* w2; const float* b2; // conv2: [image 2][tap 9][k-group 4][32], bias [32]
+  const void* ws; const float* bs; // 1x1 shortcut: [image 2][k-group 4][32], bias [32]
+  float* out;                      // block output (SP, 32 channels), N x H x W
+  int N, H, W;
+  const void* zero_line;           // >= 64 readable zero bytes
+};
+bool drs_resblock0_supported(int Cin, int Cout, int H, int W);
+int drs_launch_resblock0(const ResBlock0Desc& d, hipStream_t s);
 // edge-term / bias preparation weights (fp32): rt [5][Cc][Ch], rl [6][Cc][Ch], bt [9][Ch]
 struct UpFuseEdgeDesc {
   const float* in; int in_cs, in_co; int N, LH, LW, Cc, Ch;

@@ -1109,6 +1109,31 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       RUN(conv_bn(rb.shortcut, d));
     }
     bool dual = false;
+    // Block 0 (16 -> 32 -> 32 channels at full resolution) as ONE launch: h stays in LDS (resblock0_sp.hip)
+    if (i == 0 && rb.dual && fuse_shortcut && sp && !(c.flags & DRS_PLAN_KEEP_ALL) && c.impl == DRS_IMPL_MFMA_BF16X3 &&
+        drs_resblock0_supported(ci, co, hh, ww)) {
+      ResBlock0Desc r0 = {};
+      r0.x = xin;
+      r0.w1 = pk + rb.dual_w_off; r0.b1 = (const float*)(pk + rb.dual_b_off);
+      r0.temb = temb + rb.mlp.temb_off; r0.temb_cs = plan->temb_total;
+      r0.w2 = PW(rb.conv2); r0.b2 = PB(rb.conv2);
+      r0.ws = PW(rb.shortcut); r0.bs = PB(rb.shortcut);
+      r0.out = TP(plan->t_R[0]);
+      r0.N = B; r0.H = hh; r0.W = ww;
+      r0.zero_line = zero_line;
+      const double px0 = (double)B * hh * ww;
+      prof_begin(plan, "conv_blocks.0.fused", 2.0 * px0 * (2.0 * 9 * ci * co + 9.0 * co * co + (double)ci * co),
+                 4.0 * px0 * (ci + co) + 4.0 * (2.0 * 9 * ci * co + 9.0 * co * co + (double)ci * co), s);
+      rc = drs_launch_resblock0(r0, s);
+      prof_end(plan, s);
+      if (rc) return rc;
+      TapConv d = conv_desc(TP(plan->t_R[0]), B, hh, ww, co, co, 0, PW(plan->downs[0]), PB(plan->downs[0]), TP(plan->t_D[0]), co,
+                            co, 0, 3, 3, 2, 1);
+      d.in_sp = d.out_sp = sp; d.zero_line = zero_line;
+      RUN(plan_conv(plan, plan->downs[0], d, s));
+      xin = TP(plan->t_D[0]);
+      continue;
+    }
     if (rb.dual && !train && !(c.flags & DRS_PLAN_KEEP_ALL)) {
       // h = relu(BN1(conv1(x))) + skip(x) + relu(time_mlp(t)) in ONE launch: the skip tensor never exists in HBM
       TapConv d = conv_desc(xin, B, hh, ww, ci, ci, 0, (const float*)(pk + rb.dual_w_off), (const float*)(pk + rb.dual_b_off),
