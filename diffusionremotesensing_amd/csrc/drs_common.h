@@ -210,6 +210,7 @@ struct ResBlock0Desc {
   float* out;                      // block output (SP, 32 channels), N x H x W
   int N, H, W;
   const void* zero_line;           // >= 64 readable zero bytes
+  unsigned* fault;                 // protocol watchdog word (TapConv::fault), or null
 };
 bool drs_resblock0_supported(int Cin, int Cout, int H, int W);
 int drs_launch_resblock0(const ResBlock0Desc& d, hipStream_t s);

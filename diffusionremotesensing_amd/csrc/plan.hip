@@ -1120,7 +1120,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       r0.ws = PW(rb.shortcut); r0.bs = PB(rb.shortcut);
       r0.out = TP(plan->t_R[0]);
       r0.N = B; r0.H = hh; r0.W = ww;
-      r0.zero_line = zero_line;
+      r0.zero_line = zero_line; r0.fault = plan->fault_ptr;
       const double px0 = (double)B * hh * ww;
       prof_begin(plan, "conv_blocks.0.fused", 2.0 * px0 * (2.0 * 9 * ci * co + 9.0 * co * co + (double)ci * co),
                  4.0 * px0 * (ci + co) + 4.0 * (2.0 * 9 * ci * co + 9.0 * co * co + (double)ci * co), s);

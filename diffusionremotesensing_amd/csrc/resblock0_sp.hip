@@ -4,9 +4,9 @@
 //   out = relu(BN2(conv2(h)) + BNs(shortcut(x)))                    32 -> 32 channels, 3x3 + 1x1
 // Run as two launches (conv3x3_direct_sp.hip: the pair flavour, then conv2 with the shortcut as one more tap) h crosses
 // HBM twice at the highest resolution: 134 MB written and read back of the 600 MB the two launches move, and both run at a
-// third of the MFMA rate.  Here a block owns a 16 x 16 output patch:
-//   phase A  h on the patch's 18 x 18 window (the halo is recomputed: 27 % more conv1 work), 21 MFMA pixel blocks of 16
-//            consecutive window pixels spread over the 8 waves.  Operands come straight from global memory (x is 64 bytes
+// third of the MFMA rate.  Here a GROUP of four waves owns a patch of 8 rows x 16 columns:
+//   phase A  h on the patch's 10 x 18 window (the halo is recomputed: 41 % more conv1 work), 12 MFMA pixel blocks of 16
+//            consecutive window pixels, three per wave.  Operands come straight from global memory (x is 64 bytes
 //            per pixel; a lane gathers the pixel of ITS tap: two taps of 16 channels share the K = 32 of an MFMA, k-groups
 //            0-1 tap 2j, k-groups 2-3 tap 2j + 1, as in the pair flavour of the direct kernel); the result is split into
 //            bf16 hi | lo - the rounding the SP tensor between the two launches had - and written into an LDS window in
@@ -14,33 +14,53 @@
 //            Window pixels outside the image are conv2's zero padding: zeros, not conv1 of padded x.
 //   phase B  conv2 from the LDS window (shifted taps are shifted LDS addresses: no lane shuffles), the 1x1 shortcut of x as
 //            one more tap, ReLU, SP store.  A wave owns two rows of the patch.
-// All weights (41 + 37 + 4 KB) stay in LDS for the lifetime of the persistent block.  Two barriers per patch.
+// All weights (41 + 37 + 4 KB) stay in LDS for the lifetime of the persistent block.  A block is TWO such groups (waves
+// 0-3 and 4-7: waves w and w + 4 share a SIMD) with a window each, synchronised by two LDS counters per group, never by a
+// workgroup barrier, and started half a patch apart: a third of a patch's cycles are epilogues (bias / ReLU / hi | lo split,
+// window and global stores) in which the wave issues no MFMA - measured with all eight waves in lockstep on one 16 x 16
+// patch: 7.2 k of 17.7 k cycles per patch with the matrix pipe idle - and the other group's MFMA phase fills them.
 #include <stdio.h>
 #include <stdlib.h>
 
 #include "conv_epilogue.h"
 #include "mfma_policy.h"
+#include "sp_sync.h"
 
 namespace {
 
-constexpr int TS = 16, IW = TS + 2, NPIX = IW * IW, NBLK_A = (NPIX + 15) / 16;  // 324 window pixels, 21 pixel blocks
+constexpr int TW_ = 16, TH_ = 8, IW = TW_ + 2, IH = TH_ + 2, NPIX = IW * IH, NBLK_A = (NPIX + 15) / 16;  // 180 window pixels, 12 pixel blocks
 constexpr int IMG1 = 5 * 4 * 64 * 16, IMG2 = 36 * 32 * 16, IMGS = 4 * 32 * 16, WIN = NPIX * 128;
 constexpr int NPOST = 64;  // images whose time-embedding rows are staged in LDS (later images read them from memory)
 
+#ifdef DRS_SP_TIMELINE  // tools/build_tl.sh: per-phase s_memtime sums of waves 0 and 7 of block 0
+__device__ unsigned long long drs_rb0_tl[32];
+#define RB_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl[i] += t_ - tl_last; tl_last = t_; } while (0)
+#else
+#define RB_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsigned w1_gimage, unsigned w2_gimage,
-                                                           unsigned ws_gimage) {
+                                                           unsigned ws_gimage, int debug) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   using Frag = typename P::Frag;
+  // The three products of a split-bf16 multiply-accumulate are a dependent chain on one accumulator, and a dependent MFMA
+  // issues a full latency (8 passes) after its predecessor: the chains of a step are emitted ROUND-ROBIN (product m of
+  // every chain, then product m + 1), never chain by chain (measured: 26-31 cycles per MFMA with the compiler's order of
+  // P::mma calls, a wave alone on its SIMD).
+  auto mfma = [](const bf16x8& w, const bf16x8& x, const f32x4& c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
+  };
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, kg = lane >> 4;
   char* sW1 = smem;               // [image 2][tap pair 5][k-group 4][64 channels: conv1 | skip] slots of 16 bytes
   char* sW2 = sW1 + 2 * IMG1;     // [image 2][tap 9][k-group 4][32]
   char* sWs = sW2 + 2 * IMG2;     // [image 2][k-group 4][32]
-  char* sWin = sWs + 2 * IMGS;    // h window: pixel p = py * 18 + px at p * 128, operand slot s at ((s + p) & 7) * 16
-  float* sB1 = reinterpret_cast<float*>(sWin + WIN);  // [64] conv1 | skip biases
+  char* sWinAll = sWs + 2 * IMGS; // two h windows (one per group): pixel p = py * 18 + px at p * 128, operand slot s at ((s + p) & 7) * 16
+  float* sB1 = reinterpret_cast<float*>(sWinAll + 2 * WIN);  // [64] conv1 | skip biases
   float* sB2 = sB1 + 64;                              // [32] conv2 + shortcut bias
-  float* sPost = sB2 + 32;                            // [min(N, NPOST)][32] relu(time_mlp(t)) rows
+  unsigned* sCntRaw = reinterpret_cast<unsigned*>(sB2 + 32);  // [group 2][window written, window read] monotonic counters
+  float* sPost = sB2 + 32 + 4;                        // [min(N, NPOST)][32] relu(time_mlp(t)) rows
   const int npost = min(d.N, NPOST);
   {
     const char* w1 = reinterpret_cast<const char*>(d.w1);
@@ -62,12 +82,16 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
     copy(sWs + IMGS, wsc + ws_gimage, IMGS);
     for (int i = tid; i < 64; i += 512) sB1[i] = d.b1[i];
     for (int i = tid; i < 32; i += 512) sB2[i] = d.b2[i] + d.bs[i];
+    if (tid < 4) sCntRaw[tid] = 0u;
     for (int i = tid; i < npost * 32; i += 512) sPost[i] = d.temb[(size_t)(i >> 5) * d.temb_cs + (i & 31)];
   }
   __syncthreads();
 
   // patches: blocks of an XCD (blockIdx % 8) take a contiguous eighth (neighbouring patches share their halo in that L2)
-  const int gx = d.W / TS, gy = d.H / TS;
+  const int grp = wave >> 2, gw = wave & 3;  // group, wave inside the group
+  char* sWin = sWinAll + grp * WIN;
+  const sp_flag_ptr cWritten = (sp_flag_ptr)(sCntRaw + 2 * grp), cRead = (sp_flag_ptr)(sCntRaw + 2 * grp + 1);
+  const int gx = d.W / TW_, gy = d.H / TH_;
   const int total = d.N * gy * gx;
   const int xcd = blockIdx.x & 7, member = blockIdx.x >> 3, members = gridDim.x >> 3;
   const int t_lo = (int)((long long)total * xcd / 8), t_hi = (int)((long long)total * (xcd + 1) / 8);
@@ -75,64 +99,150 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
   const char* xb = reinterpret_cast<const char*>(d.x);
   // this lane's tap of pair j: k-groups 0-1 multiply tap 2j, k-groups 2-3 tap 2j + 1 (pair 4: tap 8 and zero weights)
   const int kc16 = (kg & 1) * 16;  // byte offset of the lane's 8 channels inside the 32-byte hi (or lo) half of a pixel
-  int tdy[5], tdx[5];
+  constexpr int MAXB = NBLK_A / 4;  // pixel blocks of a wave in phase A: blocks gw, gw + 4, gw + 8
+  static_assert(MAXB * 4 == NBLK_A, "three blocks per wave");
+
+  // this lane's window pixel per phase-A block (image coordinates, linear window index) and the operand gather
+  int wp[MAXB];
+  int tx0 = 0, ty0 = 0, n = 0;
+  const char* ximg = xb;
+  // Interior patches (every pixel of every tap inside the image: 82 % of them at 256 x 256) address their operands as
+  //   scalar base of the patch (pixel (ty0 - 2, tx0 - 2)) + a lane offset that does not depend on the patch
+  // - window pixel and tap are properties of the lane.  The general form (coordinates, four comparisons and two selects
+  // per operand, 15 operands per patch) costs more issue cycles than the MFMAs it feeds.
+  unsigned rel[MAXB], tapoff[5];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int p = min((gw + 4 * b) * 16 + lr, NPIX - 1);
+    const int py = (p * 3641) >> 16, px = p - py * IW;  // p / 18 (exact for p < 1024)
+    wp[b] = p;
+    rel[b] = (unsigned)(((py + 1) * d.W + px + 1) * 64 + kc16);
+  }
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int tap = min(2 * j + (kg >> 1), 8);
-    tdy[j] = tap / 3 - 1; tdx[j] = tap % 3 - 1;
+    tapoff[j] = (unsigned)(((tap / 3 - 1) * d.W + tap % 3 - 1) * 64);  // (wraps; rel + tapoff >= 0)
   }
-  constexpr int MAXB = (NBLK_A + 7) / 8;  // pixel blocks of a wave in phase A: blocks wave, wave + 8, wave + 16
-  const int nblk = wave + 16 < NBLK_A ? 3 : 2;  // (wave-uniform)
-
-  for (int q = t_lo + member; q < t_hi; q += members) {
-    const int tx0 = (q % gx) * TS, ty0 = ((q / gx) % gy) * TS, n = q / (gx * gy);
-    const char* ximg = xb + (size_t)n * d.H * d.W * 64;
-    // ================= phase A: h on the 18 x 18 window =================
-    int wy[MAXB], wx[MAXB], wp[MAXB];  // this lane's window pixel per block: image coordinates, linear window index
-#pragma unroll
-    for (int b = 0; b < MAXB; ++b) {
-      const int p = min((wave + 8 * b) * 16 + lr, NPIX - 1);
-      const int py = (p * 3641) >> 16, px = p - py * IW;  // p / 18 (exact for p < 1024)
-      wp[b] = p; wy[b] = ty0 - 1 + py; wx[b] = tx0 - 1 + px;
+  typedef const __attribute__((address_space(1))) char* gptr;
+  typedef const __attribute__((address_space(1))) bf16x8* gfrag;
+  gptr pbase = (gptr)xb;
+  bool interior = false;
+  auto place = [&](int q) __attribute__((always_inline)) {
+    tx0 = (q % gx) * TW_; ty0 = ((q / gx) % gy) * TH_; n = q / (gx * gy);
+    ximg = xb + (size_t)n * d.H * d.W * 64;
+    interior = ty0 >= 2 && ty0 + TH_ + 2 <= d.H && tx0 >= 2 && tx0 + TW_ + 2 <= d.W;
+#ifdef DRS_SP_TIMELINE
+    if (debug & 4) interior = false;
+#endif
+    {
+      // (opaque scalar copy: the compiler otherwise folds base + lane offset + constant into one 64-bit lane address per load)
+      gptr g = (gptr)(ximg + ((long long)(ty0 - 2) * d.W + (tx0 - 2)) * 64);
+      asm volatile("" : "+s"(g));
+      pbase = g;
     }
-    auto gather = [&](int b, int j) __attribute__((always_inline)) {
-      const int sy = wy[b] + tdy[j], sx = wx[b] + tdx[j];
-      const bool ok = sy >= 0 && sy < d.H && sx >= 0 && sx < d.W;
-      const char* p = ok ? ximg + ((size_t)sy * d.W + sx) * 64 + kc16 : zero;
-      return Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + 32 : zero)};
-    };
+  };
+  // (border patches and the epilogue's zero padding: coordinates from the window index, nothing held across phases)
+  auto win_xy = [&](int b, int& y, int& x) __attribute__((always_inline)) {
+    int p = wp[b];
+    asm volatile("" : "+v"(p));  // (not hoisted out of the patch loop: registers)
+    const int py = (p * 3641) >> 16, px = p - py * IW;
+    y = ty0 - 1 + py; x = tx0 - 1 + px;
+  };
+  auto gather_any = [&](int b, int j) __attribute__((always_inline)) {
+    int y, x;
+    win_xy(b, y, x);
+    int kh = kg >> 1;
+    asm volatile("" : "+v"(kh));
+    const int tap = min(2 * j + kh, 8);
+    const int sy = y + tap / 3 - 1, sx = x + tap % 3 - 1;
+#ifdef DRS_SP_TIMELINE
+    const bool ok = !(debug & 2) && sy >= 0 && sy < d.H && sx >= 0 && sx < d.W;  // (2: every operand from the zero line)
+#else
+    const bool ok = sy >= 0 && sy < d.H && sx >= 0 && sx < d.W;
+#endif
+    const char* p = ok ? ximg + ((size_t)sy * d.W + sx) * 64 + kc16 : zero;
+    return Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + 32 : zero)};
+  };
+  auto gather3 = [&](Frag (&dst)[MAXB], int j) __attribute__((always_inline)) {
+#ifdef DRS_SP_TIMELINE
+    if (debug & 8) {  // no operand loads at all (stale registers): the phase without its memory side
+#pragma unroll
+      for (int b = 0; b < MAXB; ++b) asm volatile("" : "+v"(dst[b].hi), "+v"(dst[b].lo));
+      return;
+    }
+#endif
+    if (interior) {  // (wave-uniform)
+#pragma unroll
+      for (int b = 0; b < MAXB; ++b) {
+        const unsigned o = rel[b] + tapoff[j];
+        dst[b] = Frag{*(gfrag)(pbase + o), *(gfrag)(pbase + (o + 32u))};
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < MAXB; ++b) dst[b] = gather_any(b, j);
+    }
+  };
+  Frag a[2][MAXB];  // operand ring: tap pair j in slot j & 1, fetched one pair ahead (pair 0 a whole phase B ahead)
+  const int q0 = t_lo + 2 * member + grp, qstep = 2 * members;  // the block's two groups take neighbouring patches
+  if (q0 < t_hi) {
+    place(q0);
+    gather3(a[0], 0);
+  }
+#ifdef DRS_SP_TIMELINE
+  unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long tl_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long tl_last = tl_begin, tl_n = 0;
+#endif
+  // the second group starts half a patch late (one MFMA phase): from then on its epilogues meet the first group's MFMA phases
+#ifdef DRS_SP_TIMELINE
+  if ((debug & 1) && grp == 1) return;  // one group alone: uncontended phase times (the output is incomplete)
+#endif
+  if (grp == 1) { __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_s_sleep(32); }
+  unsigned k = 0;  // patches done by this group
+  for (int q = q0; q < t_hi; q += qstep, ++k) {
+#ifdef DRS_SP_TIMELINE
+    ++tl_n;
+#endif
+    RB_STAMP(7);
+    // ================= phase A: h on the 18 x 18 window (the operands of tap pair 0 are already in flight) =================
     f32x4 acc[MAXB][4];
 #pragma unroll
     for (int b = 0; b < MAXB; ++b)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    Frag a[2][MAXB];
-#pragma unroll
-    for (int b = 0; b < MAXB; ++b)
-      if (b < nblk) a[0][b] = gather(b, 0);
+    // (weight fragments one step ahead of their MFMAs: read-wait-multiply exposes the LDS latency 20 times per patch)
     const char* w1lane = sW1 + ((size_t)kg * 64 + lr) * 16;
+    Frag wfa[2];
+    wfa[0] = P::load(w1lane, (size_t)IMG1, 0);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      if (j + 1 < 5) {
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-          if (b < nblk) a[(j + 1) & 1][b] = gather(b, j + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < 5) gather3(a[(j + 1) & 1], j + 1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const Frag wf = P::load(w1lane, (size_t)IMG1, (size_t)(j * 4 * 64 + t * 16) * 16);
+        const int st = j * 4 + t;
+        if (st + 1 < 20) wfa[(st + 1) & 1] = P::load(w1lane, (size_t)IMG1, (size_t)(((st + 1) >> 2) * 4 * 64 + ((st + 1) & 3) * 16) * 16);
+        {
+          const Frag& wf = wfa[st & 1];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-          if (b < nblk) acc[b][t] = P::mma(wf, a[j & 1][b], acc[b][t]);
+          for (int b = 0; b < MAXB; ++b) acc[b][t] = mfma(wf.lo, a[j & 1][b].hi, acc[b][t]);
+#pragma unroll
+          for (int b = 0; b < MAXB; ++b) acc[b][t] = mfma(wf.hi, a[j & 1][b].lo, acc[b][t]);
+#pragma unroll
+          for (int b = 0; b < MAXB; ++b) acc[b][t] = mfma(wf.hi, a[j & 1][b].hi, acc[b][t]);
+        }
+        // (pin the order: the next step's two fragment reads FIRST, then the nine MFMAs - left alone the scheduler sinks the
+        // reads behind the first MFMAs to save registers and the wave waits for the LDS in every step)
+        if (st + 1 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
+    RB_STAMP(0);  // phase A gathers + MFMA
     // the shortcut operand of phase B (the centre pixels of this wave's two rows): in flight across the barriers
     Frag xs[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const char* p = kg < 2 ? ximg + ((size_t)(ty0 + 2 * wave + r) * d.W + tx0 + lr) * 64 + kc16 : zero;
+      const char* p = kg < 2 ? ximg + ((size_t)(ty0 + 2 * gw + r) * d.W + tx0 + lr) * 64 + kc16 : zero;
       xs[r] = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(kg < 2 ? p + 32 : zero)};
     }
     // h = relu(conv1 + b1) + temb[n] + (skip + bs): tiles 0, 1 (conv1) and 2, 3 (skip) of the same lane are the same channels
@@ -151,7 +261,9 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
       bs[0] = s0.x; bs[1] = s0.y; bs[2] = s0.z; bs[3] = s0.w; bs[4] = s1.x; bs[5] = s1.y; bs[6] = s1.z; bs[7] = s1.w;
       te[0] = e0.x; te[1] = e0.y; te[2] = e0.z; te[3] = e0.w; te[4] = e1.x; te[5] = e1.y; te[6] = e1.z; te[7] = e1.w;
     }
-    u32x4 hh[MAXB], hl[MAXB];
+    RB_STAMP(1);  // last MFMAs + epilogue constants
+    sp_poll_lds(cRead, 4u * k, d.fault);  // every wave of the group has the previous patch's window rows in registers
+    RB_STAMP(2);  // wait 1
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
       float v[8];
@@ -160,19 +272,29 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           v[t * 4 + i] = (fmaxf(acc[b][t][i] + bm[t * 4 + i], 0.f) + (acc[b][t + 2][i] + bs[t * 4 + i])) + te[t * 4 + i];  // (the two-launch path's order)
-      drs_sp_split8(v, hh[b], hl[b]);
-      const bool inside = wy[b] >= 0 && wy[b] < d.H && wx[b] >= 0 && wx[b] < d.W;
-      if (!inside) { hh[b] = u32x4{0u, 0u, 0u, 0u}; hl[b] = u32x4{0u, 0u, 0u, 0u}; }
-    }
-    __syncthreads();  // every wave has finished reading the previous patch's window
-#pragma unroll
-    for (int b = 0; b < MAXB; ++b)
-      if (b < nblk && (wave + 8 * b) * 16 + lr < NPIX) {
+      u32x4 hh, hl;
+      drs_sp_split8(v, hh, hl);
+      int y, x;
+      win_xy(b, y, x);
+      const bool inside = y >= 0 && y < d.H && x >= 0 && x < d.W;
+      if (!inside) { hh = u32x4{0u, 0u, 0u, 0u}; hl = u32x4{0u, 0u, 0u, 0u}; }
+      if ((gw + 4 * b) * 16 + lr < NPIX) {
         char* wpix = sWin + wp[b] * 128;
-        *reinterpret_cast<u32x4*>(wpix + ((kg + wp[b]) & 7) * 16) = hh[b];
-        *reinterpret_cast<u32x4*>(wpix + ((4 + kg + wp[b]) & 7) * 16) = hl[b];
+        const int s0 = ((kg + wp[b]) & 7) * 16;
+        *reinterpret_cast<u32x4*>(wpix + s0) = hh;
+        *reinterpret_cast<u32x4*>(wpix + (s0 ^ 64)) = hl;  // slot + 4 (mod 8)
       }
-    __syncthreads();  // the window is complete
+    }
+    sp_release(cWritten, lane);  // (the LDS executes a wave's operations in order: the add lands behind the stores)
+    sp_poll_lds(cWritten, 4u * (k + 1), d.fault);  // the window is complete
+    RB_STAMP(3);  // window stores + wait 2
+    // the next patch's first operands: their latency hides behind phase B
+    const int cty0 = ty0, ctx0 = tx0, cn = n;
+    if (q + qstep < t_hi) {
+      place(q + qstep);
+      gather3(a[0], 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ================= phase B: out = relu(conv2(h) + shortcut(x) + b) on rows 2 * wave, 2 * wave + 1 =================
     f32x4 o[2][2];
 #pragma unroll
@@ -181,32 +303,54 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
       for (int t = 0; t < 2; ++t) o[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const char* w2lane = sW2 + ((size_t)kg * 32 + lr) * 16;
     auto win = [&](int row, int kx) __attribute__((always_inline)) {
-      const int p = (2 * wave + row) * IW + lr + kx;
+      const int p = (2 * gw + row) * IW + lr + kx;
       const char* wpix = sWin + p * 128;
-      return Frag{*reinterpret_cast<const bf16x8*>(wpix + ((kg + p) & 7) * 16), *reinterpret_cast<const bf16x8*>(wpix + ((4 + kg + p) & 7) * 16)};
+      const int s0 = ((kg + p) & 7) * 16;
+      return Frag{*reinterpret_cast<const bf16x8*>(wpix + s0), *reinterpret_cast<const bf16x8*>(wpix + (s0 ^ 64))};
     };
+    // (the four window rows of the wave's two output rows are read once: row r + 1 is tap row ky + 1 of output row r and
+    //  tap row ky of output row r + 1; rows 2 and 3 are fetched under the MFMAs of tap rows 0 and 1: three rows live)
+    Frag wr_[4][3];
+    auto win_row = [&](int row) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const Frag a0 = win(ky, kx), a1 = win(ky + 1, kx);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const Frag wf = P::load(w2lane, (size_t)IMG2, (size_t)((ky * 3 + kx) * 4 * 32 + t * 16) * 16);
-          o[0][t] = P::mma(wf, a0, o[0][t]);
-          o[1][t] = P::mma(wf, a1, o[1][t]);
-        }
-      }
-    }
+      for (int kx = 0; kx < 3; ++kx) wr_[row][kx] = win(row, kx);
+    };
+    win_row(0);
+    win_row(1);
     {
       const char* wslane = sWs + ((size_t)kg * 32 + lr) * 16;
+      Frag wfb[2][2];  // [step parity][channel tile]
+      wfb[0][0] = P::load(w2lane, (size_t)IMG2, 0);
+      wfb[0][1] = P::load(w2lane, (size_t)IMG2, (size_t)16 * 16);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const Frag wf = P::load(wslane, (size_t)IMGS, (size_t)(t * 16) * 16);
-        o[0][t] = P::mma(wf, xs[0], o[0][t]);
-        o[1][t] = P::mma(wf, xs[1], o[1][t]);
+      for (int st = 0; st < 10; ++st) {  // steps: the nine taps of conv2, then the shortcut; four accumulator chains each
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (st + 1 < 9) wfb[(st + 1) & 1][t] = P::load(w2lane, (size_t)IMG2, (size_t)((st + 1) * 4 * 32 + t * 16) * 16);
+          else if (st + 1 < 10) wfb[(st + 1) & 1][t] = P::load(wslane, (size_t)IMGS, (size_t)(t * 16) * 16);
+        }
+        if (st == 0) win_row(2);
+        if (st == 3) {
+          win_row(3);
+          sp_release(cRead, lane);  // (behind the reads, in order: the next window may be written once all four waves are here)
+        }
+        const int ky = st < 9 ? st / 3 : 0, kx = st < 9 ? st % 3 : 0;
+        const Frag& x0f = st < 9 ? wr_[ky][kx] : xs[0];
+        const Frag& x1f = st < 9 ? wr_[ky + 1][kx] : xs[1];
+        const Frag (&wf)[2] = wfb[st & 1];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { o[0][t] = mfma(wf[t].lo, x0f.hi, o[0][t]); o[1][t] = mfma(wf[t].lo, x1f.hi, o[1][t]); }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { o[0][t] = mfma(wf[t].hi, x0f.lo, o[0][t]); o[1][t] = mfma(wf[t].hi, x1f.lo, o[1][t]); }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { o[0][t] = mfma(wf[t].hi, x0f.hi, o[0][t]); o[1][t] = mfma(wf[t].hi, x1f.hi, o[1][t]); }
+        if (st == 0 || st == 3) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // next weights + a window row
+        else if (st + 1 < 10) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // next weights
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    RB_STAMP(4);  // next gathers issued, window reads, phase B MFMA (incl. the shortcut)
     {
       SpEpiConst kc;
       const float4 b0 = *reinterpret_cast<const float4*>(sB2 + kg * 8), b1 = *reinterpret_cast<const float4*>(sB2 + kg * 8 + 4);
@@ -218,19 +362,28 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
       de.out = d.out; de.out_cs = 32; de.out_co = 0;
       de.OH = d.H; de.OW = d.W; de.TH = d.H; de.TW = d.W;
       de.relu_post = 1;
-      tile_epilogue_sp_pre<2, false>(de, o, kc, n, 0, ty0, tx0, wave, lr, kg);
+      tile_epilogue_sp_pre<2, false>(de, o, kc, cn, 0, cty0, ctx0, gw, lr, kg);
     }
+    RB_STAMP(5);  // shortcut MFMA + epilogue B
   }
+#ifdef DRS_SP_TIMELINE
+  if (blockIdx.x == 0 && (wave == 0 || wave == 7) && lane == 0) {
+    const int o = wave == 0 ? 0 : 16;
+    for (int i = 0; i < 8; ++i) drs_rb0_tl[o + i] = tl[i];
+    drs_rb0_tl[o + 8] = tl_n;
+    drs_rb0_tl[o + 9] = __builtin_amdgcn_s_memtime() - tl_begin;
+  }
+#endif
 }
 
-size_t resblock0_lds(int N) { return (size_t)2 * (IMG1 + IMG2 + IMGS) + WIN + (size_t)(64 + 32 + 32 * (N < NPOST ? N : NPOST)) * 4; }
+size_t resblock0_lds(int N) { return (size_t)2 * (IMG1 + IMG2 + IMGS) + 2 * WIN + (size_t)(64 + 32 + 4 + 32 * (N < NPOST ? N : NPOST)) * 4; }
 
 }  // namespace
 
 // Shape gate: the 16 -> 32 -> 32 block on images that split into 16 x 16 patches.  DRS_RB0=0 keeps the two launches.
 bool drs_resblock0_supported(int Cin, int Cout, int H, int W) {
   static const bool env = !(getenv("DRS_RB0") && atoi(getenv("DRS_RB0")) == 0);
-  return env && Cin == 16 && Cout == 32 && H >= 32 && W >= 32 && H % TS == 0 && W % TS == 0;
+  return env && Cin == 16 && Cout == 32 && H >= 32 && W >= 32 && H % TH_ == 0 && W % TW_ == 0;
 }
 
 int drs_launch_resblock0(const ResBlock0Desc& d, hipStream_t s) {
@@ -245,7 +398,30 @@ int drs_launch_resblock0(const ResBlock0Desc& d, hipStream_t s) {
   // global operand images (drs_launch_pack_conv_mfma): [chunk 1][tap][k-group 4][channels] slots, one image per bf16 half
   const unsigned w1_gimage = 9u * 4u * 64u * 16u, w2_gimage = 9u * 4u * 32u * 16u, ws_gimage = 4u * 32u * 16u;
   const int blocks = num_cu / 8 * 8;  // one block per CU
-  hipLaunchKernelGGL(resblock0_kernel, dim3((unsigned)blocks), dim3(512), resblock0_lds(d.N), s, d, w1_gimage, w2_gimage, ws_gimage);
+  hipLaunchKernelGGL(resblock0_kernel, dim3((unsigned)blocks), dim3(512), resblock0_lds(d.N), s, d, w1_gimage, w2_gimage, ws_gimage, 0);
   DRS_CHECK_HIP(hipGetLastError());
+#ifdef DRS_SP_TIMELINE
+  {
+    unsigned long long h[32];
+    const int dbg = getenv("DRS_RB0_DEBUG") ? atoi(getenv("DRS_RB0_DEBUG")) : 0;
+    hipEvent_t e0, e1;
+    float ms = 0.f;
+    DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
+    DRS_CHECK_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(resblock0_kernel, dim3((unsigned)blocks), dim3(512), resblock0_lds(d.N), s, d, w1_gimage, w2_gimage, ws_gimage, dbg);  // timed repeat
+    DRS_CHECK_HIP(hipEventRecord(e1, s));
+    DRS_CHECK_HIP(hipStreamSynchronize(s));
+    DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    DRS_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(drs_rb0_tl), sizeof(h)));
+    for (int w = 0; w < 2; ++w) {
+      const unsigned long long* t = h + 16 * w;
+      const double sc = t[8] ? 1.0 / (double)t[8] : 0.0;
+      fprintf(stderr, "resblock0 %dx%d wave %d: %.1f us, %llu patches, alive %llu ticks (%.0f / patch) | top %.0f  A-mfma %.0f  A-epi %.0f  bar1 %.0f  "
+              "winstore+bar2 %.0f  B-mfma %.0f  B-epi %.0f\n", d.H, d.W, w ? 7 : 0, ms * 1e3, t[8], t[9], t[9] * sc, t[7] * sc, t[0] * sc, t[1] * sc,
+              t[2] * sc, t[3] * sc, t[4] * sc, t[5] * sc);
+    }
+  }
+#endif
   return DRS_OK;
 }
