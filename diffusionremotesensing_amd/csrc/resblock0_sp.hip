@@ -6,16 +6,20 @@
 // HBM twice at the highest resolution: 134 MB written and read back of the 600 MB the two launches move, and both run at a
 // third of the MFMA rate.  Here a GROUP of four waves owns a patch of 8 rows x 16 columns:
 //   phase A  h on the patch's 10 x 18 window (the halo is recomputed: 41 % more conv1 work), 12 MFMA pixel blocks of 16
-//            consecutive window pixels, three per wave.  Operands come straight from global memory (x is 64 bytes
-//            per pixel; a lane gathers the pixel of ITS tap: two taps of 16 channels share the K = 32 of an MFMA, k-groups
-//            0-1 tap 2j, k-groups 2-3 tap 2j + 1, as in the pair flavour of the direct kernel); the result is split into
-//            bf16 hi | lo - the rounding the SP tensor between the two launches had - and written into an LDS window in
-//            the rotated pixel-major layout of the wave-specialised kernel (slot s of pixel p at position (s + p) & 7).
-//            Window pixels outside the image are conv2's zero padding: zeros, not conv1 of padded x.
+//            consecutive window pixels, three per wave.  The group first stages the 12 x 20 pixels of x around the patch in
+//            LDS (coalesced 64-byte pixels, zeros outside the image: the tile IS conv1's zero padding) and every operand
+//            is a ds_read at lane address + tap offset: a lane reads the pixel of ITS tap - two taps of 16 channels share
+//            the K = 32 of an MFMA, k-groups 0-1 tap 2j, k-groups 2-3 tap 2j + 1, as in the pair flavour of the direct
+//            kernel.  (Gathering the same operands from global memory, 30 scattered loads per wave and patch, cost 2.6 k of
+//            a wave's 13 k cycles per patch in the timeline build.)  The next patch's tile travels global ->
+//            registers during phase A and registers -> LDS once every wave of the group has left phase A.
+//            The result is split into bf16 hi | lo - the rounding the SP tensor between the two launches had - and written
+//            into an LDS window in the rotated pixel-major layout of the wave-specialised kernel (slot s of pixel p at
+//            position (s + p) & 7).  Window pixels outside the image are conv2's zero padding: zeros, not conv1 of padded x.
 //   phase B  conv2 from the LDS window (shifted taps are shifted LDS addresses: no lane shuffles), the 1x1 shortcut of x as
 //            one more tap, ReLU, SP store.  A wave owns two rows of the patch.
 // All weights (41 + 37 + 4 KB) stay in LDS for the lifetime of the persistent block.  A block is TWO such groups (waves
-// 0-3 and 4-7: waves w and w + 4 share a SIMD) with a window each, synchronised by two LDS counters per group, never by a
+// 0-3 and 4-7: waves w and w + 4 share a SIMD) with a window and an x tile each, synchronised by three LDS counters per group, never by a
 // workgroup barrier, and started half a patch apart: a third of a patch's cycles are epilogues (bias / ReLU / hi | lo split,
 // window and global stores) in which the wave issues no MFMA - measured with all eight waves in lockstep on one 16 x 16
 // patch: 7.2 k of 17.7 k cycles per patch with the matrix pipe idle - and the other group's MFMA phase fills them.
@@ -30,7 +34,8 @@ namespace {
 
 constexpr int TW_ = 16, TH_ = 8, IW = TW_ + 2, IH = TH_ + 2, NPIX = IW * IH, NBLK_A = (NPIX + 15) / 16;  // 180 window pixels, 12 pixel blocks
 constexpr int IMG1 = 5 * 4 * 64 * 16, IMG2 = 36 * 32 * 16, IMGS = 4 * 32 * 16, WIN = NPIX * 128;
-constexpr int NPOST = 64;  // images whose time-embedding rows are staged in LDS (later images read them from memory)
+constexpr int NPOST = 16;  // images whose time-embedding rows are staged in LDS (later images read them from memory)
+constexpr int XPLANE = (TH_ + 4) * (TW_ + 4) * 16 + 64, XT = 4 * XPLANE;  // x tile: four slot planes of 240 pixels (+ 64 bytes: bank shift)
 
 #ifdef DRS_SP_TIMELINE  // tools/build_tl.sh: per-phase s_memtime sums of waves 0 and 7 of block 0
 __device__ unsigned long long drs_rb0_tl[32];
@@ -57,10 +62,11 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
   char* sW2 = sW1 + 2 * IMG1;     // [image 2][tap 9][k-group 4][32]
   char* sWs = sW2 + 2 * IMG2;     // [image 2][k-group 4][32]
   char* sWinAll = sWs + 2 * IMGS; // two h windows (one per group): pixel p = py * 18 + px at p * 128, operand slot s at ((s + p) & 7) * 16
-  float* sB1 = reinterpret_cast<float*>(sWinAll + 2 * WIN);  // [64] conv1 | skip biases
+  char* sXAll = sWinAll + 2 * WIN;  // two x tiles (one per group)
+  float* sB1 = reinterpret_cast<float*>(sXAll + 2 * XT);  // [64] conv1 | skip biases
   float* sB2 = sB1 + 64;                              // [32] conv2 + shortcut bias
-  unsigned* sCntRaw = reinterpret_cast<unsigned*>(sB2 + 32);  // [group 2][window written, window read] monotonic counters
-  float* sPost = sB2 + 32 + 4;                        // [min(N, NPOST)][32] relu(time_mlp(t)) rows
+  unsigned* sCntRaw = reinterpret_cast<unsigned*>(sB2 + 32);  // [group 2][window written, window read], [group 2] x tile written: monotonic counters
+  float* sPost = sB2 + 32 + 8;                        // [min(N, NPOST)][32] relu(time_mlp(t)) rows
   const int npost = min(d.N, NPOST);
   {
     const char* w1 = reinterpret_cast<const char*>(d.w1);
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
     copy(sWs + IMGS, wsc + ws_gimage, IMGS);
     for (int i = tid; i < 64; i += 512) sB1[i] = d.b1[i];
     for (int i = tid; i < 32; i += 512) sB2[i] = d.b2[i] + d.bs[i];
-    if (tid < 4) sCntRaw[tid] = 0u;
+    if (tid < 8) sCntRaw[tid] = 0u;
     for (int i = tid; i < npost * 32; i += 512) sPost[i] = d.temb[(size_t)(i >> 5) * d.temb_cs + (i & 31)];
   }
   __syncthreads();
@@ -97,106 +103,70 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
   const int t_lo = (int)((long long)total * xcd / 8), t_hi = (int)((long long)total * (xcd + 1) / 8);
   const char* zero = reinterpret_cast<const char*>(d.zero_line);
   const char* xb = reinterpret_cast<const char*>(d.x);
-  // this lane's tap of pair j: k-groups 0-1 multiply tap 2j, k-groups 2-3 tap 2j + 1 (pair 4: tap 8 and zero weights)
-  const int kc16 = (kg & 1) * 16;  // byte offset of the lane's 8 channels inside the 32-byte hi (or lo) half of a pixel
+  char* sX = sXAll + grp * XT;  // this group's x tile
+  const sp_flag_ptr cTile = (sp_flag_ptr)(sCntRaw + 4 + grp);
+  // ---- x tile: 12 x 20 pixels around the patch (origin (ty0 - 2, tx0 - 2)), zeros outside the image, as four planes of
+  // 16-byte slots [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15][pixel] (plane stride padded: conflict-free for the loader, whose
+  // 16 consecutive lanes are 4 pixels x 4 slots, and for the operand reads, whose 16 lanes are 16 pixels of one slot).
+  // The group's 256 lanes move it as 16-byte pieces e = 256 i + 64 gw + lane: pixel e >> 2, slot e & 3 - global reads of
+  // whole 64-byte pixels, 1280 consecutive bytes per tile row.
+  constexpr int XPIX = (TH_ + 4) * (TW_ + 4), XW = TW_ + 4;
+  int tx0 = 0, ty0 = 0, n = 0;
+  auto place = [&](int q) __attribute__((always_inline)) { tx0 = (q % gx) * TW_; ty0 = ((q / gx) % gy) * TH_; n = q / (gx * gy); };
+  u32x4 xr[4];
+  auto tile_load = [&]() __attribute__((always_inline)) {
+    const char* ximg = xb + (size_t)n * d.H * d.W * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = i * 256 + gw * 64 + lane, pix = e >> 2;
+      const int py = (pix * 3277) >> 16, px = pix - py * XW;  // pix / 20 (exact for pix < 1024)
+      const int y = ty0 - 2 + py, x = tx0 - 2 + px;
+      const bool ok = pix < XPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
+      xr[i] = *reinterpret_cast<const u32x4*>(ok ? ximg + ((size_t)y * d.W + x) * 64 + (e & 3) * 16 : zero);
+    }
+  };
+  auto tile_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = i * 256 + gw * 64 + lane;
+      if ((e >> 2) < XPIX) *reinterpret_cast<u32x4*>(sX + (e & 3) * XPLANE + (e >> 2) * 16) = xr[i];
+    }
+    sp_release(cTile, lane);  // (in order behind the stores)
+  };
+  // this lane's operand addresses in the tile: window pixel of phase-A block b (+ 1, + 1: the tap offsets are -1 .. 1) and
+  // the lane's tap of pair j: k-groups 0-1 multiply tap 2j, k-groups 2-3 tap 2j + 1 (pair 4: tap 8 and zero weights)
   constexpr int MAXB = NBLK_A / 4;  // pixel blocks of a wave in phase A: blocks gw, gw + 4, gw + 8
   static_assert(MAXB * 4 == NBLK_A, "three blocks per wave");
-
-  // this lane's window pixel per phase-A block (image coordinates, linear window index) and the operand gather
-  int wp[MAXB];
-  int tx0 = 0, ty0 = 0, n = 0;
-  const char* ximg = xb;
-  // Interior patches (every pixel of every tap inside the image: 82 % of them at 256 x 256) address their operands as
-  //   scalar base of the patch (pixel (ty0 - 2, tx0 - 2)) + a lane offset that does not depend on the patch
-  // - window pixel and tap are properties of the lane.  The general form (coordinates, four comparisons and two selects
-  // per operand, 15 operands per patch) costs more issue cycles than the MFMAs it feeds.
-  unsigned rel[MAXB], tapoff[5];
+  int wp[MAXB], relL[MAXB], tapL[5];
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     const int p = min((gw + 4 * b) * 16 + lr, NPIX - 1);
     const int py = (p * 3641) >> 16, px = p - py * IW;  // p / 18 (exact for p < 1024)
     wp[b] = p;
-    rel[b] = (unsigned)(((py + 1) * d.W + px + 1) * 64 + kc16);
+    relL[b] = ((py + 1) * XW + px + 1) * 16 + (kg & 1) * XPLANE;
   }
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int tap = min(2 * j + (kg >> 1), 8);
-    tapoff[j] = (unsigned)(((tap / 3 - 1) * d.W + tap % 3 - 1) * 64);  // (wraps; rel + tapoff >= 0)
+    tapL[j] = ((tap / 3 - 1) * XW + tap % 3 - 1) * 16;
   }
-  typedef const __attribute__((address_space(1))) char* gptr;
-  typedef const __attribute__((address_space(1))) bf16x8* gfrag;
-  gptr pbase = (gptr)xb;
-  bool interior = false;
-  auto place = [&](int q) __attribute__((always_inline)) {
-    tx0 = (q % gx) * TW_; ty0 = ((q / gx) % gy) * TH_; n = q / (gx * gy);
-    ximg = xb + (size_t)n * d.H * d.W * 64;
-    interior = ty0 >= 2 && ty0 + TH_ + 2 <= d.H && tx0 >= 2 && tx0 + TW_ + 2 <= d.W;
-#ifdef DRS_SP_TIMELINE
-    if (debug & 4) interior = false;
-#endif
-    {
-      // (opaque scalar copy: the compiler otherwise folds base + lane offset + constant into one 64-bit lane address per load)
-      gptr g = (gptr)(ximg + ((long long)(ty0 - 2) * d.W + (tx0 - 2)) * 64);
-      asm volatile("" : "+s"(g));
-      pbase = g;
-    }
+  auto operand = [&](int b, int j) __attribute__((always_inline)) {
+    const char* p = sX + relL[b] + tapL[j];
+    return Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + 2 * XPLANE)};
   };
-  // (border patches and the epilogue's zero padding: coordinates from the window index, nothing held across phases)
-  auto win_xy = [&](int b, int& y, int& x) __attribute__((always_inline)) {
-    int p = wp[b];
-    asm volatile("" : "+v"(p));  // (not hoisted out of the patch loop: registers)
-    const int py = (p * 3641) >> 16, px = p - py * IW;
-    y = ty0 - 1 + py; x = tx0 - 1 + px;
-  };
-  auto gather_any = [&](int b, int j) __attribute__((always_inline)) {
-    int y, x;
-    win_xy(b, y, x);
-    int kh = kg >> 1;
-    asm volatile("" : "+v"(kh));
-    const int tap = min(2 * j + kh, 8);
-    const int sy = y + tap / 3 - 1, sx = x + tap % 3 - 1;
-#ifdef DRS_SP_TIMELINE
-    const bool ok = !(debug & 2) && sy >= 0 && sy < d.H && sx >= 0 && sx < d.W;  // (2: every operand from the zero line)
-#else
-    const bool ok = sy >= 0 && sy < d.H && sx >= 0 && sx < d.W;
-#endif
-    const char* p = ok ? ximg + ((size_t)sy * d.W + sx) * 64 + kc16 : zero;
-    return Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + 32 : zero)};
-  };
-  auto gather3 = [&](Frag (&dst)[MAXB], int j) __attribute__((always_inline)) {
-#ifdef DRS_SP_TIMELINE
-    if (debug & 8) {  // no operand loads at all (stale registers): the phase without its memory side
-#pragma unroll
-      for (int b = 0; b < MAXB; ++b) asm volatile("" : "+v"(dst[b].hi), "+v"(dst[b].lo));
-      return;
-    }
-#endif
-    if (interior) {  // (wave-uniform)
-#pragma unroll
-      for (int b = 0; b < MAXB; ++b) {
-        const unsigned o = rel[b] + tapoff[j];
-        dst[b] = Frag{*(gfrag)(pbase + o), *(gfrag)(pbase + (o + 32u))};
-      }
-    } else {
-#pragma unroll
-      for (int b = 0; b < MAXB; ++b) dst[b] = gather_any(b, j);
-    }
-  };
-  Frag a[2][MAXB];  // operand ring: tap pair j in slot j & 1, fetched one pair ahead (pair 0 a whole phase B ahead)
   const int q0 = t_lo + 2 * member + grp, qstep = 2 * members;  // the block's two groups take neighbouring patches
-  if (q0 < t_hi) {
-    place(q0);
-    gather3(a[0], 0);
-  }
 #ifdef DRS_SP_TIMELINE
   unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long tl_begin = __builtin_amdgcn_s_memtime();
   unsigned long long tl_last = tl_begin, tl_n = 0;
-#endif
-  // the second group starts half a patch late (one MFMA phase): from then on its epilogues meet the first group's MFMA phases
-#ifdef DRS_SP_TIMELINE
   if ((debug & 1) && grp == 1) return;  // one group alone: uncontended phase times (the output is incomplete)
 #endif
+  if (q0 < t_hi) {
+    place(q0);
+    tile_load();
+    tile_store();
+  }
+  // the second group starts half a patch late (one MFMA phase): from then on its epilogues meet the first group's MFMA phases
   if (grp == 1) { __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_s_sleep(32); }
   unsigned k = 0;  // patches done by this group
   for (int q = q0; q < t_hi; q += qstep, ++k) {
@@ -204,23 +174,36 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
     ++tl_n;
 #endif
     RB_STAMP(7);
-    // ================= phase A: h on the 18 x 18 window (the operands of tap pair 0 are already in flight) =================
+    const int cty0 = ty0, ctx0 = tx0, cn = n;
+    sp_poll_lds(cTile, 4u * (k + 1), d.fault);  // this patch's x tile is complete
+    const bool more = q + qstep < t_hi;
+    if (more) {  // the next patch's tile: into registers now, into LDS when every wave of the group is past phase A
+      place(q + qstep);
+      tile_load();
+    }
+    // ================= phase A: h on the 10 x 18 window =================
     f32x4 acc[MAXB][4];
 #pragma unroll
     for (int b = 0; b < MAXB; ++b)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // (weight fragments one step ahead of their MFMAs: read-wait-multiply exposes the LDS latency 20 times per patch)
+    // (operands and weight fragments one step ahead of their MFMAs; the order is pinned: left alone the scheduler sinks the
+    // reads behind the first MFMAs of a step to save registers and the wave waits for the LDS in every step)
     const char* w1lane = sW1 + ((size_t)kg * 64 + lr) * 16;
-    Frag wfa[2];
+    Frag a[2][MAXB], wfa[2];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) a[0][b] = operand(b, 0);
     wfa[0] = P::load(w1lane, (size_t)IMG1, 0);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      if (j + 1 < 5) gather3(a[(j + 1) & 1], j + 1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int st = j * 4 + t;
         if (st + 1 < 20) wfa[(st + 1) & 1] = P::load(w1lane, (size_t)IMG1, (size_t)(((st + 1) >> 2) * 4 * 64 + ((st + 1) & 3) * 16) * 16);
+        if (t == 0 && j + 1 < 5) {
+#pragma unroll
+          for (int b = 0; b < MAXB; ++b) a[(j + 1) & 1][b] = operand(b, j + 1);
+        }
         {
           const Frag& wf = wfa[st & 1];
 #pragma unroll
@@ -230,31 +213,30 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
 #pragma unroll
           for (int b = 0; b < MAXB; ++b) acc[b][t] = mfma(wf.hi, a[j & 1][b].hi, acc[b][t]);
         }
-        // (pin the order: the next step's two fragment reads FIRST, then the nine MFMAs - left alone the scheduler sinks the
-        // reads behind the first MFMAs to save registers and the wave waits for the LDS in every step)
-        if (st + 1 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (t == 0 && j + 1 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * MAXB, 0);
+        else if (st + 1 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    RB_STAMP(0);  // phase A gathers + MFMA
-    // the shortcut operand of phase B (the centre pixels of this wave's two rows): in flight across the barriers
+    RB_STAMP(0);  // phase A operand reads + MFMA
+    // the shortcut operand of phase B (the centre pixels of this wave's two rows; k-groups 2-3 meet zero weights)
     Frag xs[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const char* p = kg < 2 ? ximg + ((size_t)(ty0 + 2 * gw + r) * d.W + tx0 + lr) * 64 + kc16 : zero;
-      xs[r] = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(kg < 2 ? p + 32 : zero)};
+      const char* p = sX + ((2 + 2 * gw + r) * XW + 2 + lr) * 16 + (kg & 1) * XPLANE;
+      xs[r] = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + 2 * XPLANE)};
     }
     // h = relu(conv1 + b1) + temb[n] + (skip + bs): tiles 0, 1 (conv1) and 2, 3 (skip) of the same lane are the same channels
     float bm[8], bs[8], te[8];
     {
       const float4 m0 = *reinterpret_cast<const float4*>(sB1 + kg * 8), m1 = *reinterpret_cast<const float4*>(sB1 + kg * 8 + 4);
       const float4 s0 = *reinterpret_cast<const float4*>(sB1 + 32 + kg * 8), s1 = *reinterpret_cast<const float4*>(sB1 + 32 + kg * 8 + 4);
-      const float* tp = n < npost ? sPost + n * 32 + kg * 8 : nullptr;
       float4 e0, e1;
-      if (tp) { e0 = *reinterpret_cast<const float4*>(tp); e1 = *reinterpret_cast<const float4*>(tp + 4); }
-      else {
-        const float* gp = d.temb + (size_t)n * d.temb_cs + kg * 8;
+      if (cn < npost) {
+        e0 = *reinterpret_cast<const float4*>(sPost + cn * 32 + kg * 8); e1 = *reinterpret_cast<const float4*>(sPost + cn * 32 + kg * 8 + 4);
+      } else {
+        const float* gp = d.temb + (size_t)cn * d.temb_cs + kg * 8;
         e0 = *reinterpret_cast<const float4*>(gp); e1 = *reinterpret_cast<const float4*>(gp + 4);
       }
       bm[0] = m0.x; bm[1] = m0.y; bm[2] = m0.z; bm[3] = m0.w; bm[4] = m1.x; bm[5] = m1.y; bm[6] = m1.z; bm[7] = m1.w;
@@ -274,28 +256,24 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
           v[t * 4 + i] = (fmaxf(acc[b][t][i] + bm[t * 4 + i], 0.f) + (acc[b][t + 2][i] + bs[t * 4 + i])) + te[t * 4 + i];  // (the two-launch path's order)
       u32x4 hh, hl;
       drs_sp_split8(v, hh, hl);
-      int y, x;
-      win_xy(b, y, x);
-      const bool inside = y >= 0 && y < d.H && x >= 0 && x < d.W;
+      int p = wp[b];
+      asm volatile("" : "+v"(p));  // (coordinates recomputed here: nothing held across the phases)
+      const int py = (p * 3641) >> 16, px = p - py * IW;
+      const int y = cty0 - 1 + py, x = ctx0 - 1 + px;
+      const bool inside = y >= 0 && y < d.H && x >= 0 && x < d.W;  // outside: conv2's zero padding
       if (!inside) { hh = u32x4{0u, 0u, 0u, 0u}; hl = u32x4{0u, 0u, 0u, 0u}; }
       if ((gw + 4 * b) * 16 + lr < NPIX) {
-        char* wpix = sWin + wp[b] * 128;
-        const int s0 = ((kg + wp[b]) & 7) * 16;
+        char* wpix = sWin + p * 128;
+        const int s0 = ((kg + p) & 7) * 16;
         *reinterpret_cast<u32x4*>(wpix + s0) = hh;
         *reinterpret_cast<u32x4*>(wpix + (s0 ^ 64)) = hl;  // slot + 4 (mod 8)
       }
     }
     sp_release(cWritten, lane);  // (the LDS executes a wave's operations in order: the add lands behind the stores)
-    sp_poll_lds(cWritten, 4u * (k + 1), d.fault);  // the window is complete
-    RB_STAMP(3);  // window stores + wait 2
-    // the next patch's first operands: their latency hides behind phase B
-    const int cty0 = ty0, ctx0 = tx0, cn = n;
-    if (q + qstep < t_hi) {
-      place(q + qstep);
-      gather3(a[0], 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ================= phase B: out = relu(conv2(h) + shortcut(x) + b) on rows 2 * wave, 2 * wave + 1 =================
+    sp_poll_lds(cWritten, 4u * (k + 1), d.fault);  // the window is complete: every wave of the group is past phase A ...
+    if (more) tile_store();                        // ... and its x tile may be replaced
+    RB_STAMP(3);  // window stores + wait 2 + tile stores
+    // ================= phase B: out = relu(conv2(h) + shortcut(x) + b) on rows 2 * gw, 2 * gw + 1 =================
     f32x4 o[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -350,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    RB_STAMP(4);  // next gathers issued, window reads, phase B MFMA (incl. the shortcut)
+    RB_STAMP(4);  // window reads, phase B MFMA (incl. the shortcut)
     {
       SpEpiConst kc;
       const float4 b0 = *reinterpret_cast<const float4*>(sB2 + kg * 8), b1 = *reinterpret_cast<const float4*>(sB2 + kg * 8 + 4);
@@ -364,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
       de.relu_post = 1;
       tile_epilogue_sp_pre<2, false>(de, o, kc, cn, 0, cty0, ctx0, gw, lr, kg);
     }
-    RB_STAMP(5);  // shortcut MFMA + epilogue B
+    RB_STAMP(5);  // epilogue B
   }
 #ifdef DRS_SP_TIMELINE
   if (blockIdx.x == 0 && (wave == 0 || wave == 7) && lane == 0) {
@@ -376,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
 #endif
 }
 
-size_t resblock0_lds(int N) { return (size_t)2 * (IMG1 + IMG2 + IMGS) + 2 * WIN + (size_t)(64 + 32 + 4 + 32 * (N < NPOST ? N : NPOST)) * 4; }
+size_t resblock0_lds(int N) { return (size_t)2 * (IMG1 + IMG2 + IMGS) + 2 * WIN + 2 * XT + (size_t)(64 + 32 + 8 + 32 * (N < NPOST ? N : NPOST)) * 4; }
 
 }  // namespace
 
