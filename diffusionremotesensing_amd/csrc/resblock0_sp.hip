@@ -112,17 +112,51 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
   // whole 64-byte pixels, 1280 consecutive bytes per tile row.
   constexpr int XPIX = (TH_ + 4) * (TW_ + 4), XW = TW_ + 4;
   int tx0 = 0, ty0 = 0, n = 0;
-  auto place = [&](int q) __attribute__((always_inline)) { tx0 = (q % gx) * TW_; ty0 = ((q / gx) % gy) * TH_; n = q / (gx * gy); };
+  const int qstep_ = 2 * (int)(gridDim.x >> 3);
+  // (patch coordinates advance by a fixed step: no division per patch)
+  const int step_x = qstep_ % gx, step_y = (qstep_ / gx) % gy, step_n = qstep_ / (gx * gy);
+  int bx = 0, by = 0;  // patch indices of (tx0, ty0)
+  auto place_first = [&](int q) __attribute__((always_inline)) {
+    bx = q % gx; by = (q / gx) % gy; n = q / (gx * gy);
+    tx0 = bx * TW_; ty0 = by * TH_;
+  };
+  auto place_next = [&]() __attribute__((always_inline)) {
+    bx += step_x;
+    if (bx >= gx) { bx -= gx; ++by; }
+    by += step_y;
+    if (by >= gy) { by -= gy; ++n; }
+    n += step_n;
+    tx0 = bx * TW_; ty0 = by * TH_;
+  };
+  // this lane's four pieces of a tile: byte offset from the tile's first pixel, validity of the piece index
+  unsigned goff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = i * 256 + gw * 64 + lane, pix = min(e >> 2, XPIX - 1);
+    const int py = (pix * 3277) >> 16, px = pix - py * XW;  // pix / 20 (exact for pix < 1024)
+    goff[i] = (unsigned)((py * d.W + px) * 64 + (e & 3) * 16);
+  }
   u32x4 xr[4];
   auto tile_load = [&]() __attribute__((always_inline)) {
     const char* ximg = xb + (size_t)n * d.H * d.W * 64;
+    if (ty0 >= 2 && ty0 + TH_ + 2 <= d.H && tx0 >= 2 && tx0 + TW_ + 2 <= d.W) {  // (wave-uniform) every pixel inside the image
+      typedef const __attribute__((address_space(1))) char* gptr;
+      const unsigned long long gi = (unsigned long long)(ximg + ((long long)(ty0 - 2) * d.W + (tx0 - 2)) * 64);
+      // (scalar base + lane offset: not one 64-bit lane address per piece; the value is wave-uniform, said explicitly)
+      gptr g = (gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gi >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gi));
+      asm volatile("" : "+s"(g));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = i * 256 + gw * 64 + lane, pix = e >> 2;
-      const int py = (pix * 3277) >> 16, px = pix - py * XW;  // pix / 20 (exact for pix < 1024)
-      const int y = ty0 - 2 + py, x = tx0 - 2 + px;
-      const bool ok = pix < XPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
-      xr[i] = *reinterpret_cast<const u32x4*>(ok ? ximg + ((size_t)y * d.W + x) * 64 + (e & 3) * 16 : zero);
+      for (int i = 0; i < 4; ++i) xr[i] = *(const __attribute__((address_space(1))) u32x4*)(g + goff[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = i * 256 + gw * 64 + lane, pix = e >> 2;
+        const int py = (pix * 3277) >> 16, px = pix - py * XW;
+        const int y = ty0 - 2 + py, x = tx0 - 2 + px;
+        const bool ok = pix < XPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
+        xr[i] = *reinterpret_cast<const u32x4*>(ok ? ximg + ((size_t)y * d.W + x) * 64 + (e & 3) * 16 : zero);
+      }
     }
   };
   auto tile_store = [&]() __attribute__((always_inline)) {
@@ -162,25 +196,30 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
   if ((debug & 1) && grp == 1) return;  // one group alone: uncontended phase times (the output is incomplete)
 #endif
   if (q0 < t_hi) {
-    place(q0);
+    place_first(q0);
     tile_load();
     tile_store();
+    if (q0 + qstep < t_hi) {  // the second patch's tile waits in registers for the first patch's phase A to end
+      place_next();
+      tile_load();
+      // (landed before the loop is entered: loads still pending on the entry edge make the compiler drain the memory counter
+      // at the first register write of EVERY iteration - behind the previous patch's output stores)
+      asm volatile("" :: "v"(xr[0]), "v"(xr[1]), "v"(xr[2]), "v"(xr[3]));
+    }
   }
   // the second group starts half a patch late (one MFMA phase): from then on its epilogues meet the first group's MFMA phases
   if (grp == 1) { __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_s_sleep(32); }
   unsigned k = 0;  // patches done by this group
+  u32x4 kept[4] = {};  // the previous patch's stored registers (see the output epilogue)
+  int cbx = q0 % gx, cby = (q0 / gx) % gy, cn = q0 / (gx * gy);  // the CURRENT patch ((tx0, ty0, n) run ahead: tile loads)
   for (int q = q0; q < t_hi; q += qstep, ++k) {
 #ifdef DRS_SP_TIMELINE
     ++tl_n;
 #endif
     RB_STAMP(7);
-    const int cty0 = ty0, ctx0 = tx0, cn = n;
+    const int cty0 = cby * TH_, ctx0 = cbx * TW_;
     sp_poll_lds(cTile, 4u * (k + 1), d.fault);  // this patch's x tile is complete
-    const bool more = q + qstep < t_hi;
-    if (more) {  // the next patch's tile: into registers now, into LDS when every wave of the group is past phase A
-      place(q + qstep);
-      tile_load();
-    }
+    const bool more = q + qstep < t_hi;  // (its tile is in registers: loaded before the previous patch's output stores)
     // ================= phase A: h on the 10 x 18 window =================
     f32x4 acc[MAXB][4];
 #pragma unroll
@@ -189,36 +228,47 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
       for (int t = 0; t < 4; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (operands and weight fragments one step ahead of their MFMAs; the order is pinned: left alone the scheduler sinks the
     // reads behind the first MFMAs of a step to save registers and the wave waits for the LDS in every step)
+    // A step = one tap pair x TWO channel tiles: six accumulator chains, so a dependent MFMA follows its predecessor at a
+    // distance of six (at a distance of three - one tile per step - the loop ran at 23 cycles per MFMA instead of 16).
     const char* w1lane = sW1 + ((size_t)kg * 64 + lr) * 16;
-    Frag a[2][MAXB], wfa[2];
+    Frag a[2][MAXB], wfa[2][2];
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) a[0][b] = operand(b, 0);
-    wfa[0] = P::load(w1lane, (size_t)IMG1, 0);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int u = 0; u < 2; ++u) wfa[0][u] = P::load(w1lane, (size_t)IMG1, (size_t)(u * 16) * 16);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int st = j * 4 + t;
-        if (st + 1 < 20) wfa[(st + 1) & 1] = P::load(w1lane, (size_t)IMG1, (size_t)(((st + 1) >> 2) * 4 * 64 + ((st + 1) & 3) * 16) * 16);
-        if (t == 0 && j + 1 < 5) {
+    for (int st = 0; st < 10; ++st) {  // step = (tap pair j, tile pair h): tiles 2h, 2h + 1
+      const int j = st >> 1, h = st & 1;
+      if (st + 1 < 10) {
 #pragma unroll
-          for (int b = 0; b < MAXB; ++b) a[(j + 1) & 1][b] = operand(b, j + 1);
-        }
-        {
-          const Frag& wf = wfa[st & 1];
-#pragma unroll
-          for (int b = 0; b < MAXB; ++b) acc[b][t] = mfma(wf.lo, a[j & 1][b].hi, acc[b][t]);
-#pragma unroll
-          for (int b = 0; b < MAXB; ++b) acc[b][t] = mfma(wf.hi, a[j & 1][b].lo, acc[b][t]);
-#pragma unroll
-          for (int b = 0; b < MAXB; ++b) acc[b][t] = mfma(wf.hi, a[j & 1][b].hi, acc[b][t]);
-        }
-        if (t == 0 && j + 1 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * MAXB, 0);
-        else if (st + 1 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 2; ++u)
+          wfa[(st + 1) & 1][u] = P::load(w1lane, (size_t)IMG1, (size_t)(((st + 1) >> 1) * 4 * 64 + (((st + 1) & 1) * 2 + u) * 16) * 16);
       }
+      if (h == 0 && j + 1 < 5) {
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) a[(j + 1) & 1][b] = operand(b, j + 1);
+      }
+      {
+        const Frag (&wf)[2] = wfa[st & 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int b = 0; b < MAXB; ++b) acc[b][2 * h + u] = mfma(wf[u].lo, a[j & 1][b].hi, acc[b][2 * h + u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int b = 0; b < MAXB; ++b) acc[b][2 * h + u] = mfma(wf[u].hi, a[j & 1][b].lo, acc[b][2 * h + u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int b = 0; b < MAXB; ++b) acc[b][2 * h + u] = mfma(wf[u].hi, a[j & 1][b].hi, acc[b][2 * h + u]);
+      }
+      if (h == 0 && j + 1 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * MAXB, 0);
+      else if (st + 1 < 10) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    asm volatile("" :: "v"(kept[0]), "v"(kept[1]), "v"(kept[2]), "v"(kept[3]));  // (end of their allocation)
     RB_STAMP(0);  // phase A operand reads + MFMA
     // the shortcut operand of phase B (the centre pixels of this wave's two rows; k-groups 2-3 meet zero weights)
     Frag xs[2];
@@ -328,21 +378,45 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    RB_STAMP(4);  // window reads, phase B MFMA (incl. the shortcut)
+    // the tile after the next one: into registers BEFORE this patch's output stores (one in-order memory counter: loads
+    // issued behind the stores would return behind them, and registers the stores read cannot be reloaded before they left)
+    if (q + 2 * qstep < t_hi) {
+      place_next();
+      tile_load();
+    }
+    RB_STAMP(4);  // window reads, phase B MFMA (incl. the shortcut), next tile loads issued
     {
-      SpEpiConst kc;
+      // out = relu(acc + b), split into bf16 hi | lo, stored as full 128-byte lines (lanes lr < 8 write the hi slots of
+      // pixels lr and lr + 8, lanes lr >= 8 their lo slots: conv_epilogue.h, tile_epilogue_sp_pre).  The stored registers
+      // stay allocated until the next patch's phase A is over (`kept`): a register a store in flight reads cannot be
+      // rewritten before the store has left, and the compiler guards that with a full drain of the memory counter -
+      // which was the first thing the next patch did (1.5 k cycles per patch).
       const float4 b0 = *reinterpret_cast<const float4*>(sB2 + kg * 8), b1 = *reinterpret_cast<const float4*>(sB2 + kg * 8 + 4);
-      kc.bias[0] = b0.x; kc.bias[1] = b0.y; kc.bias[2] = b0.z; kc.bias[3] = b0.w;
-      kc.bias[4] = b1.x; kc.bias[5] = b1.y; kc.bias[6] = b1.z; kc.bias[7] = b1.w;
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const bool lo = lr < 8;
+      const size_t pix0 = ((size_t)cn * d.H + cty0 + 2 * gw) * d.W + ctx0 + (lr & 7);
+      char* g = reinterpret_cast<char*>(d.out) + pix0 * 128 + (lo ? 0 : 64) + kg * 16;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { kc.post[i] = 0.f; kc.post2[i] = 0.f; }
-      TapConv de = {};
-      de.out = d.out; de.out_cs = 32; de.out_co = 0;
-      de.OH = d.H; de.OW = d.W; de.TH = d.H; de.TW = d.W;
-      de.relu_post = 1;
-      tile_epilogue_sp_pre<2, false>(de, o, kc, cn, 0, cty0, ctx0, gw, lr, kg);
+      for (int r = 0; r < 2; ++r) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = fmaxf(o[r][0][i] + bb[i], 0.f); v[4 + i] = fmaxf(o[r][1][i] + bb[4 + i], 0.f); }
+        u32x4 H, L;
+        drs_sp_split8(v, H, L);
+        const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo
+        kept[2 * r] = lo ? H : got;
+        kept[2 * r + 1] = lo ? got : L;
+        char* gr = g + (size_t)r * d.W * 128;
+        drs_store16(gr, kept[2 * r]);
+        drs_store16(gr + 8 * 128, kept[2 * r + 1]);
+      }
     }
     RB_STAMP(5);  // epilogue B
+    cbx += step_x;
+    if (cbx >= gx) { cbx -= gx; ++cby; }
+    cby += step_y;
+    if (cby >= gy) { cby -= gy; ++cn; }
+    cn += step_n;
   }
 #ifdef DRS_SP_TIMELINE
   if (blockIdx.x == 0 && (wave == 0 || wave == 7) && lane == 0) {
