@@ -341,7 +341,7 @@ def main():
         def is_dom(name):
             if name.endswith(".edges"):
                 return False  # (the composite kernel's edge vectors: 0.1 % of the work, its own small kernel)
-            return (name.endswith((".conv1.0", ".conv2.0", ".conv_upsampled_lr_img", ".conv1.0+skip")) or
+            return (name.endswith((".conv1.0", ".conv2.0", ".conv_upsampled_lr_img", ".conv1.0+skip", "conv_blocks.0.fused")) or
                     (name.startswith("ups.") and name.endswith(".conv")) or name.startswith("up_convs."))
         conv = [o for o in ops if o[2] > 0 and o[0] not in ("lr_branch", "conv0")]
         dom = [o for o in conv if is_dom(o[0])] if args.impl != "direct" else conv
@@ -398,7 +398,8 @@ def main():
             direct_ops = ("conv_blocks.0.conv1.0+skip", "conv_blocks.0.conv2.0", "up_convs.2", "up_convs.2.att")
             by_kernel = {}
             for kname, sel in (("conv3x3_direct_sp_kernel", [o for o in dom if o[0] in direct_ops]),
-                               ("upfuse_sp_kernel", [o for o in dom if o[0].endswith(".fused")]),
+                               ("resblock0_kernel", [o for o in dom if o[0] == "conv_blocks.0.fused"]),
+                               ("upfuse_sp_kernel", [o for o in dom if o[0].startswith("up_convs.") and o[0].endswith(".fused")]),
                                ("tapconv_sp_kernel", [o for o in dom if o[0] not in direct_ops and not o[0].endswith(".fused")])):
                 if sel:
                     ms = sum(o[1] for o in sel)
@@ -407,8 +408,10 @@ def main():
         roofline = {"bound": "mfma",
                     "kernel": ("3x3 stride-1 convolutions: tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL> (conv_mfma_sp.hip; 8 MFMA + 4 "
                                "mover waves per CU) on the deep layers + upfuse_sp_kernel (same structure: ups.i.transform composed "
-                               "with the x-half of up_convs.i, executed FLOPs counted) + conv3x3_direct_sp_kernel (weights "
-                               "resident in LDS, operands global -> registers) on the 32-channel layers; SP-format operands"
+                               "with the x-half of up_convs.i, executed FLOPs counted) + resblock0_kernel (the first encoder block as "
+                               "one launch: conv1 + skip into an LDS window, conv2 + shortcut from it; algorithmic FLOPs, the halo "
+                               "recomputation not counted) + conv3x3_direct_sp_kernel (weights resident in LDS, operands global -> "
+                               "registers) on up_convs.2's att-half; SP-format operands"
                                if args.impl == "mfma_bf16x3" else
                                "3x3 stride-1 family: tapconv_ws_kernel / tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *>" % args.impl)
                     if args.impl != "direct" else "tapconv_direct_kernel",

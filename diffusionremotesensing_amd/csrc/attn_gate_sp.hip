@@ -439,6 +439,250 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) 
   }
 }
 
+// ---- wide variant, second structure: no operand is fetched twice --------------------------------------------------------
+// The structure above lets every wave load its own operands: the 0.5 MB of weights twice per block (two pixel halves), x four
+// times and x_res four times (four channel groups): 2.2 MB of L2 -> CU traffic per block for 0.7 MB of distinct bytes, all
+// 256 CUs at once - it runs at the L2's pace (48 us, the pipelined form; 57 us before), not HBM's (118 MB: 22 us).
+// Here a wave owns ONE 16-channel tile (its weights: 64 KB, read by nobody else) for ALL 64 pixels of the block, and the
+// activations cross LDS: x (64 KB, coalesced 1 KB per pixel) for the gating phase, then the four x_res pixels under each
+// low-resolution pixel as four 32 KB "taps", double-buffered in the same region, moved global -> registers -> LDS by all 512
+// lanes a tap ahead.  LDS images are pixel-major 128-byte lines with the slot rotation of the wave-specialised kernels
+// (slot s of pixel p at position (s + p) & 7: conflict-free for the loader, whose 8 consecutive lanes write one line, and
+// for the operand reads, whose 16 lanes read one slot of 16 pixels).  A lane's accumulators are 4 consecutive channels of
+// its pixel (half an SP slot): g goes to LDS and att to memory as 8-byte halves.
+template <int NCX>
+__global__ __launch_bounds__(512, 1) void attn_gate_wide2_kernel(AttnGateDesc d) {
+  using P = PolicyBF16X3;
+  using Frag = typename P::Frag;
+  constexpr int Ch = 128, NG = 4;
+  constexpr int XB = 4 * NCX * 16 * 128;  // x image: [pixel block 4][chunk NCX][pixel 16] lines of 128 bytes
+  constexpr int TB = 4 * NG * 16 * 128;   // one x_res tap / the gating signal: [pixel block 4][chunk 4][pixel 16] lines
+  constexpr int RB = XB > 2 * TB ? XB : 2 * TB;  // the two tap buffers live in the x image's region
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;                 // x during the gating phase, then the two x_res tap buffers
+  char* sG = smem + RB;            // g = relu(gate(x))
+  float* sPsi = reinterpret_cast<float*>(sG + TB);  // [wave 8][pixel 64] partial psi sums
+  float* sB = sPsi + 8 * 64;       // b_wg + b_wx | w_psi | b_res | b_psi
+  for (int i = threadIdx.x; i < Ch; i += 512) {
+    sB[i] = d.b_wg[i] + d.b_wx[i];
+    sB[Ch + i] = d.w_psi[i];
+    sB[2 * Ch + i] = d.b_res[i];
+  }
+  if (threadIdx.x == 0) sB[3 * Ch] = d.b_psi[0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int lr = lane & 15, kg = lane >> 4;
+  // this lane's 4 channels (SP row permutation: the tile pair (2G, 2G + 1) of channel group G holds 8 consecutive channels per lane)
+  const int G = wave >> 1, th = wave & 1, ch0 = G * 32 + kg * 8 + th * 4;
+  const size_t gate_img = (size_t)NCX * 4 * Ch * 16, wg_img = (size_t)NG * 4 * Ch * 16, wx_img = (size_t)NG * 16 * Ch * 16;
+  const int bw = (d.LW + 15) / 16;
+  const long long nblk16 = (long long)d.N * d.LH * bw;
+  const long long nitems = (nblk16 + 3) / 4;
+  const int OW = 2 * d.LW, OH = 2 * d.LH;
+  typedef const __attribute__((address_space(1))) char* gptr;
+  typedef const __attribute__((address_space(1))) bf16x8* gfrag;
+  typedef const __attribute__((address_space(1))) u32x4* gquad;
+  auto uni = [](const void* q) __attribute__((always_inline)) {
+    gptr g = (gptr)q;
+    asm volatile("" : "+s"(g));
+    return g;
+  };
+  const gptr gw_gate = uni(d.w_gate), gw_wg = uni(d.w_wg), gw_wx = uni(d.w_wx), gw_res = uni(d.w_res);
+  const gptr gx = uni(reinterpret_cast<const char*>(d.x) + (size_t)d.x_co * 4);
+  const gptr gr = uni(reinterpret_cast<const char*>(d.xres) + (size_t)d.r_co * 4);
+  const unsigned lane_w = (unsigned)((kg * Ch + wave * 16 + lr) * 16);  // this lane's weight slot inside a (chunk, tap) row block
+  auto opaque = [](unsigned v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+  auto wfrag = [&](gptr base, size_t img, int urow) __attribute__((always_inline)) {  // urow (uniform) = (chunk * taps + tap) * 4: first k-group row
+    const unsigned o = opaque(lane_w) + (unsigned)urow * (unsigned)(Ch * 16);
+    return Frag{*(gfrag)(base + o), *(gfrag)(base + (o + (unsigned)img))};
+  };
+  // operand fragment of pixel block pb, chunk c of an LDS image with NC chunks per pixel block
+  auto afrag = [&](const char* img, int nc, int pb, int c) __attribute__((always_inline)) {
+    const char* line = img + ((pb * nc + c) * 16 + lr) * 128;
+    const int s0 = ((kg + lr) & 7) * 16;
+    return Frag{*reinterpret_cast<const bf16x8*>(line + s0), *reinterpret_cast<const bf16x8*>(line + (s0 ^ 64))};
+  };
+  auto mfma = [](const bf16x8& w, const bf16x8& x, const f32x4& c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
+  };
+  // one step: the four pixel blocks' chains round-robin (a dependent MFMA issues a full latency behind its predecessor)
+  auto step4 = [&](const Frag& w, const Frag (&a)[4], f32x4 (&acc)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = mfma(w.lo, a[b].hi, acc[b]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = mfma(w.hi, a[b].lo, acc[b]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = mfma(w.hi, a[b].hi, acc[b]);
+  };
+  __syncthreads();
+  for (long long it = blockIdx.x; it < nitems; it += gridDim.x) {
+    // the item's four pixel blocks: byte offsets of their first pixel in x / x_res / out, validity
+    unsigned xo[4], ro[4], oo[4];
+    int nn[4], npx[4];  // image, valid pixels of the block (0: block beyond the tensor)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const long long q = it * 4 + b;
+      const long long qc = q < nblk16 ? q : nblk16 - 1;
+      const int xb = (int)(qc % bw), y = (int)((qc / bw) % d.LH);
+      nn[b] = (int)(qc / ((long long)bw * d.LH));
+      npx[b] = q < nblk16 ? min(16, d.LW - xb * 16) : 0;
+      xo[b] = (unsigned)((((size_t)nn[b] * d.LH + y) * d.LW + xb * 16) * d.x_cs * 4);
+      ro[b] = (unsigned)((((size_t)nn[b] * OH + 2 * y) * OW + 2 * xb * 16) * d.r_cs * 4);
+      oo[b] = (unsigned)((((size_t)nn[b] * OH + 2 * y) * OW + 2 * xb * 16) * d.out_cs * 4);
+    }
+    auto pick = [&](const unsigned (&v)[4], int b) __attribute__((always_inline)) { return b == 0 ? v[0] : b == 1 ? v[1] : b == 2 ? v[2] : v[3]; };
+    auto picki = [&](const int (&v)[4], int b) __attribute__((always_inline)) { return b == 0 ? v[0] : b == 1 ? v[1] : b == 2 ? v[2] : v[3]; };
+    // ---- loaders: 16-byte pieces e = 512 i + tid; slot e & 7, then chunk, then pixel: consecutive pieces are consecutive bytes
+    u32x4 xr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = i * 512 + tid, pix = e / (8 * NCX), pb = pix >> 4, pl = pix & 15;
+      const int plc = min(pl, max(picki(npx, pb) - 1, 0));  // (pixels beyond the row / the tensor: a valid address, the value is never stored to memory)
+      xr[i] = *(gquad)(gx + (pick(xo, pb) + (unsigned)(plc * d.x_cs * 4) + (unsigned)((e % (8 * NCX)) * 16)));
+    }
+    u32x4 tr[4];  // the next tap's pieces
+    auto tap_load = [&](int t4) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = i * 512 + tid, pix = e >> 5, pb = pix >> 4, pl = pix & 15;
+        const int plc = min(pl, max(picki(npx, pb) - 1, 0));
+        tr[i] = *(gquad)(gr + (pick(ro, pb) + (unsigned)((((t4 >> 1) * OW + 2 * plc + (t4 & 1)) * d.r_cs) * 4) + (unsigned)((e & 31) * 16)));
+      }
+    };
+    auto tap_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = i * 512 + tid, pix = e >> 5, c = (e >> 3) & 3, sl = e & 7, pb = pix >> 4, pl = pix & 15;
+        *reinterpret_cast<u32x4*>(sX + buf * TB + ((pb * NG + c) * 16 + pl) * 128 + ((sl + pl) & 7) * 16) = tr[i];
+      }
+    };
+    tap_load(0);
+    // result weights of this wave's tile: the same for all four taps, held
+    Frag wr[NG];
+#pragma unroll
+    for (int cc = 0; cc < NG; ++cc) wr[cc] = wfrag(gw_res, wg_img, cc * 4);
+    Frag wq[2];  // weight ring of the current phase: one step ahead
+    wq[0] = wfrag(gw_gate, gate_img, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = i * 512 + tid, pix = e / (8 * NCX), c = (e / 8) % NCX, sl = e & 7, pb = pix >> 4, pl = pix & 15;
+      *reinterpret_cast<u32x4*>(sX + ((pb * NCX + c) * 16 + pl) * 128 + ((sl + pl) & 7) * 16) = xr[i];
+    }
+    __syncthreads();
+    // ---- gating signal: g = relu(W_gate x + b), this wave's 16 channels of all 64 pixels ----
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCX; ++c) {
+      if (c + 1 < NCX) wq[(c + 1) & 1] = wfrag(gw_gate, gate_img, (c + 1) * 4);
+      else wq[(c + 1) & 1] = wfrag(gw_wg, wg_img, 0);  // first step of the next phase
+      Frag a[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) a[b] = afrag(sX, NCX, b, c);
+      step4(wq[c & 1], a, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float* bsrc = (d.b_gate_img ? d.b_gate_img + (size_t)nn[b] * Ch : d.b_gate) + ch0;  // (both global: no flat load)
+        const float4 bb = *reinterpret_cast<const float4*>(bsrc);
+        const float v[4] = {fmaxf(acc[b][0] + bb.x, 0.f), fmaxf(acc[b][1] + bb.y, 0.f), fmaxf(acc[b][2] + bb.z, 0.f), fmaxf(acc[b][3] + bb.w, 0.f)};
+        unsigned h2[2], l2[2];
+        drs_sp_split4(v, h2, l2);
+        char* line = sG + ((b * NG + G) * 16 + lr) * 128;
+        const int s0 = ((kg + lr) & 7) * 16 + th * 8;
+        *reinterpret_cast<uint2*>(line + s0) = make_uint2(h2[0], h2[1]);
+        *reinterpret_cast<uint2*>(line + (s0 ^ 64)) = make_uint2(l2[0], l2[1]);
+      }
+    }
+    __syncthreads();  // g complete; every wave has left the x image
+    tap_store(0);
+    tap_load(1);
+    __syncthreads();
+    // ---- p = relu(w_g(g) + w_x(x_res) + b) and the ungated result W' x_res ----
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NG; ++cc) {
+      if (cc + 1 < NG) wq[(NCX + cc + 1) & 1] = wfrag(gw_wg, wg_img, (cc + 1) * 4);
+      else wq[(NCX + cc + 1) & 1] = wfrag(gw_wx, wx_img, 0);
+      Frag a[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) a[b] = afrag(sG, NG, b, cc);
+      step4(wq[(NCX + cc) & 1], a, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 att[4][4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) att[t4][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      if (t4 + 1 < 4) tap_store((t4 + 1) & 1);  // (its buffer was left by every wave before the previous barrier)
+      if (t4 + 2 < 4) tap_load(t4 + 2);
+#pragma unroll
+      for (int cc = 0; cc < NG; ++cc) {
+        const int st = NCX + NG + t4 * NG + cc;  // running step index: parity of the weight ring
+        if (cc + 1 < NG) wq[(st + 1) & 1] = wfrag(gw_wx, wx_img, ((cc + 1) * 4 + t4) * 4);
+        else if (t4 + 1 < 4) wq[(st + 1) & 1] = wfrag(gw_wx, wx_img, (t4 + 1) * 4);
+        Frag a[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) a[b] = afrag(sX + (t4 & 1) * TB, NG, b, cc);
+        step4(wq[st & 1], a, acc);
+        step4(wr[cc], a, att[t4]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+    // ---- psi = sigmoid(w_psi . p + b): this wave's 16 channels, then across the 8 waves through LDS ----
+    {
+      const float4 bsum = *reinterpret_cast<const float4*>(sB + ch0), wp = *reinterpret_cast<const float4*>(sB + Ch + ch0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float dot = fmaxf(acc[b][0] + bsum.x, 0.f) * wp.x + fmaxf(acc[b][1] + bsum.y, 0.f) * wp.y +
+                    fmaxf(acc[b][2] + bsum.z, 0.f) * wp.z + fmaxf(acc[b][3] + bsum.w, 0.f) * wp.w;
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+        if (kg == 0) sPsi[wave * 64 + b * 16 + lr] = dot;
+      }
+    }
+    __syncthreads();
+    {
+      const float4 br = *reinterpret_cast<const float4*>(sB + 2 * Ch + ch0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = b * 16 + lr;
+        float sum = sB[3 * Ch];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += sPsi[w * 64 + i];
+        const float psi = 1.f / (1.f + expf(-sum));
+        const bool ok = lr < npx[b];
+        if (d.psi_out && ok && kg == 0 && wave == 0) {
+          const long long q = it * 4 + b;
+          const int xb = (int)(q % bw), y = (int)((q / bw) % d.LH);
+          d.psi_out[((size_t)nn[b] * d.LH + y) * d.LW + xb * 16 + lr] = psi;
+        }
+        // att = psi * (W' x_res) + b' for the 4 pixels under the low-resolution pixel: 8-byte halves of the SP slots
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const float v[4] = {psi * att[t4][b][0] + br.x, psi * att[t4][b][1] + br.y, psi * att[t4][b][2] + br.z, psi * att[t4][b][3] + br.w};
+          unsigned h2[2], l2[2];
+          drs_sp_split4(v, h2, l2);
+          if (ok) {
+            char* o = reinterpret_cast<char*>(d.out) + (size_t)d.out_co * 4 + oo[b] +
+                      (size_t)(((t4 >> 1) * OW + 2 * lr + (t4 & 1)) * d.out_cs + G * 32) * 4 + kg * 16 + th * 8;
+            *reinterpret_cast<uint2*>(o) = make_uint2(h2[0], h2[1]);
+            *reinterpret_cast<uint2*>(o + 64) = make_uint2(l2[0], l2[1]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // sX / sG / sPsi are rewritten by the next item
+  }
+}
+
 template <int NT>
 int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
   auto kern = attn_gate_sp_kernel<NT>;
@@ -503,11 +747,25 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
               DRS_ERR_SHAPE, "attn_gate: channel strides / offsets must be multiples of 32");
   if ((long long)d.N * d.LH * d.LW == 0) return DRS_OK;
   if (d.Ch == 128) {
+    // DRS_GATE_WIDE=1: the first structure (every wave loads its own operands)
+    static const int wide_env = getenv("DRS_GATE_WIDE") ? atoi(getenv("DRS_GATE_WIDE")) : 2;
     int num_cu = 0;
+    const long long nitems = ((long long)d.N * d.LH * ((d.LW + 15) / 16) + 3) / 4;
+    if (wide_env == 2) {
+      auto kern = d.Cc == 256 ? attn_gate_wide2_kernel<8> : attn_gate_wide2_kernel<4>;
+      const int ncx = d.Cc / 32;
+      const size_t xb = (size_t)4 * ncx * 16 * 128, tb = (size_t)4 * 4 * 16 * 128;
+      const size_t lds = (xb > 2 * tb ? xb : 2 * tb) + tb + (size_t)(8 * 64 + 3 * 128 + 4) * 4;
+      const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
+      if (rc) return rc;
+      const long long blocks = nitems < 4LL * num_cu ? nitems : 4LL * num_cu;
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, d);
+      DRS_CHECK_HIP(hipGetLastError());
+      return DRS_OK;
+    }
     auto kern = d.Cc == 256 ? attn_gate_wide_kernel<8> : attn_gate_wide_kernel<4>;
     const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 0, &num_cu);
     if (rc) return rc;
-    const long long nitems = ((long long)d.N * d.LH * ((d.LW + 15) / 16) + 3) / 4;
     const long long blocks = nitems < 4LL * num_cu ? nitems : 4LL * num_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, s, d);
     DRS_CHECK_HIP(hipGetLastError());

@@ -165,6 +165,17 @@ __device__ __forceinline__ void drs_sp_split8(const float (&v)[8], u32x4& hi, u3
   hi = __builtin_bit_cast(u32x4, h);
   lo = __builtin_bit_cast(u32x4, l);
 }
+typedef __bf16 drs_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void drs_sp_split4(const float (&v)[4], unsigned (&hi)[2], unsigned (&lo)[2]) {  // half a slot
+  drs_bf16x4 h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = (__bf16)v[j];
+    l[j] = (__bf16)(v[j] - (float)h[j]);
+  }
+  const uint2 hh = __builtin_bit_cast(uint2, h), ll = __builtin_bit_cast(uint2, l);
+  hi[0] = hh.x; hi[1] = hh.y; lo[0] = ll.x; lo[1] = ll.y;
+}
 __device__ __forceinline__ void drs_sp_join8(const u32x4& hi, const u32x4& lo, float (&v)[8]) {
   const drs_bf16x8 h = __builtin_bit_cast(drs_bf16x8, hi), l = __builtin_bit_cast(drs_bf16x8, lo);
 #pragma unroll
