@@ -560,8 +560,18 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide2_kernel(AttnGateDesc d)
     Frag wr[NG];
 #pragma unroll
     for (int cc = 0; cc < NG; ++cc) wr[cc] = wfrag(gw_res, wg_img, cc * 4);
-    Frag wq[2];  // weight ring of the current phase: one step ahead
-    wq[0] = wfrag(gw_gate, gate_img, 0);
+    // weight ring over the item's NCX + 4 + 16 steps (gating chunks, w_g chunks, (tap, chunk) of w_x), WD steps ahead: a
+    // step is 12 - 24 MFMAs (200 - 400 cycles), a fragment comes from L2 (one step ahead, every step waited for it)
+    constexpr int WD = 3, NST = NCX + NG + 4 * NG;
+    Frag wq[WD + 1];
+    auto wstep = [&](int st) __attribute__((always_inline)) {
+      if (st < NCX) return wfrag(gw_gate, gate_img, st * 4);
+      if (st < NCX + NG) return wfrag(gw_wg, wg_img, (st - NCX) * 4);
+      const int t4 = (st - NCX - NG) / NG, cc = (st - NCX - NG) % NG;
+      return wfrag(gw_wx, wx_img, (cc * 4 + t4) * 4);
+    };
+#pragma unroll
+    for (int st = 0; st < WD; ++st) wq[st] = wstep(st);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int e = i * 512 + tid, pix = e / (8 * NCX), c = (e / 8) % NCX, sl = e & 7, pb = pix >> 4, pl = pix & 15;
@@ -574,12 +584,11 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide2_kernel(AttnGateDesc d)
     for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NCX; ++c) {
-      if (c + 1 < NCX) wq[(c + 1) & 1] = wfrag(gw_gate, gate_img, (c + 1) * 4);
-      else wq[(c + 1) & 1] = wfrag(gw_wg, wg_img, 0);  // first step of the next phase
+      if (c + WD < NST) wq[(c + WD) % (WD + 1)] = wstep(c + WD);
       Frag a[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) a[b] = afrag(sX, NCX, b, c);
-      step4(wq[c & 1], a, acc);
+      step4(wq[c % (WD + 1)], a, acc);
       __builtin_amdgcn_sched_barrier(0);
     }
     {
@@ -605,12 +614,11 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide2_kernel(AttnGateDesc d)
     for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int cc = 0; cc < NG; ++cc) {
-      if (cc + 1 < NG) wq[(NCX + cc + 1) & 1] = wfrag(gw_wg, wg_img, (cc + 1) * 4);
-      else wq[(NCX + cc + 1) & 1] = wfrag(gw_wx, wx_img, 0);
+      if (NCX + cc + WD < NST) wq[(NCX + cc + WD) % (WD + 1)] = wstep(NCX + cc + WD);
       Frag a[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) a[b] = afrag(sG, NG, b, cc);
-      step4(wq[(NCX + cc) & 1], a, acc);
+      step4(wq[(NCX + cc) % (WD + 1)], a, acc);
       __builtin_amdgcn_sched_barrier(0);
     }
     f32x4 att[4][4];
@@ -624,13 +632,12 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide2_kernel(AttnGateDesc d)
       if (t4 + 2 < 4) tap_load(t4 + 2);
 #pragma unroll
       for (int cc = 0; cc < NG; ++cc) {
-        const int st = NCX + NG + t4 * NG + cc;  // running step index: parity of the weight ring
-        if (cc + 1 < NG) wq[(st + 1) & 1] = wfrag(gw_wx, wx_img, ((cc + 1) * 4 + t4) * 4);
-        else if (t4 + 1 < 4) wq[(st + 1) & 1] = wfrag(gw_wx, wx_img, (t4 + 1) * 4);
+        const int st = NCX + NG + t4 * NG + cc;  // running step index: slot of the weight ring
+        if (st + WD < NST) wq[(st + WD) % (WD + 1)] = wstep(st + WD);
         Frag a[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) a[b] = afrag(sX + (t4 & 1) * TB, NG, b, cc);
-        step4(wq[st & 1], a, acc);
+        step4(wq[st % (WD + 1)], a, acc);
         step4(wr[cc], a, att[t4]);
         __builtin_amdgcn_sched_barrier(0);
       }
