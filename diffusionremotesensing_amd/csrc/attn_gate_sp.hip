@@ -20,7 +20,10 @@
 namespace {
 
 template <int NT>  // Ch = 16 * NT output channels everywhere: NT = 2 (Ch = 32), 4 (Ch = 64)
-__global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
+__global__ __launch_bounds__(NT == 2 ? 1024 : 512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
+  // (a 32-channel stage needs 92 registers: 16 waves per CU instead of 8 - the kernel is a chain of memory round trips per
+  // item and wave, with nothing but the other waves of the CU to fill them)
+  constexpr int THREADS = NT == 2 ? 1024 : 512, NW = THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   constexpr int Ch = 16 * NT, NC = NT / 2;  // NC: 32-channel chunks of a Ch-channel tensor
@@ -35,16 +38,16 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
   {
     const int tid = threadIdx.x;
     auto copy = [&](char* dst, const void* src, int bytes) {  // 8 loads in flight per thread (not a round trip per 8 KB)
-      for (int o0 = tid * 16; o0 < bytes; o0 += 8 * 512 * 16) {
+      for (int o0 = tid * 16; o0 < bytes; o0 += 8 * THREADS * 16) {
         u32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int o = o0 + u * 512 * 16;
+          const int o = o0 + u * THREADS * 16;
           if (o < bytes) v[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src) + o);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int o = o0 + u * 512 * 16;
+          const int o = o0 + u * THREADS * 16;
           if (o < bytes) *reinterpret_cast<u32x4*>(dst + o) = v[u];
         }
       }
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
     copy(sWx, d.w_wx, 2 * wx_img);
     copy(sRes, d.w_res, 2 * wg_img);
     // bias vectors: a global load inside an item is a memory round trip on the wave's critical path (five of them per item)
-    for (int i = tid; i < Ch; i += 512) {
+    for (int i = tid; i < Ch; i += THREADS) {
       sB[i] = d.b_gate[i];
       sB[Ch + i] = d.b_wg[i] + d.b_wx[i];
       sB[2 * Ch + i] = d.w_psi[i];
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
   const int bw = (d.LW + 15) / 16;
   const long long nitems = (long long)d.N * d.LH * bw;
   const int OW = 2 * d.LW, OH = 2 * d.LH;
-  for (long long it = (long long)blockIdx.x * 8 + wave; it < nitems; it += (long long)gridDim.x * 8) {
+  for (long long it = (long long)blockIdx.x * NW + wave; it < nitems; it += (long long)gridDim.x * NW) {
     const int xb = (int)(it % bw), y = (int)((it / bw) % d.LH), n = (int)(it / ((long long)bw * d.LH));
     const int px_raw = xb * 16 + lr;
     const bool valid = px_raw < d.LW;
@@ -699,9 +702,10 @@ int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
     if (rc) return rc;
   }
   const long long nitems = (long long)d.N * d.LH * ((d.LW + 15) / 16);
-  long long blocks = num_cu;  // one 8-wave block per CU, persistent over the pixel blocks
-  if (blocks * 8 > nitems) blocks = (nitems + 7) / 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, d);
+  constexpr int nw = NT == 2 ? 16 : 8;
+  long long blocks = num_cu;  // one block per CU, persistent over the pixel blocks
+  if (blocks * nw > nitems) blocks = (nitems + nw - 1) / nw;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nw * 64), lds, s, d);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
