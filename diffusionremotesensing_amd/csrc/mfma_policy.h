@@ -56,7 +56,9 @@ struct PolicyBF16X3 {  // x = hi + lo (both bf16, 16 mantissa bits together): w*
     return Frag{*reinterpret_cast<const bf16x8*>(base + off), *reinterpret_cast<const bf16x8*>(base + img_stride + off)};
   }
   __device__ static f32x4 mma(const Frag& w, const Frag& a, f32x4 c) {
+#ifndef DRS_EXPERIMENT_2MFMA  // (experiment, never shipped: tools/experiment_2mfma.sh drops the w_lo * a_hi product - DESIGN.md section 7)
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, a.hi, c, 0, 0, 0);
+#endif
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, a.lo, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, a.hi, c, 0, 0, 0);
   }
