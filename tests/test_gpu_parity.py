@@ -291,6 +291,24 @@ def test_unet_forward_config2_full_size(dev, model, seeded_sd, impl):
         _assert_close(got[5:6], single.cpu(), 1e-6, "batch independence")
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+def test_unet_forward_rectangular_vs_oracle(dev, model, seeded_sd, impl):
+    """A 96 x 160 image, batch 3: every fused kernel of the default plan engages (the first encoder block's 8 x 16
+    patches, the composite up-sampling stages from 12 x 20 cells, the 128-channel gate with a 4-pixel tail block per row) on
+    shapes where rows != columns, patch counts are not powers of two and pixel blocks are partly outside the tensor."""
+    from diffusionremotesensing_amd import synthetic
+    from oracle import unet_oracle as U
+    model.hip_engine().set_impl(impl)
+    x = synthetic.tensor_normal("rect.x", (3, 3, 96, 160), 0)
+    lr = synthetic.tensor_uniform("rect.lr", (3, 3, 48, 80), 0)
+    t = synthetic.tensor_randint("rect.t", (3,), 1, 1500, 0)
+    with torch.no_grad():
+        want = U.unet_forward(seeded_sd, x, t, lr, 2)
+        got = model(x.to(dev), t.to(dev), lr.to(dev), 2)
+    _assert_close(got, want, _tol(impl), "rectangular forward")
+    model.hip_engine().check_faults()
+
+
 def test_reuse_cond_matches_full(dev, model):
     model.hip_engine().set_impl(IMPLS[-1])
     x, t, lr = golden_inputs("g4", 2, 2, 3, 64, 2, 1500)
