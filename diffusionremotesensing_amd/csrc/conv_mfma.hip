@@ -526,6 +526,7 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((size_t)d.N * d.TH * d.TW == 0) return DRS_OK;
   MfmaGeom g; int bn, rpw, mode; size_t lds;
   geom(d, impl, &g, &bn, &rpw, &mode, &lds);
+  if (mode == MODE_GENERIC && drs_down_sp_supported(d, impl)) return drs_launch_down_sp(d, s);
   if (mode == MODE_GENERIC && drs_conv_s2_sp_supported(d, impl)) return drs_launch_conv_s2_sp(d, s);
   if (mode == MODE_CONVT && drs_convt_sp_supported(d, impl)) return drs_launch_convt_sp(d, s);
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_conv3x3_direct_sp_supported(d, impl))

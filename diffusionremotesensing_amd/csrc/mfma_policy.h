@@ -89,6 +89,8 @@ int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s);
 // 3x3 stride-2 convolution over SP tensors, operands straight from global memory (conv_s2_sp.hip; DRS_S2K=0 disables)
 bool drs_conv_s2_sp_supported(const TapConv& d, int impl);
 int drs_launch_conv_s2_sp(const TapConv& d, hipStream_t s);
+bool drs_down_sp_supported(const TapConv& d, int impl);  // down_sp.hip: the 32- / 64-channel levels with the window staged in LDS
+int drs_launch_down_sp(const TapConv& d, hipStream_t s);
 // 3x3 stride 1 for the shallow layers: weights resident in LDS, operands straight from global memory (conv3x3_direct_sp.hip)
 bool drs_conv3x3_direct_sp_supported(const TapConv& d, int impl);
 int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s);
