@@ -38,6 +38,7 @@ SIGNATURES = {
     "drs_ema_multi": (_I, [_P, _I, C.c_int64, C.c_double, _I, _P]),
     "drs_downblur_scratch_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "drs_downblur_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _Z, _P]),
+    "drs_add_noise_clip_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "drs_aggregate_tiles": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "drs_conv2d_workspace_bytes": (_Z, [_I] * 11),
     "drs_conv2d_nchw": (_I, [_P, _P, _P, _P] + [_I] * 12 + [_P, _Z, _I, _P]),

@@ -110,6 +110,19 @@ float gaussian_box_radius(float radius, int passes) {
   return l + a;
 }
 
+// x (N, C, H, W) += noise (N, H, W, C), clipped to [0, 1]: the device half of the `Gauss_noise=True` step (reference
+// utils.py:15-38: `img += noise.astype(float32)` on the (H, W, C) view, `np.clip(img, 0, 1)`; the noise itself is drawn on the
+// host from the reference's generators).  One float add and the clip per element: bit-exact with numpy's.
+__global__ __launch_bounds__(256) void add_noise_clip_kernel(float* __restrict__ x, const float* __restrict__ noise, int C,
+                                                             long long hw, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i % hw, nc = i / hw;
+    const int c = (int)(nc % C);
+    const long long n = nc / C;
+    const float v = x[i] + noise[(n * hw + p) * C + c];
+    x[i] = fminf(fmaxf(v, 0.f), 1.f);
+  }
+}
 }  // namespace
 
 extern "C" size_t drs_downblur_scratch_bytes(int N, int C, int H, int W, int out_h, int out_w) {
@@ -173,6 +186,17 @@ extern "C" int drs_downblur_u8(const uint8_t* hr, int N, int C, int H, int W, in
                      planes * out_h * out_w);
   if (y_hr)
     hipLaunchKernelGGL(u8_to_unit_float_kernel, dim3(blocks_for(planes * H * W)), dim3(256), 0, s, hr, y_hr, planes * H * W);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+extern "C" int drs_add_noise_clip_f32(float* x, const float* noise_nhwc, int N, int C, int H, int W, drs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DRS_REQUIRE(x && noise_nhwc, DRS_ERR_ARG, "add_noise_clip: null pointer");
+  DRS_REQUIRE(N >= 0 && C >= 1 && H >= 1 && W >= 1, DRS_ERR_SHAPE, "add_noise_clip: N=%d C=%d H=%d W=%d", N, C, H, W);
+  const long long hw = (long long)H * W, total = (long long)N * C * hw;
+  if (total == 0) return DRS_OK;
+  hipLaunchKernelGGL(add_noise_clip_kernel, dim3(blocks_for(total)), dim3(256), 0, s, x, noise_nhwc, C, hw, total);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -8,11 +8,16 @@ the same pair, bit for bit, for a whole batch (tests/test_gpu_degradation.py aga
 Kept from the reference: the `(y.size[0] // m, y.size[1] // m)` size expression, which hands (W // m, H // m) to a
 (height, width) argument (non-square images come out transposed in size, utils.py:141-142), and `blur_radius='random'`
 being drawn ONCE per dataset object with `random.triangular(0.5, 1.5, 1)` (quirk Q10, utils.py:151-152).
-Not covered: `Gauss_noise=True` (host numpy RNG noise, utils.py:15-38) and the BSRGAN degradation.
+`Gauss_noise=True` (Degradation_type DownBlurNoise, utils.py:15-38,163-164): the noise comes from the host generators the
+reference uses (Python `random` for the level, numpy's global generator for everything else) drawn in its order, item by
+item (`reference_noise`); the add and the clip run on the device (`drs_add_noise_clip_f32`).  Seeded alike, the feed
+reproduces the reference's items bit for bit (tests/test_gpu_degradation.py, fixtures from the reference function itself).
+Not covered: the BSRGAN degradation.
 """
 import ctypes as C
 import random
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -41,12 +46,55 @@ def downblur(hr_u8, magnification_factor, blur_radius):
     return x, y
 
 
+def reference_noise(c, h, w, noise_level1=2, noise_level2=25):
+    """The noise term `add_Gaussian_noise` (utils.py:15-38) adds to ONE (c, h, w) image, as an (h, w, c) float32 array,
+    consuming Python's `random` and numpy's global generator exactly as the reference does: one `random.randint` for the
+    level, one `np.random.rand` for the branch, then the branch's draws - white noise per channel (> 0.6), one plane for
+    all channels (< 0.4), or 3-channel noise with a random covariance scaled by noise_level2.  The two 3-channel branches
+    need c == 3, as in the reference (numpy raises on the broadcast)."""
+    from scipy.linalg import orth
+    level = random.randint(noise_level1, noise_level2)
+    draw = np.random.rand()
+    if draw > 0.6:
+        noise = np.random.normal(0, level / 255.0, (h, w, c)).astype(np.float32)
+    elif draw < 0.4:
+        noise = np.broadcast_to(np.random.normal(0, level / 255.0, (h, w, 1)).astype(np.float32), (h, w, c))
+    else:
+        if c != 3:
+            raise ValueError(f"operands could not be broadcast together with shapes ({h},{w},{c}) ({h},{w},3)")
+        scale = noise_level2 / 255.
+        diag = np.diag(np.random.rand(3))
+        basis = orth(np.random.rand(3, 3))
+        cov = np.dot(np.dot(np.transpose(basis), diag), basis)
+        noise = np.random.multivariate_normal([0, 0, 0], np.abs(scale ** 2 * cov), (h, w)).astype(np.float32)
+    return np.ascontiguousarray(noise)
+
+
+def add_reference_noise(x, noise_level1=2, noise_level2=10):
+    """In place: x (N, C, H, W) float32 on the device += the reference's noise, item by item in batch order, clipped to
+    [0, 1] (the dataset item's `add_Gaussian_noise(x, noise_level1=2, noise_level2=10)`, utils.py:163-164)."""
+    lib = _lib.load()
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+        raise RuntimeError("add_reference_noise: x must be a contiguous (N, C, H, W) float32 tensor on a ROCm device")
+    n, c, h, w = x.shape
+    if n == 0:
+        return x
+    noise = np.stack([reference_noise(c, h, w, noise_level1, noise_level2) for _ in range(n)])
+    nd = torch.from_numpy(noise).to(x.device)
+    with torch.cuda.device(x.device):
+        st = lib.drs_add_noise_clip_f32(C.c_void_p(x.data_ptr()), C.c_void_p(nd.data_ptr()), n, c, h, w,
+                                        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    _lib.check(st, "drs_add_noise_clip_f32")
+    return x
+
+
 class DeviceSuperresFeed:
     """Iterable of (lr, hr) float batches drawn from a uint8 HR cache on the device: what
     `DataLoader(get_data_superres(root, magnification_factor, blur_radius), batch_size, shuffle)` yields, without
     the per-item PIL work.  `hr_u8`: (L, C, H, W) uint8 on the device (the decoded dataset)."""
 
-    def __init__(self, hr_u8, magnification_factor, blur_radius=0.5, batch_size=16, shuffle=True, generator=None):
+    def __init__(self, hr_u8, magnification_factor, blur_radius=0.5, batch_size=16, shuffle=True, generator=None,
+                 Gauss_noise=False):
         self.hr = hr_u8
         self.magnification_factor = magnification_factor
         if blur_radius == "random":  # drawn once per dataset object, like the reference
@@ -55,6 +103,7 @@ class DeviceSuperresFeed:
         self.batch_size = batch_size
         self.shuffle = shuffle
         self.generator = generator
+        self.Gauss_noise = Gauss_noise  # reference get_data_superres(..., Gauss_noise): levels 2 .. 10 per item
 
     def __len__(self):
         return (self.hr.shape[0] + self.batch_size - 1) // self.batch_size
@@ -64,4 +113,7 @@ class DeviceSuperresFeed:
         order = torch.randperm(n, generator=self.generator) if self.shuffle else torch.arange(n)
         order = order.to(self.hr.device)
         for i in range(0, n, self.batch_size):
-            yield downblur(self.hr[order[i:i + self.batch_size]], self.magnification_factor, self.blur_radius)
+            x, y = downblur(self.hr[order[i:i + self.batch_size]], self.magnification_factor, self.blur_radius)
+            if self.Gauss_noise:
+                add_reference_noise(x, noise_level1=2, noise_level2=10)
+            yield x, y

@@ -324,8 +324,9 @@ def launch(args):
         # Pillow on the host) from a uint8 HR cache on the device, bit-exact (degradation.py); rank r owns every
         # world-th image like DistributedSampler
         from .degradation import DeviceSuperresFeed
-        if args.Degradation_type.lower() != "downblur":
-            raise NotImplementedError("the on-device feed implements Degradation_type=DownBlur")
+        if args.Degradation_type.lower() not in ("downblur", "downblurnoise"):
+            raise NotImplementedError("the on-device feed implements Degradation_type=DownBlur and DownBlurNoise")
+        gauss_noise = args.Degradation_type.lower() == "downblurnoise"  # (reference :612-616: Gauss_noise=True)
         radius = args.Blur_radius if args.Blur_radius == "random" else float(args.Blur_radius)
         r, wsz = (drs_dist.rank(), drs_dist.world_size()) if args.multiple_gpus else (0, 1)
 
@@ -336,7 +337,8 @@ def launch(args):
             if per_rank == 0:
                 raise ValueError(f"dataset of {len(ds)} images cannot be sharded over {wsz} ranks")
             u8 = (ds.hr[r::wsz][:per_rank] * 255).round().clamp(0, 255).to(torch.uint8).to(device)
-            return DeviceSuperresFeed(u8, args.magnification_factor, radius, args.batch_size, shuffle=True)
+            return DeviceSuperresFeed(u8, args.magnification_factor, radius, args.batch_size, shuffle=True,
+                                      Gauss_noise=gauss_noise)
         train_loader, val_loader = feed(train_dataset), feed(val_dataset)
     elif args.multiple_gpus:
         train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=False,

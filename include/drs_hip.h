@@ -131,6 +131,12 @@ size_t drs_downblur_scratch_bytes(int N, int C, int H, int W, int out_h, int out
 int drs_downblur_u8(const uint8_t* hr, int N, int C, int H, int W, int out_h, int out_w, float blur_radius, float* x_lr,
                     float* y_hr, void* scratch, size_t scratch_bytes, drs_stream_t stream);
 
+/* The device half of the dataset item's `Gauss_noise=True` step: x (N,C,H,W) float32 += noise (N,H,W,C) float32, clipped to
+ * [0, 1], in place.  The noise is drawn on the host from the generators the reference uses (Python `random`, numpy's global
+ * generator), in its order, by diffusionremotesensing_amd.degradation.reference_noise.
+ * Replaces the add and the clip of add_Gaussian_noise, utils.py:27-36 (called at utils.py:163-164). */
+int drs_add_noise_clip_f32(float* x, const float* noise_nhwc, int N, int C, int H, int W, drs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (used by the parity tests for every convolution flavour
  * the UNet contains, at arbitrary/ragged shapes)

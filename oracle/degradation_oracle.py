@@ -110,3 +110,31 @@ def downblur(hr_u8, out_h, out_w, blur_radius):
     returns (x, y) float32 in [0, 1]."""
     lr = gaussian_blur_u8(resize_bicubic_u8(hr_u8, out_h, out_w), blur_radius)
     return lr.astype(np.float32) / np.float32(255), hr_u8.astype(np.float32) / np.float32(255)
+
+
+def add_gaussian_noise(img_chw, noise_level1=2, noise_level2=25):
+    """The `Gauss_noise=True` step of the dataset item (reference utils.py:15-38, called at :163-164 with levels 2 and 10)
+    for ONE (C, H, W) float32 image in [0, 1].  Randomness comes, in this order, from Python's `random` (the level) and
+    from numpy's global generator (the branch draw, then the branch's own draws); the caller seeds both.  Three branches:
+    per-channel white noise (draw > 0.6), one noise plane shared by the channels (draw < 0.4), or noise with a random
+    3 x 3 channel covariance whose scale is tied to noise_level2 (otherwise).  Noise is rounded to float32 before it is
+    added, the sum is clipped to [0, 1].  Returns a new (C, H, W) float32 array."""
+    import random
+
+    from scipy.linalg import orth
+
+    level = random.randint(noise_level1, noise_level2)
+    draw = np.random.rand()
+    hwc = np.ascontiguousarray(np.transpose(np.asarray(img_chw, dtype=np.float32), (1, 2, 0))).copy()
+    h, w = hwc.shape[:2]
+    if draw > 0.6:
+        hwc += np.random.normal(0, level / 255.0, hwc.shape).astype(np.float32)
+    elif draw < 0.4:
+        hwc += np.random.normal(0, level / 255.0, (h, w, 1)).astype(np.float32)
+    else:
+        scale = noise_level2 / 255.
+        diag = np.diag(np.random.rand(3))
+        basis = orth(np.random.rand(3, 3))
+        cov = np.dot(np.dot(np.transpose(basis), diag), basis)
+        hwc += np.random.multivariate_normal([0, 0, 0], np.abs(scale ** 2 * cov), (h, w)).astype(np.float32)
+    return np.ascontiguousarray(np.transpose(np.clip(hwc, 0.0, 1.0), (2, 0, 1))).astype(np.float32)

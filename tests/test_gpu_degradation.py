@@ -1,4 +1,5 @@
-"""drs_downblur_u8 (on-device DownBlur data feed) against Pillow fixtures and the integer oracle: bit-exact."""
+"""drs_downblur_u8 / drs_add_noise_clip_f32 (on-device DownBlur and DownBlurNoise data feed) against Pillow fixtures, the
+integer oracle and the reference-pinned noise oracle: bit-exact."""
 import os
 
 import numpy as np
@@ -51,15 +52,49 @@ def test_downblur_batch_full_size_vs_oracle(dev):
         downblur(torch.from_numpy(hr), 2, 0.5)  # CPU tensor: no fallback
 
 
-def test_cli_launch_with_device_feed(dev, tmp_path, monkeypatch):
-    """`python -m ...train_diffusion_superres` (reference CLI flags) end to end on the on-device DownBlur feed:
-    one epoch, validation, snapshot in the reference's format, final sampling."""
+def test_gauss_noise_feed_matches_reference_items(dev):
+    """Degradation_type=DownBlurNoise: seeded like the reference's process (Python `random`, numpy's global generator),
+    the feed's items equal `add_Gaussian_noise(downblur item, 2, 10)` bit for bit, item by item in batch order - all three
+    noise branches occur among the 12 items.  The oracle is pinned to the reference function itself
+    (tests/test_oracle_golden.py, tests/golden/degradation_noise_golden.npz)."""
+    import random
+    from diffusionremotesensing_amd.degradation import DeviceSuperresFeed, add_reference_noise
+    from oracle import degradation_oracle as G
+    rng = np.random.default_rng(11)
+    hr = rng.integers(0, 256, (12, 3, 64, 48), dtype=np.uint8)
+    feed = DeviceSuperresFeed(torch.from_numpy(hr).to(dev), 2, blur_radius=0.8, batch_size=5, shuffle=False, Gauss_noise=True)
+    random.seed(3)
+    np.random.seed(3)
+    got = [b[0].cpu() for b in feed]
+    random.seed(3)
+    np.random.seed(3)
+    wx, _ = G.downblur(hr, 24, 32, 0.8)  # (the reference's transposed size expression: (W // m, H // m) as (h, w))
+    branches = set()
+    want = []
+    for i in range(12):
+        state = (random.getstate(), np.random.get_state())
+        random.randint(2, 10)
+        r = np.random.rand()
+        branches.add("color" if r > 0.6 else ("gray" if r < 0.4 else "cov"))
+        random.setstate(state[0])
+        np.random.set_state(state[1])
+        want.append(G.add_gaussian_noise(wx[i], 2, 10))
+    assert branches == {"color", "gray", "cov"}
+    assert torch.equal(torch.cat(got), torch.from_numpy(np.stack(want)))
+    with pytest.raises(RuntimeError):
+        add_reference_noise(torch.zeros(1, 3, 4, 4))  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("degradation", ["DownBlur", "DownBlurNoise"])
+def test_cli_launch_with_device_feed(dev, tmp_path, monkeypatch, degradation):
+    """`python -m ...train_diffusion_superres` (reference CLI flags) end to end on the on-device DownBlur feed (with and
+    without the Gauss_noise step): one epoch, validation, snapshot in the reference's format, final sampling."""
     from diffusionremotesensing_amd import train_diffusion_superres as T
     monkeypatch.chdir(tmp_path)
     torch.manual_seed(0)
     T.main(["--epochs", "1", "--batch_size", "4", "--image_size", "32", "--model_name", "cli_test", "--noise_steps", "10",
             "--loss", "MSE", "--magnification_factor", "2", "--dataset_path", "synthetic_u8:8", "--Degradation_type",
-            "DownBlur", "--Blur_radius", "random", "--check_preds_epoch", "1", "--ema_smoothing", "True"])
+            degradation, "--Blur_radius", "random", "--check_preds_epoch", "1", "--ema_smoothing", "True"])
     snap = torch.load(tmp_path / "models_run" / "cli_test" / "weights" / "snapshot.pt")
     assert set(snap) == {"MODEL_STATE", "EPOCHS_RUN"} and len(snap["MODEL_STATE"]) == 299
     res = torch.load(tmp_path / "models_run" / "cli_test" / "results" / "superres_results.pt")

@@ -166,3 +166,46 @@ def test_degradation_oracle_matches_pillow_fixtures():
         assert np.array_equal(y, planes.astype(np.float32) / np.float32(255))
     # Gaussian radius -> box radius: values of BoxBlur.c's float formula
     assert abs(float(G.gaussian_box_radius(0.5)) - 0.0) < 0.3 and float(G.gaussian_box_radius(1.5)) > 0.9
+
+
+def test_gauss_noise_oracle_matches_reference_function():
+    """The oracle's `Gauss_noise=True` step against outputs of the reference's own add_Gaussian_noise (utils.py:15-38) on
+    seeded inputs, one per branch (tools/make_golden_degradation_noise.py): bit-exact, so the generators are consumed in
+    the reference's order."""
+    import os
+    import random
+    from oracle import degradation_oracle as G
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "degradation_noise_golden.npz")))
+    for kind in ("color", "gray", "cov"):
+        seed = int(g[kind + "_seed"])
+        random.seed(seed)
+        np.random.seed(seed)
+        got = G.add_gaussian_noise(g[kind + "_in"], 2, 10)
+        assert got.dtype == np.float32 and np.array_equal(got, g[kind + "_out"]), kind
+        assert got.min() >= 0.0 and got.max() <= 1.0
+
+
+def test_feed_noise_term_consumes_the_generators_like_the_oracle():
+    """Host half of the on-device DownBlurNoise feed (no GPU): `reference_noise` draws from Python's `random` and numpy's
+    global generator exactly as the oracle does - x + noise, clipped, equals the oracle's item, and both leave the
+    generators in the same state (so a batch of items stays aligned)."""
+    import random
+    from diffusionremotesensing_amd.degradation import reference_noise
+    from oracle import degradation_oracle as G
+    rng = np.random.default_rng(5)
+    for seed in range(8):
+        x = rng.random((3, 10, 14), dtype=np.float32)
+        random.seed(seed)
+        np.random.seed(seed)
+        want = G.add_gaussian_noise(x, 2, 10)
+        after_oracle = (random.random(), np.random.rand())
+        random.seed(seed)
+        np.random.seed(seed)
+        noise = reference_noise(3, 10, 14, 2, 10)
+        after_feed = (random.random(), np.random.rand())
+        hwc = np.transpose(x, (1, 2, 0)).copy()
+        hwc += noise
+        got = np.transpose(np.clip(hwc, 0.0, 1.0), (2, 0, 1))
+        assert noise.shape == (10, 14, 3) and noise.dtype == np.float32
+        assert np.array_equal(got, want), seed
+        assert after_oracle == after_feed, seed
