@@ -12,12 +12,13 @@
 #ifndef DRS_WT_STORES
 #define DRS_WT_STORES 0
 #endif
-#ifdef DRS_SP_TIMELINE
-static __device__ int drs_tl_nostore;  // timeline builds (one copy per translation unit): 1 = the epilogues compute, but do not store
-#endif
+// Experiment switches (tools/build_variant.sh NAME "-DDRS_X_...=1"; never defined in the shipped build): what an item
+// epilogue costs without its stores / bias-ReLU-add arithmetic / hi | lo split / lane swap.  Compile-time on purpose: a
+// run-time switch read from memory inside the epilogue costs more than what it switches off.
 __device__ __forceinline__ void drs_store16(void* p, const u32x4& v) {
-#ifdef DRS_SP_TIMELINE
-  if (drs_tl_nostore) { asm volatile("" :: "v"(v), "v"(p)); return; }
+#ifdef DRS_X_NOSTORE
+  asm volatile("" :: "v"(v), "v"(p));
+  return;
 #endif
 #if DRS_WT_STORES
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
@@ -310,8 +311,7 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
   const bool lo = lr < 8;
   const int pl = lr & 7;
   // (the two optional ReLUs as max(v, bound) with a launch-uniform bound, 0 or -inf: one instruction per value instead of a
-  // max and a select on the flag - the item epilogue is VALU-bound: ~600 vector instructions per wave and item, both
-  // consumer waves of a SIMD at once, 6.4 k cycles per item with the matrix pipe idle)
+  // max and a select on the flag)
   const float lo_pre = d.relu_pre ? 0.f : -__builtin_inff(), lo_post = d.relu_post ? 0.f : -__builtin_inff();
   const int tyb = ty0 + wave * RPW;
   const size_t pix0 = ((size_t)n * d.OH + tyb) * d.OW + tx0 + pl;  // (out_scale 1, no phase offset: 3x3 stride 1)
@@ -329,12 +329,26 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
       for (int j = 0; j < 4; ++j) { v[j] = acc[r][0][j] + k.bias[j]; v[4 + j] = acc[r][1][j] + k.bias[4 + j]; }
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaxf(v[j], lo_pre) + k.post[j], lo_post);
+#ifdef DRS_X_NOAFFINE
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = acc[r][0][j]; v[4 + j] = acc[r][1][j]; }
+#endif
       auto put = [&](char* g, int hb, const float (&w8)[8]) __attribute__((always_inline)) {
         u32x4 H, L;
+#ifdef DRS_X_NOSPLIT
+        H = u32x4{__float_as_uint(w8[0]), __float_as_uint(w8[1]), __float_as_uint(w8[2]), __float_as_uint(w8[3])};
+        L = u32x4{__float_as_uint(w8[4]), __float_as_uint(w8[5]), __float_as_uint(w8[6]), __float_as_uint(w8[7])};
+#else
         drs_sp_split8(w8, H, L);
+#endif
+#ifdef DRS_X_NOSWAP
+        if (ok0) drs_store16(g, H);
+        if (ok1) drs_store16(g + hb, L);
+#else
         const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo
         if (ok0) drs_store16(g, lo ? H : got);
         if (ok1) drs_store16(g + hb, lo ? got : L);
+#endif
       };
       if (o1) put(o1 + r * row1, h1, v);
       if constexpr (OUT2) {
