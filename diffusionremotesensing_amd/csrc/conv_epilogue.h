@@ -20,7 +20,11 @@ __device__ __forceinline__ void drs_store16(void* p, const u32x4& v) {
   asm volatile("" :: "v"(v), "v"(p));
   return;
 #endif
-#if DRS_WT_STORES
+#if DRS_WT_STORES == 2  // experiment: non-temporal
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif DRS_WT_STORES == 3  // experiment: system-coherent write-through
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif DRS_WT_STORES
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
   *reinterpret_cast<u32x4*>(p) = v;
