@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
         FuseEpiConst kc;
         kc.b0 = *reinterpret_cast<const float4*>(sBias + kg * 4);
         kc.b1 = *reinterpret_cast<const float4*>(sBias + 16 + kg * 4);
-        const int m = min(lr, 3);
+        const int m = min(lr >> 2, 3);  // (row lr of the projection operand = channel lr >> 2: fuse_epilogue_mfma_pre)
         const float4 w0 = *reinterpret_cast<const float4*>(sBias + 32 + m * 32 + kg * 4);
         const float4 w1 = *reinterpret_cast<const float4*>(sBias + 32 + m * 32 + 16 + kg * 4);
         kc.w8[0] = w0.x; kc.w8[1] = w0.y; kc.w8[2] = w0.z; kc.w8[3] = w0.w;

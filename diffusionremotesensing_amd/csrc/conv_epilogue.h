@@ -427,7 +427,10 @@ __device__ __forceinline__ void fuse_epilogue_mfma_pre(const TapConv& d, f32x4 (
   typename P::Frag wfr;
   {
     float w8[8];
-    const float keep = lr < d.fuse_dim ? 1.f : 0.f;
+    // output channel j sits in MFMA row 4 * j (the caller hands row lr the weights of channel lr >> 2): its results land in
+    // register 0 of the lanes of k-group j, so ONE store instruction writes all fuse_dim planes (48 lanes) instead of one
+    // 16-lane instruction per plane - a store costs its wave ~250 cycles under load, whatever it carries
+    const float keep = ((lr & 3) == 0 && (lr >> 2) < d.fuse_dim) ? 1.f : 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) w8[j] = k.w8[j] * keep;
     u32x4 h, l;
@@ -451,12 +454,10 @@ __device__ __forceinline__ void fuse_epilogue_mfma_pre(const TapConv& d, f32x4 (
     u32x4 h, l;
     drs_sp_split8(v, h, l);
     const typename P::Frag vf{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
-    const f32x4 y = P::mma(wfr, vf, f32x4{0.f, 0.f, 0.f, 0.f});  // lanes of k-group 0: outputs 0..3 of pixel lr
-    if (valid && kg == 0) {
-      float* o = d.fuse_out + (size_t)n * d.fuse_dim * plane + (size_t)oy * d.OW + ox;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < d.fuse_dim) o[(size_t)j * plane] = y[j] + k.fb[j];
+    const f32x4 y = P::mma(wfr, vf, f32x4{0.f, 0.f, 0.f, 0.f});  // register 0 of the lanes of k-group j: output j of pixel lr
+    if (valid && kg < d.fuse_dim) {
+      const float fbk = kg == 0 ? k.fb[0] : kg == 1 ? k.fb[1] : kg == 2 ? k.fb[2] : k.fb[3];
+      d.fuse_out[((size_t)n * d.fuse_dim + kg) * plane + (size_t)oy * d.OW + ox] = y[0] + fbk;
     }
   }
 }
@@ -469,7 +470,7 @@ __device__ __forceinline__ void fuse_epilogue_mfma(const TapConv& d, f32x4 (&acc
     k.b0 = *reinterpret_cast<const float4*>(d.bias + n0 + kg * 4);
     k.b1 = *reinterpret_cast<const float4*>(d.bias + n0 + 16 + kg * 4);
   }
-  const int m = min(lr, d.fuse_dim - 1);
+  const int m = min(lr >> 2, d.fuse_dim - 1);  // (row lr of the projection operand = channel lr >> 2: fuse_epilogue_mfma_pre)
   const float4 w0 = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)m * d.Cout + n0 + kg * 4);
   const float4 w1 = *reinterpret_cast<const float4*>(d.fuse_w + (size_t)m * d.Cout + n0 + 16 + kg * 4);
   k.w8[0] = w0.x; k.w8[1] = w0.y; k.w8[2] = w0.z; k.w8[3] = w0.w; k.w8[4] = w1.x; k.w8[5] = w1.y; k.w8[6] = w1.z; k.w8[7] = w1.w;

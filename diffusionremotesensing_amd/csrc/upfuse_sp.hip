@@ -447,10 +447,12 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         typename P::Frag wfr;
         float fb[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (FUSE) {
-          // A operand of the projection: row lr = fuse_w[lr][this lane's 8 channels] (rows >= fuse_dim are zero)
+          // A operand of the projection: row 4 * j = fuse_w[j][this lane's 8 channels], every other row zero: output j of
+          // pixel lr lands in register 0 of the lane of k-group j, and all fuse_dim planes go out in ONE store instruction
+          // (and come in, for the projected att-half, in one load): a store costs its wave ~250 cycles, whatever it carries
           float w8[8];
-          load8(sConst + 256 + min(lr_e, 3) * 32 + c8, w8);
-          const float keep = lr_e < d.fuse_dim ? 1.f : 0.f;
+          load8(sConst + 256 + min(lr_e >> 2, 3) * 32 + c8, w8);
+          const float keep = ((lr_e & 3) == 0 && (lr_e >> 2) < d.fuse_dim) ? 1.f : 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) w8[j] *= keep;
           u32x4 h, l;
@@ -469,25 +471,23 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         UF_STAMP(8);
         const int lane_b = (lo ? 0 : 64) + kg_e * 16;
         // fused projection on top of the projected att-half already in fuse_out: its values, loaded before the first store
-        float prev[FUSE ? RPW : 1][2][4];
+        float prev[FUSE ? RPW : 1][2];  // (this lane's plane: k-group kg_e)
+        float fbk = 0.f;
         if constexpr (FUSE) {
           const size_t plane = (size_t)OH * OW;
+          fbk = kg_e == 0 ? fb[0] : kg_e == 1 ? fb[1] : kg_e == 2 ? fb[2] : fb[3];
 #pragma unroll
           for (int r = 0; r < RPW; ++r)
 #pragma unroll
-            for (int py = 0; py < 2; ++py)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                prev[r][py][j] = 0.f;
-                if (d.fuse_acc && own_ok && kg_e == 0 && j < d.fuse_dim && myb + r < d.LH)
-                  prev[r][py][j] = d.fuse_out[((size_t)n * d.fuse_dim + j) * plane + (size_t)(2 * (myb + r) + py) * OW + ox_own];
-              }
+            for (int py = 0; py < 2; ++py) {
+              prev[r][py] = 0.f;
+              if (d.fuse_acc && own_ok && kg_e < d.fuse_dim && myb + r < d.LH)
+                prev[r][py] = d.fuse_out[((size_t)n * d.fuse_dim + kg_e) * plane + (size_t)(2 * (myb + r) + py) * OW + ox_own];
+            }
 #pragma unroll
           for (int r = 0; r < RPW; ++r)  // (consumed unconditionally, like the constants above: no load may stay formally pending)
-#pragma unroll
-            for (int py = 0; py < 2; ++py) asm volatile("" :: "v"(prev[r][py][0]), "v"(prev[r][py][1]), "v"(prev[r][py][2]), "v"(prev[r][py][3]));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fb[j]));
+            asm volatile("" :: "v"(prev[r][0]), "v"(prev[r][1]));
+          asm volatile("" :: "v"(fbk));
           asm volatile("" :: "v"(wfr.hi), "v"(wfr.lo));
         }
 #pragma unroll
@@ -504,16 +504,13 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
                 u32x4 h, l;
                 drs_sp_split8(v, h, l);
                 const typename P::Frag vf{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
-                const f32x4 y = P::mma(wfr, vf, f32x4{0.f, 0.f, 0.f, 0.f});  // lanes of k-group 0: outputs 0..3 of pixel lr
+                const f32x4 y = P::mma(wfr, vf, f32x4{0.f, 0.f, 0.f, 0.f});  // register 0 of the lane of k-group j: output j of pixel lr
 #ifdef DRS_SP_TIMELINE
                 if (debug & 1) { asm volatile("" :: "v"(y)); } else
 #endif
-                if (own_ok && kg_e == 0) {
+                if (own_ok && kg_e < d.fuse_dim) {
                   const size_t plane = (size_t)OH * OW;
-                  float* o = d.fuse_out + (size_t)n * d.fuse_dim * plane + (size_t)oy * OW + ox_own;
-#pragma unroll
-                  for (int j = 0; j < 4; ++j)
-                    if (j < d.fuse_dim) o[(size_t)j * plane] = y[j] + fb[j] + prev[r][py][j];
+                  d.fuse_out[((size_t)n * d.fuse_dim + kg_e) * plane + (size_t)oy * OW + ox_own] = y[0] + fbk + prev[r][py];
                 }
               } else {
                 // SP stores in full 128-byte lines: lanes lr < 8 write hi slots, lanes lr >= 8 lo slots, of cells pl and pl + 8
