@@ -136,12 +136,12 @@ def _build_workload(wl, impl, dev, rank, multi):
         d = Diffusion("cosine", m, "/nonexistent/snapshot.pt", noise_steps=1000, device=dev, image_size=128)
         x = synthetic.tensor_normal("sar.x", (32, 1, 128, 128), seed=rank).to(dev)
         sar = synthetic.tensor_uniform("sar.sar", (32, 2, 128, 128), seed=rank).to(dev)
-        t = torch.empty(32, dtype=torch.int64, device=dev)
+        t_rows = hip_ops.timestep_table(1000, 32, dev)
         state = {"i": 999, "first": True}
 
         def step():
             i = max(state["i"], 2)
-            eps = m.hip_engine().forward(x, t.fill_(i), sar, 1, reuse_cond=not state["first"], check_weights=state["first"])
+            eps = m.hip_engine().forward(x, t_rows[i], sar, 1, reuse_cond=not state["first"], check_weights=state["first"])
             hip_ops.sampler_step_(x, eps, torch.randn_like(x), i, d.alpha, d.alpha_hat, d.beta)
             state["i"] -= 1
             state["first"] = False
@@ -157,12 +157,12 @@ def _build_workload(wl, impl, dev, rank, multi):
     x = synthetic.tensor_normal("gen.x", (64, 3, 64, 64), seed=rank).to(dev)
     labels2 = torch.cat([synthetic.tensor_randint("gen.y", (64,), 0, 10, seed=rank),
                          torch.full((64,), -1, dtype=torch.int64)]).to(dev)
-    t2 = torch.empty(128, dtype=torch.int64, device=dev)
+    t_rows = hip_ops.timestep_table(1000, 128, dev)
     state = {"i": 999, "first": True}
 
     def step():
         i = max(state["i"], 2)
-        eps2 = m.hip_engine().forward(x.repeat(2, 1, 1, 1), t2.fill_(i), None, 1, labels=labels2,
+        eps2 = m.hip_engine().forward(x.repeat(2, 1, 1, 1), t_rows[i], None, 1, labels=labels2,
                                       check_weights=state["first"])
         hip_ops.sampler_step_cfg_(x, eps2[:64], eps2[64:], 3.0, torch.randn_like(x), i, d.alpha, d.alpha_hat, d.beta)
         state["i"] -= 1
@@ -294,10 +294,10 @@ def main():
     x = x_cpu.to(dev)
     lr = lr_cpu.to(dev)
     t = torch.empty(BATCH, dtype=torch.int64, device=dev)
+    t_rows = hip_ops.timestep_table(T_STEPS, BATCH, dev)  # what Diffusion.sample uses: a row view per step, no fill kernel
 
     def step(i, first):
-        t.fill_(i)
-        eps = engine.forward(x, t, lr, MAG, reuse_cond=not first, check_weights=first)
+        eps = engine.forward(x, t_rows[i], lr, MAG, reuse_cond=not first, check_weights=first)
         noise = torch.randn_like(x) if i > 1 else None
         hip_ops.sampler_step_(x, eps, noise, i, diffusion.alpha, diffusion.alpha_hat, diffusion.beta)
 

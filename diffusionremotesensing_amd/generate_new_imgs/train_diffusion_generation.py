@@ -61,8 +61,7 @@ class Diffusion(_SuperresDiffusion):
                 labels2 = torch.cat([target_class.to(torch.int64).expand(n) if target_class.numel() == 1
                                      else target_class.to(torch.int64), torch.full((n,), -1, dtype=torch.int64,
                                                                                    device=x.device)]).contiguous()
-                t2 = torch.empty(2 * n, dtype=torch.int64, device=x.device)
-            t = torch.empty(n, dtype=torch.int64, device=x.device)
+            t_rows = hip_ops.timestep_table(self.noise_steps, 2 * n, x.device)  # (row i: step i; the unguided forward takes n of the 2n)
             first = True
             for i in reversed(range(1, self.noise_steps)):
                 if i > 1:
@@ -70,14 +69,12 @@ class Diffusion(_SuperresDiffusion):
                 else:
                     noise = None
                 if guided:
-                    t2.fill_(i)
-                    eps2 = engine.forward(x.repeat(2, 1, 1, 1), t2, None, 1, labels=labels2, check_weights=first)
+                    eps2 = engine.forward(x.repeat(2, 1, 1, 1), t_rows[i], None, 1, labels=labels2, check_weights=first)
                     hip_ops.sampler_step_cfg_(x, eps2[:n], eps2[n:], cfg_scale, noise, i, self.alpha, self.alpha_hat,
                                               self.beta)
                 else:
-                    t.fill_(i)
                     # cfg_scale > 0 without a class: lerp(u, u, w) == u, one forward is enough
-                    predicted_noise = engine.forward(x, t, None, 1, labels=target_class, check_weights=first)
+                    predicted_noise = engine.forward(x, t_rows[i, :n], None, 1, labels=target_class, check_weights=first)
                     hip_ops.sampler_step_(x, predicted_noise, noise, i, self.alpha, self.alpha_hat, self.beta)
                 first = False
                 if generate_video:

@@ -138,6 +138,13 @@ def noise_images(x0, eps, t, alpha_hat):
     return out
 
 
+def timestep_table(noise_steps, n, device):
+    """(noise_steps, n) int64: row i is the reference's `t = (torch.ones(n) * i).long()` of sampling step i
+    (train_diffusion_superres.py:237) for every step of a chain, built once: a row view per step instead of a fill kernel
+    per step (one launch of ~4 us in a 1.35 ms step)."""
+    return torch.arange(noise_steps, dtype=torch.int64, device=device).unsqueeze(1).expand(noise_steps, n).contiguous()
+
+
 def sampler_step_(x, eps_pred, noise, t, alpha, alpha_hat, beta):
     """In-place ancestral update of x for the scalar timestep t (noise may be None)."""
     lib = _lib.load()

@@ -41,10 +41,10 @@ class Diffusion(_SuperresDiffusion):
         with torch.no_grad():
             x = (noise_source(self.noise_steps, shape) if noise_source is not None else torch.randn(shape)).to(self.device)
             x = x.contiguous()
-            t = torch.empty(n, dtype=torch.int64, device=x.device)
+            t_rows = hip_ops.timestep_table(self.noise_steps, n, x.device)
             first = True
             for i in reversed(range(1, self.noise_steps)):
-                t.fill_(i)
+                t = t_rows[i]
                 predicted_noise = engine.forward(x, t, SAR_img, 1, reuse_cond=not first, check_weights=first)
                 first = False
                 if i > 1:

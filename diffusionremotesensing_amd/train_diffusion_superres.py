@@ -107,10 +107,10 @@ class Diffusion:
             else:
                 x = torch.randn(shape).to(self.device)  # CPU generator, like the reference (:230)
             x = x.contiguous()
-            t = torch.empty(n, dtype=torch.int64, device=x.device)
+            t_rows = hip_ops.timestep_table(self.noise_steps, n, x.device)
             first = True
             for i in reversed(range(1, self.noise_steps)):
-                t.fill_(i)
+                t = t_rows[i]
                 predicted_noise = engine.forward(x, t, lr_img, self.magnification_factor, reuse_cond=not first,
                                                  check_weights=first)
                 first = False
