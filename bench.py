@@ -184,6 +184,7 @@ def _time_workload(wl, impl, dev, rank, steps, warmup, sync):
             step()
         sync()
         elapsed = time.perf_counter() - t0
+    engine.check_faults()  # (outside the timed region) a forward whose wave-specialised kernels gave up on a counter is not a measurement
     return elapsed, unit, batch, gflop, desc, dtype
 
 
@@ -246,6 +247,15 @@ def other_configs_block(impl, dev):
         gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+def norm_kernel(k):
+    """Kernel name as tools/collect_pmc.py normalises it (template arguments kept, parameter list and qualifiers dropped)."""
+    import re
+    k = k.replace("(anonymous namespace)::", "").replace(" [clone .kd]", "")
+    k = re.sub(r"\.kd$", "", k.strip())
+    k = re.sub(r"^void\s+", "", k)
+    return re.sub(r"\s+", "", k.split("(")[0])
 
 
 def main():
@@ -320,6 +330,7 @@ def main():
             i -= 1
         sync()
         elapsed = time.perf_counter() - t0
+    engine.check_faults()  # (outside the timed region) a forward whose wave-specialised kernels gave up on a counter is not a measurement
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist.is_initialized():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -369,9 +380,20 @@ def main():
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             if args.impl != "mfma_bf16x3":
                 break
-            per_op = json.load(open(tpath)).get("per_op_last_forward") or []
+            pj = json.load(open(tpath))
+            per_op = pj.get("per_op_last_forward") or []
+            if not pj.get("attribution"):
+                continue  # (files older than round 4 zipped op names onto dispatches picked by a hand-kept regex: not used)
             by_name = {e["op"]: e["hbm_read_bytes"] + e["hbm_write_bytes"] for e in per_op}
             if not all(o[0] in by_name for o in ops if o[0] != "lr_branch"):
+                continue
+            # ... and the same kernel behind every op as in this run (the plan's launch log of the profiled forward above)
+            mine = {}
+            for op_, kn_ in engine.last_launch_log:
+                kn_ = norm_kernel(kn_)
+                if op_ and kn_ not in mine.setdefault(op_, []):
+                    mine[op_].append(kn_)
+            if any(" + ".join(mine.get(e["op"], [])) != e["kernel"] for e in per_op if e["op"] != "-" and e["op"] in mine):
                 continue
             tsource = os.path.relpath(tpath, ROOT)
             dom_t = [by_name[o[0]] for o in dom]
@@ -420,7 +442,8 @@ def main():
                     "flops_per_launch": round(dom_fl / len(dom)), "avg_launch_us": round(1e3 * dom_ms / len(dom), 2),
                     "algorithmic_bytes_per_launch": round(dom_by / len(dom)),
                     "traffic": traffic, "traffic_source": (tsource + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per "
-                                                           "op of one forward; op names match this run)") if tsource else None,
+                                                           "op of one forward through the plan's launch log; op names AND the "
+                                                           "kernel behind every op match this run)") if tsource else None,
                     "mfma_instructions_per_product": mfma_per_product,
                     "mfma_pipe_frac": round(mfma_per_product * achieved / peak, 5),
                     "forward_ms_sum_of_ops": round(all_ms, 4), "conv_ms": round(conv_ms, 4),

@@ -67,6 +67,8 @@ SIGNATURES = {
     "drs_unet_profile_enable": (_I, [_P, _I]),
     "drs_unet_profile_num_ops": (_I, [_P]),
     "drs_unet_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "drs_unet_profile_num_launches": (_I, [_P]),
+    "drs_unet_profile_launch": (_I, [_P, _I, C.c_char_p, _I, C.c_char_p, _I]),
 }
 
 _lib = None

@@ -705,7 +705,7 @@ int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
   constexpr int nw = NT == 2 ? 16 : 8;
   long long blocks = num_cu;  // one block per CU, persistent over the pixel blocks
   if (blocks * nw > nitems) blocks = (nitems + nw - 1) / nw;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nw * 64), lds, s, d);
+  DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(nw * 64), lds, s, d);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -770,7 +770,7 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
       const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
       if (rc) return rc;
       const long long blocks = nitems < 4LL * num_cu ? nitems : 4LL * num_cu;
-      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, d);
+      DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds, s, d);
       DRS_CHECK_HIP(hipGetLastError());
       return DRS_OK;
     }
@@ -778,7 +778,7 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
     const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 0, &num_cu);
     if (rc) return rc;
     const long long blocks = nitems < 4LL * num_cu ? nitems : 4LL * num_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, s, d);
+    DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), 0, s, d);
     DRS_CHECK_HIP(hipGetLastError());
     return DRS_OK;
   }
@@ -789,7 +789,7 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
 int drs_launch_gate_bias(const float* w, const float* b, const float* vec, int vec_stride, float* out, int N, int Cc, int Ch,
                          hipStream_t s) {
   if (N * Ch == 0) return DRS_OK;
-  hipLaunchKernelGGL(gate_bias_kernel, dim3((Ch + 63) / 64, N), dim3(256), 0, s, w, b, vec, vec_stride, out, N, Cc, Ch);
+  DRS_LAUNCH(gate_bias_kernel, dim3((Ch + 63) / 64, N), dim3(256), 0, s, w, b, vec, vec_stride, out, N, Cc, Ch);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -106,13 +106,13 @@ int drs_launch_bn_train(const float* z, int z_cs, int z_co, long long npix, long
   // at any size); 512 blocks still cover the chip twice
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, npix, C, z_cs, z_co, sums_scratch);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_scratch, npix, C, eps, momentum, mean,
+  DRS_LAUNCH(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, npix, C, z_cs, z_co, sums_scratch);
+  DRS_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_scratch, npix, C, eps, momentum, mean,
                      rstd, running_mean, running_var);
   long long total = npix * (C >> 2);
   long long ab = (total + 255) / 256;
   if (ab > 8192) ab = 8192;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ab), dim3(256), 0, s, z, z_cs, z_co, mean, rstd, gamma, beta, post_add,
+  DRS_LAUNCH(bn_apply_kernel, dim3((unsigned)ab), dim3(256), 0, s, z, z_cs, z_co, mean, rstd, gamma, beta, post_add,
                      post_cs, res, res_cs, res_co, out, out_cs, out_co, npix, pix_per_image, C, relu_pre, relu_post);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;

@@ -343,7 +343,7 @@ int direct_launch(const TapConv& d, hipStream_t s) {
   const unsigned w_gimage = (unsigned)((size_t)nck * 9 * 4 * CW * 16);
   const unsigned w2_gimage = HAS2 ? (unsigned)((size_t)((d.Cin2 + 31) / 32) * 4 * d.Cout * 16) : 0u;
   const int blocks = num_cu / 8 * 8;  // one block per CU
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), direct_lds_bytes(d), s, d, nck, w_gimage, w2_gimage);
+  DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), direct_lds_bytes(d), s, d, nck, w_gimage, w2_gimage);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

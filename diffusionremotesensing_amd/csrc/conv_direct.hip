@@ -90,16 +90,16 @@ int drs_launch_tapconv_direct(const TapConv& d, hipStream_t s) {
   dim3 block(256);
   if (d.Cout % 16 == 0) {
     dim3 grid((unsigned)((P + 255) / 256), d.Cout / 16);
-    hipLaunchKernelGGL(tapconv_direct_kernel<16>, grid, block, 0, s, d);
+    DRS_LAUNCH(tapconv_direct_kernel<16>, grid, block, 0, s, d);
   } else if (d.Cout % 4 == 0) {
     dim3 grid((unsigned)((P + 255) / 256), d.Cout / 4);
-    hipLaunchKernelGGL(tapconv_direct_kernel<4>, grid, block, 0, s, d);
+    DRS_LAUNCH(tapconv_direct_kernel<4>, grid, block, 0, s, d);
   } else if (d.Cout > 1 && d.Cout < 4) {  // image-channel outputs (2, 3): one pass over the input instead of Cout
     dim3 grid((unsigned)((P + 255) / 256), 1);
-    hipLaunchKernelGGL((tapconv_direct_kernel<4, true>), grid, block, 0, s, d);
+    DRS_LAUNCH((tapconv_direct_kernel<4, true>), grid, block, 0, s, d);
   } else {
     dim3 grid((unsigned)((P + 255) / 256), d.Cout);
-    hipLaunchKernelGGL(tapconv_direct_kernel<1>, grid, block, 0, s, d);
+    DRS_LAUNCH(tapconv_direct_kernel<1>, grid, block, 0, s, d);
   }
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;

@@ -497,7 +497,7 @@ static int launch_t(const TapConv& d, const MfmaGeom& g, size_t lds, hipStream_t
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
   dim3 grid((unsigned)blocks);
-  hipLaunchKernelGGL(kern, grid, dim3(256 * NWG), lds, s, d, g);
+  DRS_LAUNCH(kern, grid, dim3(256 * NWG), lds, s, d, g);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -626,7 +626,7 @@ int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
 #define DRS_PACK(P)                                                                                                   \
-  hipLaunchKernelGGL(pack_conv_mfma_kernel<P>, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps,    \
+  DRS_LAUNCH(pack_conv_mfma_kernel<P>, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps,    \
                      (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps, co_off, partial, perm, \
                      cin_total, cin_off)
   if (impl == DRS_IMPL_MFMA_F32) DRS_PACK(PolicyF32);

@@ -492,7 +492,7 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
   long long blocks = num_cu;  // one 12-wave block per CU
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);
+  DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);
   DRS_CHECK_HIP(hipGetLastError());
 #ifdef DRS_WS_TIMELINE
   {
@@ -501,7 +501,7 @@ int ws_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
     float ms = 0.f;
     DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
     DRS_CHECK_HIP(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);  // timed repeat (same result)
+    DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(768), kLds, s, d, g);  // timed repeat (same result)
     DRS_CHECK_HIP(hipEventRecord(e1, s));
     DRS_CHECK_HIP(hipStreamSynchronize(s));
     DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));

@@ -351,7 +351,7 @@ int s2_launch(const TapConv& d, int nck, unsigned w_gimage, hipStream_t s) {
   int per_xcd = num_cu / 8;                     // one block per CU; blocks of an XCD split into the channel groups
   per_xcd = per_xcd / ngroups * ngroups;
   if (per_xcd < ngroups) per_xcd = ngroups;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * per_xcd)), dim3(512), lds, s, d, nck, w_gimage);
+  DRS_LAUNCH(kern, dim3((unsigned)(8 * per_xcd)), dim3(512), lds, s, d, nck, w_gimage);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -149,7 +149,7 @@ extern "C" int drs_downblur_u8(const uint8_t* hr, int N, int C, int H, int W, in
   const unsigned char* hsrc = hr;
   int cur_w = W;
   if (out_w != W) {
-    hipLaunchKernelGGL(resize_pass_kernel, dim3(blocks_for(planes * H * out_w)), dim3(256), 0, s, hr, tmp, (long long)H, W,
+    DRS_LAUNCH(resize_pass_kernel, dim3(blocks_for(planes * H * out_w)), dim3(256), 0, s, hr, tmp, (long long)H, W,
                        out_w, (long long)W, (long long)out_w, 1LL, 1LL, planes, (long long)H * W, (long long)H * out_w);
     hsrc = tmp;
     cur_w = out_w;
@@ -157,7 +157,7 @@ extern "C" int drs_downblur_u8(const uint8_t* hr, int N, int C, int H, int W, in
   unsigned char* cur = a;
   if (out_h != H) {
     // lines = columns: "rows" = out_w columns, axis stride = row pitch
-    hipLaunchKernelGGL(resize_pass_kernel, dim3(blocks_for(planes * out_w * out_h)), dim3(256), 0, s, hsrc, a, (long long)cur_w,
+    DRS_LAUNCH(resize_pass_kernel, dim3(blocks_for(planes * out_w * out_h)), dim3(256), 0, s, hsrc, a, (long long)cur_w,
                        H, out_h, 1LL, 1LL, (long long)cur_w, (long long)out_w, planes, (long long)H * cur_w,
                        (long long)out_h * out_w);
   } else {
@@ -171,21 +171,21 @@ extern "C" int drs_downblur_u8(const uint8_t* hr, int N, int C, int H, int W, in
       const unsigned fw = ((1u << 24) - (unsigned)(radius * 2 + 1) * ww) / 2;
       unsigned char* other = b;
       for (int pass = 0; pass < 3; ++pass) {  // horizontal
-        hipLaunchKernelGGL(box_pass_kernel, dim3(blocks_for(planes * out_h * out_w)), dim3(256), 0, s, cur, other,
+        DRS_LAUNCH(box_pass_kernel, dim3(blocks_for(planes * out_h * out_w)), dim3(256), 0, s, cur, other,
                            (long long)out_h, out_w, (long long)out_w, 1LL, planes, (long long)out_h * out_w, radius, ww, fw);
         std::swap(cur, other);
       }
       for (int pass = 0; pass < 3; ++pass) {  // vertical
-        hipLaunchKernelGGL(box_pass_kernel, dim3(blocks_for(planes * out_h * out_w)), dim3(256), 0, s, cur, other,
+        DRS_LAUNCH(box_pass_kernel, dim3(blocks_for(planes * out_h * out_w)), dim3(256), 0, s, cur, other,
                            (long long)out_w, out_h, 1LL, (long long)out_w, planes, (long long)out_h * out_w, radius, ww, fw);
         std::swap(cur, other);
       }
     }
   }
-  hipLaunchKernelGGL(u8_to_unit_float_kernel, dim3(blocks_for(planes * out_h * out_w)), dim3(256), 0, s, cur, x_lr,
+  DRS_LAUNCH(u8_to_unit_float_kernel, dim3(blocks_for(planes * out_h * out_w)), dim3(256), 0, s, cur, x_lr,
                      planes * out_h * out_w);
   if (y_hr)
-    hipLaunchKernelGGL(u8_to_unit_float_kernel, dim3(blocks_for(planes * H * W)), dim3(256), 0, s, hr, y_hr, planes * H * W);
+    DRS_LAUNCH(u8_to_unit_float_kernel, dim3(blocks_for(planes * H * W)), dim3(256), 0, s, hr, y_hr, planes * H * W);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -196,7 +196,7 @@ extern "C" int drs_add_noise_clip_f32(float* x, const float* noise_nhwc, int N, 
   DRS_REQUIRE(N >= 0 && C >= 1 && H >= 1 && W >= 1, DRS_ERR_SHAPE, "add_noise_clip: N=%d C=%d H=%d W=%d", N, C, H, W);
   const long long hw = (long long)H * W, total = (long long)N * C * hw;
   if (total == 0) return DRS_OK;
-  hipLaunchKernelGGL(add_noise_clip_kernel, dim3(blocks_for(total)), dim3(256), 0, s, x, noise_nhwc, C, hw, total);
+  DRS_LAUNCH(add_noise_clip_kernel, dim3(blocks_for(total)), dim3(256), 0, s, x, noise_nhwc, C, hw, total);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

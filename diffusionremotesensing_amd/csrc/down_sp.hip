@@ -152,7 +152,7 @@ int drs_launch_down_sp(const TapConv& d, hipStream_t s) {
   int per_xcd = num_cu / 8;  // one block per CU; blocks of an XCD split into the channel groups
   per_xcd = per_xcd / ngroups * ngroups;
   if (per_xcd < ngroups) per_xcd = ngroups;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * per_xcd)), dim3(512), lds, s, d, w_gimage);
+  DRS_LAUNCH(kern, dim3((unsigned)(8 * per_xcd)), dim3(512), lds, s, d, w_gimage);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

@@ -112,6 +112,18 @@ struct DrsErr {
 
 static inline int drs_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Every kernel of the library is launched through DRS_LAUNCH (same arguments as hipLaunchKernelGGL).  While a plan runs a
+// PROFILED forward (drs_unet_profile_enable) on this host thread, the launch is also appended to that plan's launch log
+// (kernel name as the runtime reports it + the op of the schedule that issued it: drs_unet_profile_launch), which is what
+// ties the per-dispatch rows of a rocprofv3 counter pass to the plan's ops (tools/collect_pmc.py) without a hand-kept list
+// of kernel names.  Outside a profiled forward the hook is one thread-local load.
+void drs_note_launch(const void* kernel_fn, const char* expr);
+#define DRS_LAUNCH(kern, grid, block, lds, stream, ...)                       \
+  do {                                                                        \
+    drs_note_launch(reinterpret_cast<const void*>(kern), #kern);              \
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);          \
+  } while (0)
+
 // Per-DEVICE launch facts: sets the kernel's dynamic-LDS limit once per (current device, kernel) and returns that device's
 // CU count.  Keyed by device, mutex-protected: correct with several devices in one process and from several host threads.
 int drs_kernel_prepare(const void* kernel, int max_dynamic_lds, int* num_cu);

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cxxabi.h>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -24,7 +25,7 @@ void DrsErr::set(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* drs_last_error(void) { return g_err; }
-extern "C" int drs_abi_version(void) { return 5; }
+extern "C" int drs_abi_version(void) { return 6; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -405,6 +406,10 @@ struct drs_plan {
   struct OpRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
   bool profiling = false;
   std::vector<OpRec> ops;
+  // launch log of the last profiled forward (drs_note_launch): one entry per kernel launch, in host launch order
+  struct LaunchRec { std::string op, kernel; };
+  std::vector<LaunchRec> launches;
+  std::string cur_op;  // op of the schedule whose prof_begin / prof_end bracket is open ("" between ops)
 
   // workspace offsets
   size_t o_lr[3], o_up, o_temb;
@@ -914,10 +919,32 @@ static void prof_begin(drs_plan* plan, const std::string& name, double flops, do
   (void)hipEventCreate(&r.e1);
   (void)hipEventRecord(r.e0, s);
   plan->ops.push_back(r);
+  plan->cur_op = name;
 }
 static void prof_end(drs_plan* plan, hipStream_t s) {
-  if (plan->profiling) (void)hipEventRecord(plan->ops.back().e1, s);
+  if (!plan->profiling) return;
+  (void)hipEventRecord(plan->ops.back().e1, s);
+  plan->cur_op.clear();
 }
+
+// Launch log (DRS_LAUNCH, drs_common.h): the plan whose profiled forward is running on this host thread, if any.
+static thread_local drs_plan* tls_logged_plan = nullptr;
+void drs_note_launch(const void* kernel_fn, const char* expr) {
+  drs_plan* plan = tls_logged_plan;
+  if (!plan) return;
+  const char* nm = hipKernelNameRefByPtr(kernel_fn, nullptr);  // mangled name of the device function
+  std::string kname = nm ? nm : expr;
+  int status = 0;
+  if (char* dm = abi::__cxa_demangle(kname.c_str(), nullptr, nullptr, &status)) {
+    if (status == 0) kname = dm;
+    free(dm);
+  }
+  plan->launches.push_back({plan->cur_op, kname});
+}
+struct LaunchLogScope {  // active for the duration of one drs_unet_forward of a profiling plan
+  explicit LaunchLogScope(drs_plan* p) { if (p && p->profiling) { p->launches.clear(); p->cur_op.clear(); tls_logged_plan = p; } }
+  ~LaunchLogScope() { tls_logged_plan = nullptr; }
+};
 static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d_in, hipStream_t s) {
   // second output (TapConv::out2): written by the wave-specialised SP kernel's epilogue; shapes that kernel does not
   // take get it from a separate pass over the first output
@@ -997,6 +1024,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     for (auto& r : plan->ops) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     plan->ops.clear();
   }
+  LaunchLogScope launch_log(plan);
 #define RUN(expr) do { if ((rc = (expr))) return rc; } while (0)
 
   // --- second stream (eval plans): see the decoder section ---
@@ -1504,6 +1532,15 @@ extern "C" int drs_unet_profile_read(drs_plan* plan, int i, char* name, int name
   snprintf(name, name_len, "%s", r.name.c_str());
   *flops = r.flops;
   *bytes = r.bytes;
+  return DRS_OK;
+}
+
+extern "C" int drs_unet_profile_num_launches(const drs_plan* plan) { return plan ? (int)plan->launches.size() : 0; }
+extern "C" int drs_unet_profile_launch(const drs_plan* plan, int i, char* op, int op_len, char* kernel, int kernel_len) {
+  DRS_REQUIRE(plan && i >= 0 && i < (int)plan->launches.size() && op && kernel && op_len > 0 && kernel_len > 0, DRS_ERR_ARG,
+              "profile_launch: bad args");
+  snprintf(op, op_len, "%s", plan->launches[i].op.c_str());
+  snprintf(kernel, kernel_len, "%s", plan->launches[i].kernel.c_str());
   return DRS_OK;
 }
 

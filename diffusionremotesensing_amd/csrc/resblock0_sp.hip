@@ -450,7 +450,7 @@ int drs_launch_resblock0(const ResBlock0Desc& d, hipStream_t s) {
   // global operand images (drs_launch_pack_conv_mfma): [chunk 1][tap][k-group 4][channels] slots, one image per bf16 half
   const unsigned w1_gimage = 9u * 4u * 64u * 16u, w2_gimage = 9u * 4u * 32u * 16u, ws_gimage = 4u * 32u * 16u;
   const int blocks = num_cu / 8 * 8;  // one block per CU
-  hipLaunchKernelGGL(resblock0_kernel, dim3((unsigned)blocks), dim3(512), resblock0_lds(d.N), s, d, w1_gimage, w2_gimage, ws_gimage, 0);
+  DRS_LAUNCH(resblock0_kernel, dim3((unsigned)blocks), dim3(512), resblock0_lds(d.N), s, d, w1_gimage, w2_gimage, ws_gimage, 0);
   DRS_CHECK_HIP(hipGetLastError());
 #ifdef DRS_SP_TIMELINE
   {
@@ -460,7 +460,7 @@ int drs_launch_resblock0(const ResBlock0Desc& d, hipStream_t s) {
     float ms = 0.f;
     DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
     DRS_CHECK_HIP(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(resblock0_kernel, dim3((unsigned)blocks), dim3(512), resblock0_lds(d.N), s, d, w1_gimage, w2_gimage, ws_gimage, dbg);  // timed repeat
+    DRS_LAUNCH(resblock0_kernel, dim3((unsigned)blocks), dim3(512), resblock0_lds(d.N), s, d, w1_gimage, w2_gimage, ws_gimage, dbg);  // timed repeat
     DRS_CHECK_HIP(hipEventRecord(e1, s));
     DRS_CHECK_HIP(hipStreamSynchronize(s));
     DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));

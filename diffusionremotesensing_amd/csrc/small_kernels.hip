@@ -54,7 +54,7 @@ int drs_launch_pack_conv(const float* w, const float* b, const float* gamma, con
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps, dst_w,
+  DRS_LAUNCH(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps, dst_w,
                      dst_b, Cout, Cin, taps, transposed, mfma_layout);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -134,14 +134,14 @@ static inline int ew_blocks(int64_t total) {
 }
 int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
                             hipStream_t s) {
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H,
+  DRS_LAUNCH(nchw_to_nhwc_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H,
                      W, dst_cs, dst_co);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
 int drs_launch_sp_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int src_cs, int src_co,
                           hipStream_t s) {
-  hipLaunchKernelGGL(sp_to_nchw_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, s,
+  DRS_LAUNCH(sp_to_nchw_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, s,
                      reinterpret_cast<const char*>(src), dst, N, C, H, W, src_cs, src_co);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -151,14 +151,14 @@ int drs_launch_sp_add_rowvec(const float* src, float* dst, const float* vec, int
   DRS_REQUIRE(C % 32 == 0, DRS_ERR_SHAPE, "sp_add_rowvec: C=%d", C);
   const int64_t per_image = (int64_t)pix_per_image * (C / 8), slots = per_image * N;
   if (slots == 0) return DRS_OK;
-  hipLaunchKernelGGL(sp_add_rowvec_kernel, dim3(ew_blocks(slots)), dim3(256), 0, s, reinterpret_cast<const char*>(src),
+  DRS_LAUNCH(sp_add_rowvec_kernel, dim3(ew_blocks(slots)), dim3(256), 0, s, reinterpret_cast<const char*>(src),
                      reinterpret_cast<char*>(dst), vec, vec_stride, slots, per_image, C);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
 int drs_launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int src_cs, int src_co,
                             hipStream_t s) {
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H,
+  DRS_LAUNCH(nhwc_to_nchw_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H,
                      W, src_cs, src_co);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -218,7 +218,7 @@ int drs_launch_conv3x3_planar(const float* in, const float* w, const float* b, c
                               int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
   DRS_REQUIRE(Cin >= 1 && Cin <= 4 && Cout >= 1 && Cout <= 4, DRS_ERR_SHAPE, "planar conv: Cin=%d Cout=%d (max 4)", Cin,
               Cout);
-  hipLaunchKernelGGL(conv3x3_planar_kernel, dim3(ew_blocks((int64_t)N * H * W)), dim3(256), 0, s, in, w, b, res, out,
+  DRS_LAUNCH(conv3x3_planar_kernel, dim3(ew_blocks((int64_t)N * H * W)), dim3(256), 0, s, in, w, b, res, out,
                      N, Cin, Cout, H, W, relu);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -368,7 +368,7 @@ int drs_launch_stem(const float* in_nchw, const float* w, const float* b, const 
   if (units == 0) return DRS_OK;
   DRS_REQUIRE(units < (1LL << 31), DRS_ERR_SHAPE, "stem: %lld row segments", (long long)units);
   const int64_t blocks = std::min<int64_t>((units + 3) / 4, 16384);
-  hipLaunchKernelGGL(stem_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, in_nchw, w, b, res_nhwc,
+  DRS_LAUNCH(stem_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, in_nchw, w, b, res_nhwc,
                      res_batch, out_nhwc, N, Cin, H, W, out_sp);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
 }
 int drs_launch_bicubic(const float* x, float* y, int N, int C, int H, int W, int scale, hipStream_t s) {
   DRS_REQUIRE(scale >= 1, DRS_ERR_SHAPE, "bicubic: scale=%d", scale);
-  hipLaunchKernelGGL(bicubic_kernel, dim3(ew_blocks((int64_t)N * C * H * W * scale * scale)), dim3(256), 0, s, x, y,
+  DRS_LAUNCH(bicubic_kernel, dim3(ew_blocks((int64_t)N * C * H * W * scale * scale)), dim3(256), 0, s, x, y,
                      N * C, H, W, scale);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -469,7 +469,7 @@ int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1
   DRS_REQUIRE(dim_in % 2 == 0 && dim_in > 0 && dim_out > 0, DRS_ERR_SHAPE, "time_mlp: dims %d %d", dim_in, dim_out);
   if (B == 0) return DRS_OK;
   const size_t shmem = (size_t)(dim_in + dim_out) * sizeof(float);
-  hipLaunchKernelGGL(time_mlp_kernel, dim3(B), dim3(256), shmem, s, t, inv_freq, W1, b1, W2, b2, out, out_stride,
+  DRS_LAUNCH(time_mlp_kernel, dim3(B), dim3(256), shmem, s, t, inv_freq, W1, b1, W2, b2, out, out_stride,
                      dim_in, dim_out);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -535,7 +535,7 @@ int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const cha
                               hipStream_t s) {
   if (B == 0 || nmlp == 0) return DRS_OK;
   const size_t shmem = (size_t)(dim_in + max_dim) * sizeof(float);
-  hipLaunchKernelGGL(time_mlp_multi_kernel, dim3(B, nmlp), dim3(256), shmem, s, t, inv_freq, packed, table, out,
+  DRS_LAUNCH(time_mlp_multi_kernel, dim3(B, nmlp), dim3(256), shmem, s, t, inv_freq, packed, table, out,
                      out_stride, dim_in, label_emb, labels, label_batch, num_classes);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -566,7 +566,7 @@ extern "C" int drs_noise_images(const float* x0, const float* eps, const int64_t
   if (n == 0 || chw == 0) return DRS_OK;
   int bx = (int)((chw + 255) / 256);
   if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(noise_images_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, x0, eps, t, alpha_hat, x_t,
+  DRS_LAUNCH(noise_images_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, x0, eps, t, alpha_hat, x_t,
                      chw);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -597,7 +597,7 @@ extern "C" int drs_sampler_step(float* x, const float* eps_pred, const float* no
   DRS_REQUIRE(x && eps_pred && alpha && alpha_hat && beta, DRS_ERR_ARG, "sampler_step: null pointer");
   DRS_REQUIRE(t >= 0 && t < noise_steps, DRS_ERR_ARG, "sampler_step: t=%d outside [0,%d)", t, noise_steps);
   if (numel <= 0) return DRS_OK;
-  hipLaunchKernelGGL(sampler_step_tab_kernel, dim3(ew_blocks(numel)), dim3(256), 0, (hipStream_t)stream, x, eps_pred,
+  DRS_LAUNCH(sampler_step_tab_kernel, dim3(ew_blocks(numel)), dim3(256), 0, (hipStream_t)stream, x, eps_pred,
                      noise, t, alpha, alpha_hat, beta, numel);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -628,7 +628,7 @@ extern "C" int drs_sampler_step_cfg(float* x, const float* eps_cond, const float
   DRS_REQUIRE(x && eps_cond && eps_uncond && alpha && alpha_hat && beta, DRS_ERR_ARG, "sampler_step_cfg: null pointer");
   DRS_REQUIRE(t >= 0 && t < noise_steps, DRS_ERR_ARG, "sampler_step_cfg: t=%d outside [0,%d)", t, noise_steps);
   if (numel <= 0) return DRS_OK;
-  hipLaunchKernelGGL(sampler_step_cfg_kernel, dim3(ew_blocks(numel)), dim3(256), 0, (hipStream_t)stream, x, eps_cond,
+  DRS_LAUNCH(sampler_step_cfg_kernel, dim3(ew_blocks(numel)), dim3(256), 0, (hipStream_t)stream, x, eps_cond,
                      eps_uncond, cfg_scale, noise, t, alpha, alpha_hat, beta, numel);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -670,7 +670,7 @@ extern "C" int drs_aggregate_tiles(const float* tiles, const int32_t* origins, c
   DRS_REQUIRE(n >= 1 && C >= 1 && S >= 1 && H >= S && W >= S, DRS_ERR_SHAPE, "aggregate_tiles: n=%d C=%d S=%d H=%d W=%d", n,
               C, S, H, W);
   if (uncovered) DRS_CHECK_HIP(hipMemsetAsync(uncovered, 0, sizeof(int32_t), (hipStream_t)stream));
-  hipLaunchKernelGGL(aggregate_tiles_kernel, dim3(ew_blocks((int64_t)H * W)), dim3(256), 0, (hipStream_t)stream, tiles,
+  DRS_LAUNCH(aggregate_tiles_kernel, dim3(ew_blocks((int64_t)H * W)), dim3(256), 0, (hipStream_t)stream, tiles,
                      origins, weight, out, uncovered, n, C, S, H, W);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;

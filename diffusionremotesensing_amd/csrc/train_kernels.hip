@@ -96,7 +96,7 @@ int drs_launch_wgrad(const WgradDesc& d, hipStream_t s) {
   if (chunk < 256) chunk = 256;
   chunk = (chunk + 15) / 16 * 16;
   chunks = (P + chunk - 1) / chunk;
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)chunks, d.ntaps, tiles), dim3(256), 0, s, d, (int)chunk);
+  DRS_LAUNCH(wgrad_kernel, dim3((unsigned)chunks, d.ntaps, tiles), dim3(256), 0, s, d, (int)chunk);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -177,12 +177,12 @@ int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, lon
   }
   const long long blocks = (npix + rpb - 1) / rpb;
   if (C % 4 == 0 && cs % 4 == 0 && co % 4 == 0 && C <= 1024 && 256 % (C >> 2) == 0) {
-    hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, cs, co, C, npix, pix_per_image, per_image,
+    DRS_LAUNCH(colsum4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, cs, co, C, npix, pix_per_image, per_image,
                        out_stride, out, (int)rpb);
     DRS_CHECK_HIP(hipGetLastError());
     return DRS_OK;
   }
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, cs, co, C, npix, pix_per_image, per_image,
+  DRS_LAUNCH(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, cs, co, C, npix, pix_per_image, per_image,
                      out_stride, out, (int)rpb);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -202,7 +202,7 @@ __global__ void relu_mask_kernel(float* g, int g_cs, int g_co, const float* y, i
 }
 int drs_launch_relu_mask(float* g, int g_cs, int g_co, const float* y, int y_cs, int y_co, int C, long long npix,
                          hipStream_t s) {
-  hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, y, y_cs, y_co, C,
+  DRS_LAUNCH(relu_mask_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, y, y_cs, y_co, C,
                      npix);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -221,7 +221,7 @@ __global__ void add_slice_kernel(float* dst, int d_cs, int d_co, const float* sr
 }
 int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s_cs, int s_co, int C, long long npix,
                          int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(add_slice_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, dst, d_cs, d_co, src, s_cs, s_co,
+  DRS_LAUNCH(add_slice_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, dst, d_cs, d_co, src, s_cs, s_co,
                      C, npix, accumulate);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -295,13 +295,13 @@ int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float*
   DRS_CHECK_HIP(hipMemsetAsync(sums_scratch, 0, 2 * (size_t)C * sizeof(double), s));
   if (C <= 256) {
     const int rows = 256 / C;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid1d(npix, rows, 512)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
+    DRS_LAUNCH(bn_bwd_reduce_kernel, dim3(grid1d(npix, rows, 512)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
                        gamma, beta, relu_pre, C, npix, sums_scratch);
   } else {
     DrsErr::set("bn_bwd: C > 256 not needed by this network");
     return DRS_ERR_SHAPE;
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
+  DRS_LAUNCH(bn_bwd_apply_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
                      gamma, beta, relu_pre, C, npix, sums_scratch, dgamma, dbeta);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 int drs_launch_gate_bwd(const float* x, const float* E, const float* psi, float* dx, float* dpsi_pre, int N, int LH,
                         int LW, int C, hipStream_t s) {
   const long long total = (long long)N * LH * LW;
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, x, E, psi, dx, dpsi_pre, N, LH, LW,
+  DRS_LAUNCH(gate_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, x, E, psi, dx, dpsi_pre, N, LH, LW,
                      C);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -384,7 +384,7 @@ int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre
                        long long npix, hipStream_t s) {
   DRS_REQUIRE(C <= 256 && 256 % C == 0, DRS_ERR_SHAPE, "psi_bwd: C=%d", C);
   const int rpb = 1024;
-  hipLaunchKernelGGL(psi_bwd_kernel, dim3((unsigned)((npix + rpb - 1) / rpb)), dim3(256), 0, s, Pm, wpsi, dpsi_pre, dP, dw,
+  DRS_LAUNCH(psi_bwd_kernel, dim3((unsigned)((npix + rpb - 1) / rpb)), dim3(256), 0, s, Pm, wpsi, dpsi_pre, dP, dw,
                      db, C, npix, rpb);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -490,7 +490,7 @@ int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const flo
                             float* dW2, float* db2, const float* label_emb, const long long* labels, int label_batch,
                             int num_classes, float* dlabel, hipStream_t s) {
   DRS_REQUIRE(dim <= 256, DRS_ERR_SHAPE, "time_mlp_bwd: dim=%d", dim);
-  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3((dim + 7) / 8), dim3(256), 0, s, t, inv_freq, W1, b1, W2, temb, dtemb, stride, B, dim, dW1,
+  DRS_LAUNCH(time_mlp_bwd_kernel, dim3((dim + 7) / 8), dim3(256), 0, s, t, inv_freq, W1, b1, W2, temb, dtemb, stride, B, dim, dW1,
                      db1, dW2, db2, label_emb, labels, label_batch, num_classes, dlabel);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -534,7 +534,7 @@ __global__ void bicubic_bwd_kernel(const float* __restrict__ dy, float* __restri
 }
 int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, hipStream_t s) {
   const long long total = (long long)N * H * W * scale * scale * C;
-  hipLaunchKernelGGL(bicubic_bwd_kernel, dim3(grid1d(total, 256, 8192)), dim3(256), 0, s, dy, dx, N, C, H, W, scale);
+  DRS_LAUNCH(bicubic_bwd_kernel, dim3(grid1d(total, 256, 8192)), dim3(256), 0, s, dy, dx, N, C, H, W, scale);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -571,7 +571,7 @@ extern "C" int drs_adam_multi(const drs_adam_tensor* table, int ntensors, int64_
   DRS_REQUIRE(table && ntensors >= 0, DRS_ERR_ARG, "adam_multi: bad arguments");
   if (ntensors == 0 || max_numel <= 0) return DRS_OK;
   const unsigned gx = (unsigned)((max_numel + 4095) / 4096);
-  hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, ntensors), dim3(256), 0, (hipStream_t)stream, table, lr, beta1, beta2,
+  DRS_LAUNCH(adam_multi_kernel, dim3(gx, ntensors), dim3(256), 0, (hipStream_t)stream, table, lr, beta1, beta2,
                      (float)eps);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
@@ -602,7 +602,7 @@ extern "C" int drs_ema_multi(const drs_ema_tensor* table, int ntensors, int64_t 
   DRS_REQUIRE(table && ntensors >= 0 && (mode == 0 || mode == 1), DRS_ERR_ARG, "ema_multi: bad arguments");
   if (ntensors == 0 || max_numel <= 0) return DRS_OK;
   const unsigned gx = (unsigned)((max_numel + 4095) / 4096);
-  hipLaunchKernelGGL(ema_multi_kernel, dim3(gx, ntensors), dim3(256), 0, (hipStream_t)stream, table, (float)beta,
+  DRS_LAUNCH(ema_multi_kernel, dim3(gx, ntensors), dim3(256), 0, (hipStream_t)stream, table, (float)beta,
                      (float)(1.0 - beta), mode);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;

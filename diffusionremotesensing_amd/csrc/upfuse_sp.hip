@@ -828,18 +828,18 @@ int drs_launch_upfuse_pack(const float* v_w, const float* v_b, const float* t_w,
   DRS_REQUIRE(Cc % 32 == 0 && Ch % 32 == 0, DRS_ERR_SHAPE, "upfuse_pack: Cc=%d Ch=%d", Cc, Ch);
   const size_t nslots = drs_upfuse_weight_bytes(Cc, Ch) / 32;
   int blocks = (int)((nslots + 127) / 128);
-  hipLaunchKernelGGL(upfuse_pack_kernel, dim3(blocks), dim3(128), 0, s, v_w, t_w, Cc, Ch, (char*)dst_w);
+  DRS_LAUNCH(upfuse_pack_kernel, dim3(blocks), dim3(128), 0, s, v_w, t_w, Cc, Ch, (char*)dst_w);
   DRS_CHECK_HIP(hipGetLastError());
   const size_t total = (size_t)11 * Cc * Ch + (size_t)9 * Ch;
   blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(upfuse_aux_kernel, dim3(blocks), dim3(256), 0, s, v_w, v_b, t_w, t_b, Cc, Ch, dst_aux);
+  DRS_LAUNCH(upfuse_aux_kernel, dim3(blocks), dim3(256), 0, s, v_w, v_b, t_w, t_b, Cc, Ch, dst_aux);
   DRS_CHECK_HIP(hipGetLastError());
   float* bt = dst_aux + (size_t)11 * Cc * Ch;
-  hipLaunchKernelGGL(upfuse_bias_kernel, dim3((Ch + 127) / 128), dim3(128), 0, s, v_b, Ch, bt, bt + 9 * Ch);
+  DRS_LAUNCH(upfuse_bias_kernel, dim3((Ch + 127) / 128), dim3(128), 0, s, v_b, Ch, bt, bt + 9 * Ch);
   DRS_CHECK_HIP(hipGetLastError());
   {
     const size_t img = drs_upfuse_edge_image_bytes(Cc, Ch) / 2;
-    hipLaunchKernelGGL(upfuse_edge_pack_kernel, dim3((unsigned)((img / 16 + 255) / 256)), dim3(256), 0, s, dst_aux, Cc, Ch,
+    DRS_LAUNCH(upfuse_edge_pack_kernel, dim3((unsigned)((img / 16 + 255) / 256)), dim3(256), 0, s, dst_aux, Cc, Ch,
                        (char*)dst_edge, img);
     DRS_CHECK_HIP(hipGetLastError());
   }
@@ -852,7 +852,7 @@ int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s) {
   if ((size_t)d.N * d.LH * d.LW == 0) return DRS_OK;
   DRS_REQUIRE(d.Ch % 32 == 0 && d.Cc % 32 == 0 && d.wimg && d.zero_line, DRS_ERR_SHAPE, "upfuse_edges: Cc=%d Ch=%d", d.Cc, d.Ch);
   const int segs = drs_cdiv(d.LH > d.LW ? d.LH : d.LW, 16);
-  hipLaunchKernelGGL(upfuse_edges_mfma_kernel, dim3(segs * (d.Ch / 32), 2, d.N), dim3(64), 0, s, d,
+  DRS_LAUNCH(upfuse_edges_mfma_kernel, dim3(segs * (d.Ch / 32), 2, d.N), dim3(64), 0, s, d,
                      reinterpret_cast<const char*>(d.wimg), drs_upfuse_edge_image_bytes(d.Cc, d.Ch) / 2,
                      reinterpret_cast<const char*>(d.zero_line));
   DRS_CHECK_HIP(hipGetLastError());
@@ -887,9 +887,9 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
   blocks = (blocks + 7) / 8 * 8;
   static const int dbg = getenv("DRS_DEBUG_FLAGS") ? atoi(getenv("DRS_DEBUG_FLAGS")) : 0;  // timeline builds: 1 no stores, 2 no residual loads
   if (d.fuse_out)
-    hipLaunchKernelGGL(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
+    DRS_LAUNCH(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
   else
-    hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
+    DRS_LAUNCH(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
   DRS_CHECK_HIP(hipGetLastError());
 #ifdef DRS_SP_TIMELINE
   {
@@ -899,9 +899,9 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
     DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
     DRS_CHECK_HIP(hipEventRecord(e0, s));
     if (d.fuse_out)  // timed repeat (same result)
-      hipLaunchKernelGGL(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
+      DRS_LAUNCH(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
     else
-      hipLaunchKernelGGL(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
+      DRS_LAUNCH(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
     DRS_CHECK_HIP(hipEventRecord(e1, s));
     DRS_CHECK_HIP(hipStreamSynchronize(s));
     DRS_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
@@ -929,7 +929,7 @@ int drs_launch_nchw_to_sp(const float* src, float* dst, int N, int C, int H, int
   if (slots == 0) return DRS_OK;
   int64_t b = (slots + 255) / 256;
   if (b > 8192) b = 8192;
-  hipLaunchKernelGGL(nchw_to_sp_kernel, dim3((unsigned)b), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), N, C, H, W);
+  DRS_LAUNCH(nchw_to_sp_kernel, dim3((unsigned)b), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), N, C, H, W);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

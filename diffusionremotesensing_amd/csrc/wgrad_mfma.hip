@@ -236,7 +236,7 @@ int launch_cfg(const WgradMfmaArgs& a0, int target_blocks, size_t partial_bytes,
   if (lds > 160 * 1024) return -1;
   auto kern = wgrad_mfma_kernel<NT, MW, NW, WM, WN, WK>;
   if (lds > 64 * 1024) DRS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)ksplit, ct), dim3(256), lds, s, a);
+  DRS_LAUNCH(kern, dim3((unsigned)ksplit, ct), dim3(256), lds, s, a);
   DRS_CHECK_HIP(hipGetLastError());
   *nslices = (int)ksplit * WK;
   return DRS_OK;
@@ -269,7 +269,7 @@ int drs_wgrad_reduce(const float* partial, long long slice_stride, int nslices, 
   int gy = (int)std::min<long long>(nslices, std::max<long long>(1, 1024 / gx));
   const int spy = (nslices + gy - 1) / gy;
   gy = (nslices + spy - 1) / spy;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, s, r, spy);
+  DRS_LAUNCH(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, s, r, spy);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

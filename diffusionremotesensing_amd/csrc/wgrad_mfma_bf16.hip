@@ -259,7 +259,7 @@ int launch_cfg(const WgradBf16Args& a0, int target_blocks, size_t partial_bytes,
   if (lds > 160 * 1024) return -1;
   auto kern = wgrad_bf16_kernel<NT, MW, NW>;
   if (lds > 64 * 1024) DRS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)ksplit, ct), dim3(256), lds, s, a);
+  DRS_LAUNCH(kern, dim3((unsigned)ksplit, ct), dim3(256), lds, s, a);
   DRS_CHECK_HIP(hipGetLastError());
   *nslices = (int)ksplit;
   return DRS_OK;

@@ -292,7 +292,10 @@ class HipUNetEngine:
 
     def check_faults(self):
         """Synchronise and raise if a wave of the wave-specialised kernels gave up on an LDS counter during a forward of the
-        last plan (drs_unet_check_faults: a protocol bug reports itself instead of hanging or faulting the device)."""
+        last plan (drs_unet_check_faults: a protocol bug reports itself instead of hanging or faulting the device).
+        The word is sticky: once set it is reported by every call until the weights are packed again.  Called at the end of
+        every `Diffusion.sample` chain (hence by the tiler and the training previews), by bench.py after its timed loop and
+        by smoke()."""
         plan = getattr(self, "_last_plan", None)
         if plan is None or plan.signature is None:
             return
@@ -325,9 +328,36 @@ class HipUNetEngine:
                         acc[key] = [0.0, fl.value, by.value]
                         order.append(key)
                     acc[key][0] += ms.value
+            self.last_launch_log = self._read_launch_log(plan)
         finally:
             lib.drs_unet_profile_enable(plan.handle, 0)
         return [(k, acc[k][0] / iters, acc[k][1], acc[k][2]) for k in order]
+
+    @staticmethod
+    def _read_launch_log(plan):
+        """[(op name or "", kernel name)] for every kernel the last profiled forward launched, in launch order
+        (drs_unet_profile_launch): what tools/collect_pmc.py joins with the dispatch rows of a counter pass."""
+        lib = plan.lib
+        op, kn = C.create_string_buffer(128), C.create_string_buffer(512)
+        out = []
+        for i in range(lib.drs_unet_profile_num_launches(plan.handle)):
+            _lib.check(lib.drs_unet_profile_launch(plan.handle, i, op, 128, kn, 512), "drs_unet_profile_launch")
+            out.append((op.value.decode(), kn.value.decode()))
+        return out
+
+    def logged_forward(self, x, timestep, lr_img, magnification_factor, **kw):
+        """One forward with the plan's launch log on (per-op events too; the serial profiled schedule): returns
+        (output, [(op, kernel)])."""
+        plan = getattr(self, "_last_plan", None)
+        if plan is None or plan.signature is None:
+            raise RuntimeError("logged_forward: run a plain forward of the same shape first (plan and weights in place)")
+        _lib.check(plan.lib.drs_unet_profile_enable(plan.handle, 1), "drs_unet_profile_enable")
+        try:
+            out = self.forward(x, timestep, lr_img, magnification_factor, **kw)
+            log = self._read_launch_log(plan)
+        finally:
+            plan.lib.drs_unet_profile_enable(plan.handle, 0)
+        return out, log
 
     # -- introspection (parity tests) ---------------------------------------------------------
     def tensor_names(self):

@@ -79,6 +79,9 @@ class Diffusion(_SuperresDiffusion):
                 first = False
                 if generate_video:
                     frames.append(x.clone())
+        # a protocol fault of the wave-specialised kernels is reported through a device word instead of a trap
+        # (csrc/sp_sync.h): read it where the caller is about to consume x (one 4-byte copy + stream sync per chain)
+        engine.check_faults()
         if generate_video:
             from ..video import video_maker
             video_maker(frames, os.path.join(os.getcwd(), "models_run", self.model_name, "results",

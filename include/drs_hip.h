@@ -53,7 +53,7 @@ enum {
  * Human-readable message for the last non-zero status returned on this thread. */
 const char* drs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
-int drs_abi_version(void);  /* 5 */
+int drs_abi_version(void);  /* 6 */
 
 /* ------------------------------------------------------------------------------------------
  * Diffusion arithmetic
@@ -286,6 +286,13 @@ int drs_unet_check_faults(drs_plan* plan, const void* packed, drs_stream_t strea
 int drs_unet_profile_enable(drs_plan* plan, int on);
 int drs_unet_profile_num_ops(const drs_plan* plan);
 int drs_unet_profile_read(drs_plan* plan, int i, char* name, int name_len, float* ms, double* flops, double* bytes);
+/* Launch log of the last PROFILED forward (ABI 6): one entry per kernel the forward launched, in host launch order, with
+ * the kernel's name as the runtime reports it (demangled) and the op of the schedule that issued it ("" for launches
+ * outside any op bracket, e.g. the per-image gate-bias tables).  A rocprofv3 counter pass over the same process sees
+ * exactly these dispatches, in this order, as the process's last launches: tools/collect_pmc.py joins the two and
+ * refuses to attribute bytes if a kernel name differs. */
+int drs_unet_profile_num_launches(const drs_plan* plan);
+int drs_unet_profile_launch(const drs_plan* plan, int i, char* op, int op_len, char* kernel, int kernel_len);
 
 #ifdef __cplusplus
 }

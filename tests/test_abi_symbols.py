@@ -14,7 +14,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in drs_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.drs_abi_version() == 5
+    assert lib.drs_abi_version() == 6
 
 
 def test_argument_validation_without_gpu():

@@ -18,6 +18,9 @@ ap.add_argument("--impl", default="mfma_bf16x3")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--image", type=int, default=256)
+ap.add_argument("--launch-log", default=None,
+                help="write the plan's launch log of the LAST forward here (op <TAB> kernel per launch); that forward is "
+                     "then the process's last GPU work, so a counter pass sees exactly these dispatches at its end")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 m = Residual_Attention_UNet_superres(3, 3, dev)
@@ -36,5 +39,16 @@ with torch.no_grad():
         t.fill_(i)
         eps = eng.forward(x, t, lr, 2, reuse_cond=k > 0, check_weights=k == 0)
         hip_ops.sampler_step_(x, eps, torch.randn_like(x), i, d.alpha, d.alpha_hat, d.beta)
-torch.cuda.synchronize()
-print("done", float(x.abs().mean()))
+    torch.cuda.synchronize()
+    mean_abs = float(x.abs().mean())
+    if a.launch_log:
+        # the LAST GPU work of the process: one more forward with the plan's launch log on (serial schedule, cached
+        # conditioning branch like every step of a chain but the first); nothing is launched after it
+        t.fill_(1499 - a.steps)
+        torch.cuda.synchronize()
+        _, log = eng.logged_forward(x, t, lr, 2, reuse_cond=True, check_weights=False)
+        torch.cuda.synchronize()
+        with open(a.launch_log, "w") as f:
+            for op, kernel in log:
+                f.write(f"{op or '-'}\t{kernel}\n")
+print("done", mean_abs)
