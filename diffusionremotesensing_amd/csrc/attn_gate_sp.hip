@@ -190,260 +190,10 @@ __global__ __launch_bounds__(NT == 2 ? 1024 : 512, 1) void attn_gate_sp_kernel(A
 }
 
 // ---- wide variant (Ch = 128: the first decoder stage, whose weights, 524 KB as bf16 hi | lo, cannot live in LDS) ----------
-// A block (8 waves) owns 64 low-resolution pixels = 4 MFMA pixel blocks; wave w computes output channels
-// [32 * (w & 3), + 32) of pixel blocks {2 * (w >> 2), + 1}.  Weight fragments come straight from global memory (every CU reads the
-// same 0.5 MB: L2-resident; the two waves of a channel group share them through L1), activations as above; the gating
-// signal crosses the channel groups through a 32 KB LDS image in operand-slot order, the psi partial sums through 1 KB.
-template <int NCX>  // 32-channel chunks of the stage input (compile time: the whole item is one unrolled pipeline)
-__global__ __launch_bounds__(512, 1) void attn_gate_wide_kernel(AttnGateDesc d) {
-  using P = PolicyBF16X3;
-  constexpr int Ch = 128, NG = 4;
-  __shared__ __attribute__((aligned(16))) char sG[4 * NG * 2 * 4 * 16 * 16];  // [pixel block 4][chunk 4][hi | lo][k-group 4][pixel 16]
-  __shared__ float sPsi[NG][64];
-  __shared__ __attribute__((aligned(16))) float sB[4 * 128 + 4];  // b_gate | b_wg + b_wx | w_psi | b_res | b_psi
-  for (int i = threadIdx.x; i < Ch; i += 512) {
-    sB[i] = d.b_gate[i];
-    sB[Ch + i] = d.b_wg[i] + d.b_wx[i];
-    sB[2 * Ch + i] = d.w_psi[i];
-    sB[3 * Ch + i] = d.b_res[i];
-  }
-  if (threadIdx.x == 0) sB[4 * Ch] = d.b_psi[0];
-  __syncthreads();
-  // (wave-uniform values are marked as such: every address below is a scalar base + one 32-bit lane offset, otherwise the
-  // 64-bit lane addresses of the whole pipeline get computed up front and spill)
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lr = lane & 15, kg = lane >> 4;
-  const int cg = wave & 3, pb2 = wave >> 2;
-  constexpr int ncx = NCX;
-  const size_t gate_img = (size_t)ncx * 4 * Ch * 16, wg_img = (size_t)NG * 4 * Ch * 16, wx_img = (size_t)NG * 16 * Ch * 16;
-  const int bw = (d.LW + 15) / 16;
-  const long long nblk16 = (long long)d.N * d.LH * bw;
-  const long long nitems = (nblk16 + 3) / 4;
-  const int OW = 2 * d.LW, OH = 2 * d.LH;
-  const unsigned lane_w = (unsigned)((kg * Ch + lr) * 16);
-  // Addressing: every load is  scalar base (opaque copy, global address space) + ONE 32-bit lane offset.  Left to itself
-  // the compiler re-associates base + lane + constant into a 64-bit lane address (or a scalar pair) PER FRAGMENT, hoists
-  // all of them out of the item loop and spills them; and behind a plain asm copy it no longer sees the address space: a
-  // flat load counts on the LDS counter as well, which turns every counted wait into a full drain.
-  typedef const __attribute__((address_space(1))) char* gptr;
-  typedef const __attribute__((address_space(1))) bf16x8* gfrag;
-  auto uni = [](const void* q) __attribute__((always_inline)) {
-    gptr g = (gptr)q;
-    asm volatile("" : "+s"(g));
-    return g;
-  };
-  const gptr gw_gate = uni(d.w_gate), gw_wg = uni(d.w_wg), gw_wx = uni(d.w_wx), gw_res = uni(d.w_res);
-  // (lw: the step's opaque copy of lane_w, or lane_w + constant is loop-invariant for every fragment: ~100 hoisted registers)
-  auto wfrag = [&](gptr base, size_t img, int uslot, unsigned lw) {  // uslot (uniform) = (chunk * taps + tap) * 4 * Ch + first channel
-    const unsigned o = lw + (unsigned)uslot * 16u;
-    return typename P::Frag{*(gfrag)(base + o), *(gfrag)(base + (o + (unsigned)img))};
-  };
-  auto gslot = [&](int pbl, int cc, int img) { return sG + ((((pbl * NG + cc) * 2 + img) * 4 + kg) * 16 + lr) * 16; };
-  for (long long it = blockIdx.x; it < nitems; it += gridDim.x) {
-    int nn[2], yy[2], px[2];
-    bool valid[2];
-    gptr xrow[2], grow[2];  // (uniform) x_res row 2 * yy of image nn, stage-input row yy: channel offsets applied
-    char* orow[2];          // (uniform) output row 2 * yy, this wave's channel group
-    unsigned xoff[2][4], goff[2], ooff[2];  // lane offsets: the four x_res pixels under the lane's pixel, its input pixel
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const long long q = it * 4 + pb2 * 2 + b;
-      const long long qc = q < nblk16 ? q : nblk16 - 1;
-      const int xb = (int)(qc % bw);
-      yy[b] = (int)((qc / bw) % d.LH);
-      nn[b] = (int)(qc / ((long long)bw * d.LH));
-      const int pr = xb * 16 + lr;
-      valid[b] = q < nblk16 && pr < d.LW;
-      px[b] = pr < d.LW ? pr : d.LW - 1;
-      xrow[b] = uni(reinterpret_cast<const char*>(d.xres) + ((((size_t)nn[b] * OH + 2 * yy[b]) * OW) * d.r_cs + d.r_co) * 4);
-      grow[b] = uni(reinterpret_cast<const char*>(d.x) + ((((size_t)nn[b] * d.LH + yy[b]) * d.LW) * d.x_cs + d.x_co) * 4);
-      orow[b] = reinterpret_cast<char*>(d.out) + ((((size_t)nn[b] * OH + 2 * yy[b]) * OW) * d.out_cs + d.out_co + cg * 32) * 4;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) xoff[b][t] = (unsigned)(((t >> 1) * OW + 2 * px[b] + (t & 1)) * d.r_cs * 4 + kg * 16);
-      goff[b] = (unsigned)(px[b] * d.x_cs * 4 + kg * 16);
-      ooff[b] = (unsigned)(2 * px[b] * d.out_cs * 4 + kg * 16);
-    }
-    auto xres_frag = [&](int b, int t, int cc) {
-      return typename P::Frag{*(gfrag)(xrow[b] + (xoff[b][t] + (unsigned)(cc * 128))), *(gfrag)(xrow[b] + (xoff[b][t] + (unsigned)(cc * 128 + 64)))};
-    };
-    // Every operand of this kernel comes straight from L2 / HBM (a wave has 12 MFMAs of work per 4 KB it loads) and a block
-    // has ONE item: the launch is as long as the chain of memory round trips of a wave.  The whole item is therefore one
-    // software pipeline of "steps" (one 32-channel chunk of one operand pair: 2 weight + 2 activation fragments, 32
-    // registers): the loads of step s + 1 are issued before the MFMAs of step s, across the phase boundaries as well, and
-    // the gated result convolution W' x_res runs in the SAME steps as w_x(x_res) on the fragments that one loaded (its
-    // 64 accumulators wait for psi in registers; its weights come with each step: held for the whole item they spill).
-    struct Step { typename P::Frag w[2], a[2], r[2]; };  // r: result weights of the chunk (x_res steps only)
-    Step buf[2];
-    auto opaque = [](unsigned v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
-    auto load_gate = [&](Step& st, int c) __attribute__((always_inline)) {
-      const unsigned lw = opaque(lane_w);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(gw_gate, gate_img, c * 4 * Ch + cg * 32 + t * 16, lw);
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-      {
-        st.a[b] = typename P::Frag{*(gfrag)(grow[b] + (goff[b] + (unsigned)(c * 128))), *(gfrag)(grow[b] + (goff[b] + (unsigned)(c * 128 + 64)))};
-      }
-    };
-    auto load_wg = [&](Step& st, int cc) __attribute__((always_inline)) {
-      const unsigned lw = opaque(lane_w);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(gw_wg, wg_img, cc * 4 * Ch + cg * 32 + t * 16, lw);
-    };
-    auto load_x = [&](Step& st, int t4, int cc) __attribute__((always_inline)) {
-      const unsigned lw = opaque(lane_w);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) st.w[t] = wfrag(gw_wx, wx_img, (cc * 4 + t4) * 4 * Ch + cg * 32 + t * 16, lw);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) st.a[b] = xres_frag(b, t4, cc);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) st.r[t] = wfrag(gw_res, wg_img, cc * 4 * Ch + cg * 32 + t * 16, lw);
-    };
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mma_step = [&](const Step& st) __attribute__((always_inline)) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc[b][t] = P::mma(st.w[t], st.a[b], acc[b][t]);
-    };
-    // ---- gating signal: this wave's 32 channels of g = relu(Wg x + bg) for its two pixel blocks ----
-    // (its bias first: the oldest loads of the item, long landed when the phase ends.  Both candidates are global: a
-    // pointer that may be global or LDS makes the loads flat, and a flat load waits for everything in flight)
-    float gbias[2][8];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float* bsrc = (d.b_gate_img ? d.b_gate_img + (size_t)nn[b] * Ch : d.b_gate) + cg * 32 + kg * 8;
-      const float4 b0 = *reinterpret_cast<const float4*>(bsrc);
-      const float4 b1 = *reinterpret_cast<const float4*>(bsrc + 4);
-      gbias[b][0] = b0.x; gbias[b][1] = b0.y; gbias[b][2] = b0.z; gbias[b][3] = b0.w;
-      gbias[b][4] = b1.x; gbias[b][5] = b1.y; gbias[b][6] = b1.z; gbias[b][7] = b1.w;
-    }
-    load_gate(buf[0], 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < ncx; ++c) {
-      if (c + 1 < ncx) load_gate(buf[(c + 1) & 1], c + 1);
-      else load_wg(buf[(c + 1) & 1], 0);  // first step of the next phase (its activations come from LDS)
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(buf[c & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float* bb = gbias[b];
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = fmaxf(acc[b][0][j] + bb[j], 0.f);
-          v[4 + j] = fmaxf(acc[b][1][j] + bb[4 + j], 0.f);
-        }
-        u32x4 h, l;
-        drs_sp_split8(v, h, l);
-        *reinterpret_cast<u32x4*>(gslot(pb2 * 2 + b, cg, 0)) = h;
-        *reinterpret_cast<u32x4*>(gslot(pb2 * 2 + b, cg, 1)) = l;
-      }
-    }
-    __syncthreads();
-    // ---- p = relu(w_g(g) + w_x(x_res) + biases) and the ungated result W' x_res, this wave's 32 channels ----
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 att[4][2][2];
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) att[t4][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NG + 4 * NG; ++s) {  // steps 0 .. NG-1: w_g(g); then (pixel t4, chunk cc) of x_res
-      Step& cur = buf[(ncx + s) & 1];
-      Step& nxt = buf[(ncx + s + 1) & 1];
-      if (s + 1 < NG) load_wg(nxt, s + 1);
-      else if (s + 1 < 5 * NG) load_x(nxt, (s + 1 - NG) / NG, (s + 1 - NG) % NG);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s < NG) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          cur.a[b] = typename P::Frag{*reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, s, 0)),
-                                      *reinterpret_cast<const bf16x8*>(gslot(pb2 * 2 + b, s, 1))};
-        mma_step(cur);
-      } else {
-        const int t4 = (s - NG) / NG;
-        mma_step(cur);
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) att[t4][b][t] = P::mma(cur.r[t], cur.a[b], att[t4][b][t]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-      const int ch = cg * 32 + kg * 8;
-      float wp[8], bsum[8];
-      {
-        const float4 a0 = *reinterpret_cast<const float4*>(sB + 2 * Ch + ch), a1 = *reinterpret_cast<const float4*>(sB + 2 * Ch + ch + 4);
-        const float4 s0 = *reinterpret_cast<const float4*>(sB + Ch + ch), s1 = *reinterpret_cast<const float4*>(sB + Ch + ch + 4);
-        wp[0] = a0.x; wp[1] = a0.y; wp[2] = a0.z; wp[3] = a0.w; wp[4] = a1.x; wp[5] = a1.y; wp[6] = a1.z; wp[7] = a1.w;
-        bsum[0] = s0.x; bsum[1] = s0.y; bsum[2] = s0.z; bsum[3] = s0.w; bsum[4] = s1.x; bsum[5] = s1.y; bsum[6] = s1.z; bsum[7] = s1.w;
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        float dot = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          dot += fmaxf(acc[b][0][j] + bsum[j], 0.f) * wp[j];
-          dot += fmaxf(acc[b][1][j] + bsum[4 + j], 0.f) * wp[4 + j];
-        }
-        dot += __shfl_xor(dot, 16);
-        dot += __shfl_xor(dot, 32);
-        if (kg == 0) sPsi[cg][(pb2 * 2 + b) * 16 + lr] = dot;
-      }
-    }
-    __syncthreads();
-    float psi[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int i = (pb2 * 2 + b) * 16 + lr;
-      psi[b] = 1.f / (1.f + expf(-(sPsi[0][i] + sPsi[1][i] + sPsi[2][i] + sPsi[3][i] + sB[4 * Ch])));
-      if (d.psi_out && valid[b] && kg == 0 && cg == 0) d.psi_out[((size_t)nn[b] * d.LH + yy[b]) * d.LW + px[b]] = psi[b];
-    }
-    // ---- att = psi * (W' x_res) + b' for the 4 pixels under each low-resolution pixel ----
-    {
-      const float4 b0 = *reinterpret_cast<const float4*>(sB + 3 * Ch + cg * 32 + kg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(sB + 3 * Ch + cg * 32 + kg * 8 + 4);
-      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] = psi[b] * att[t4][b][0][j] + bb[j];
-            v[4 + j] = psi[b] * att[t4][b][1][j] + bb[4 + j];
-          }
-          u32x4 h, l;
-          drs_sp_split8(v, h, l);
-          if (valid[b]) {
-            char* o = orow[b] + (size_t)((t4 >> 1) * OW + (t4 & 1)) * d.out_cs * 4 + ooff[b];
-            drs_store16(o, h);
-            drs_store16(o + 64, l);
-          }
-        }
-    }
-    __syncthreads();  // sG / sPsi are rewritten by the next item
-  }
-}
+// (The first structure - every wave loading its own operands, weight fragments straight from global memory: 57 -> 48 us -
+// was removed in round 4; the structure below superseded it at 36 us and is covered by the same goldens.)
 
-// ---- wide variant, second structure: no operand is fetched twice --------------------------------------------------------
-// The structure above lets every wave load its own operands: the 0.5 MB of weights twice per block (two pixel halves), x four
+// No operand is fetched twice.  Letting every wave load its own operands costs the 0.5 MB of weights twice per block (two pixel halves), x four
 // times and x_res four times (four channel groups): 2.2 MB of L2 -> CU traffic per block for 0.7 MB of distinct bytes, all
 // 256 CUs at once - it runs at the L2's pace (48 us, the pipelined form; 57 us before), not HBM's (118 MB: 22 us).
 // Here a wave owns ONE 16-channel tile (its weights: 64 KB, read by nobody else) for ALL 64 pixels of the block, and the
@@ -758,27 +508,16 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
               DRS_ERR_SHAPE, "attn_gate: channel strides / offsets must be multiples of 32");
   if ((long long)d.N * d.LH * d.LW == 0) return DRS_OK;
   if (d.Ch == 128) {
-    // DRS_GATE_WIDE=1: the first structure (every wave loads its own operands)
-    static const int wide_env = getenv("DRS_GATE_WIDE") ? atoi(getenv("DRS_GATE_WIDE")) : 2;
     int num_cu = 0;
     const long long nitems = ((long long)d.N * d.LH * ((d.LW + 15) / 16) + 3) / 4;
-    if (wide_env == 2) {
-      auto kern = d.Cc == 256 ? attn_gate_wide2_kernel<8> : attn_gate_wide2_kernel<4>;
-      const int ncx = d.Cc / 32;
-      const size_t xb = (size_t)4 * ncx * 16 * 128, tb = (size_t)4 * 4 * 16 * 128;
-      const size_t lds = (xb > 2 * tb ? xb : 2 * tb) + tb + (size_t)(8 * 64 + 3 * 128 + 4) * 4;
-      const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
-      if (rc) return rc;
-      const long long blocks = nitems < 4LL * num_cu ? nitems : 4LL * num_cu;
-      DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds, s, d);
-      DRS_CHECK_HIP(hipGetLastError());
-      return DRS_OK;
-    }
-    auto kern = d.Cc == 256 ? attn_gate_wide_kernel<8> : attn_gate_wide_kernel<4>;
-    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 0, &num_cu);
+    auto kern = d.Cc == 256 ? attn_gate_wide2_kernel<8> : attn_gate_wide2_kernel<4>;
+    const int ncx = d.Cc / 32;
+    const size_t xb = (size_t)4 * ncx * 16 * 128, tb = (size_t)4 * 4 * 16 * 128;
+    const size_t lds = (xb > 2 * tb ? xb : 2 * tb) + tb + (size_t)(8 * 64 + 3 * 128 + 4) * 4;
+    const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
     if (rc) return rc;
     const long long blocks = nitems < 4LL * num_cu ? nitems : 4LL * num_cu;
-    DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), 0, s, d);
+    DRS_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds, s, d);
     DRS_CHECK_HIP(hipGetLastError());
     return DRS_OK;
   }

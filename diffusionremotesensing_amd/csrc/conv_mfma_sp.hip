@@ -330,10 +330,9 @@ int sp_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
 }  // namespace
 
 // Eligibility: 3x3 stride 1 on 16-row patches, SP-format input(s), SP-format output (or the fused fp32 projection).
-// DRS_SPK=0 sends these layers to the lock-step kernel (tapconv_mfma_kernel<.., SP>).
+// Layers it does not take (8-row patches, gates, residuals ...) run on the lock-step kernel (tapconv_mfma_kernel<.., SP>).
 bool drs_tapconv_sp_supported(const TapConv& d, int impl) {
-  static const int env = getenv("DRS_SPK") ? atoi(getenv("DRS_SPK")) : 1;
-  if (!env || impl != DRS_IMPL_MFMA_BF16X3) return false;
+  if (impl != DRS_IMPL_MFMA_BF16X3) return false;
   if (!d.in || !d.in_sp || !sp_std3x3(d) || !d.zero_line) return false;
   if (d.gate || d.in_add || d.res || d.sigmoid || d.out_nchw || d.TH <= 8) return false;
   if ((d.in_co & 31) || !(d.in_cs == 16 || (d.in_cs & 31) == 0)) return false;

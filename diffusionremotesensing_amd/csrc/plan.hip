@@ -1344,8 +1344,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     // the attention gate: they only need ups.i.conv's output, are three tiny launches' worth of latency (35 us per
     // forward on the main stream) and occupy a fraction of the CUs.  So: UpConvBlock conv, [edges || gate], att-half,
     // composite.  Everything else keeps the reference's order (gate first).
-    static const int edges_env = getenv("DRS_EDGES_ASIDE") ? atoi(getenv("DRS_EDGES_ASIDE")) : 1;
-    const bool edges_aside = st.upfuse && mlp_side && !concurrent && edges_env != 0;
+    const bool edges_aside = st.upfuse && mlp_side && !concurrent;
     if (edges_aside) {
       RUN(upconv_block());
       DRS_CHECK_HIP(hipEventRecord(plan->ev_edge_in[i], s));
