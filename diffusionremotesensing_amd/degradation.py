@@ -12,6 +12,7 @@ being drawn ONCE per dataset object with `random.triangular(0.5, 1.5, 1)` (quirk
 reference uses (Python `random` for the level, numpy's global generator for everything else) drawn in its order, item by
 item (`reference_noise`); the add and the clip run on the device (`drs_add_noise_clip_f32`).  Seeded alike, the feed
 reproduces the reference's items bit for bit (tests/test_gpu_degradation.py, fixtures from the reference function itself).
+`load_image_folder_u8` fills the cache from an image folder (decode + the launch transform's resize with Pillow, once).
 Not covered: the BSRGAN degradation.
 """
 import ctypes as C
@@ -88,6 +89,42 @@ def add_reference_noise(x, noise_level1=2, noise_level2=10):
     return x
 
 
+def load_image_folder_u8(root_dir, image_size=None, rank=0, world_size=1):
+    """Decode side of the reference's `get_data_superres` (utils.py:93-138) + the `transforms.Resize((image_size,
+    image_size))` its `launch` hands it as `transform` (train_diffusion_superres.py:594-605): the images of `root_dir` in
+    `sorted(os.listdir(...))` order, opened with Pillow (`data_format='PIL'`), resized to image_size x image_size when they
+    are not already (torchvision's Resize on a PIL image is `img.resize((w, h), BILINEAR)`: the same Pillow call is made
+    here, so the bytes are the reference's), stacked as ONE (L, C, S, S) uint8 tensor on the host - the HR cache
+    `DeviceSuperresFeed` then keeps on the device.  Everything after the decode (bicubic down-sampling, blur, noise,
+    ToTensor) happens per batch on the device.  Done once per dataset, not per item per epoch.
+
+    `rank` / `world_size`: decode only this rank's shard (every world-th file, equal shard sizes: the remainder is
+    dropped, see launch()).  8-bit modes L / RGB / RGBA (what ToTensor turns into 1 / 3 / 4 channels of uint8 / 255); other
+    modes raise."""
+    import os
+
+    from PIL import Image
+    names = sorted(os.listdir(root_dir))
+    per_rank = len(names) // world_size
+    if per_rank == 0:
+        raise ValueError(f"dataset of {len(names)} images in {root_dir} cannot be sharded over {world_size} ranks")
+    names = names[rank::world_size][:per_rank]
+    planes = []
+    for name in names:
+        with Image.open(os.path.join(root_dir, name)) as y:
+            y.load()
+            if y.mode not in ("L", "RGB", "RGBA"):
+                raise ValueError(f"{name}: image mode {y.mode!r} is not an 8-bit L / RGB / RGBA image")
+            if image_size is not None and y.size != (image_size, image_size):
+                y = y.resize((image_size, image_size), Image.BILINEAR)
+            a = np.asarray(y, dtype=np.uint8)
+        planes.append(a[None] if a.ndim == 2 else np.moveaxis(a, -1, 0))
+    shapes = {p.shape for p in planes}
+    if len(shapes) != 1:
+        raise ValueError(f"images of {root_dir} differ in shape {sorted(shapes)}: pass image_size, as the reference's launch does")
+    return torch.from_numpy(np.ascontiguousarray(np.stack(planes)))
+
+
 class DeviceSuperresFeed:
     """Iterable of (lr, hr) float batches drawn from a uint8 HR cache on the device: what
     `DataLoader(get_data_superres(root, magnification_factor, blur_radius), batch_size, shuffle)` yields, without
@@ -107,6 +144,12 @@ class DeviceSuperresFeed:
 
     def __len__(self):
         return (self.hr.shape[0] + self.batch_size - 1) // self.batch_size
+
+    def item(self, idx):
+        """(x, y) of one dataset item, (C, h, w) / (C, H, W): `dataset[idx]` of the reference's Dataset (no noise draw is
+        consumed for Gauss_noise feeds: previews and the final sampling only need the degraded image's shape and content)."""
+        x, y = downblur(self.hr[idx:idx + 1], self.magnification_factor, self.blur_radius)
+        return x[0], y[0]
 
     def __iter__(self):
         n = self.hr.shape[0]

@@ -287,8 +287,10 @@ class SyntheticSuperresDataset(torch.utils.data.Dataset):
 
 
 def launch(args):
-    """Reference launch (:513-693) for the hot path: model + Diffusion + train + final sampling.  Dataset
-    wiring for image folders is out of scope; `--dataset_path synthetic[:N]` selects seeded patches."""
+    """Reference launch (:513-693) for the hot path: model + Diffusion + train + final sampling.  `--dataset_path` is the
+    reference's image folder (`<path>/train_original`, `<path>/val_original`, :597-598: decoded once with Pillow into a uint8
+    cache on the device, DownBlur / DownBlurNoise per batch on the device) or `synthetic[:N]` / `synthetic_u8[:N]` (seeded
+    patches; float pairs / the same device feed)."""
     from torch.utils.data import DataLoader
     from torch.utils.data.distributed import DistributedSampler
 
@@ -315,42 +317,57 @@ def launch(args):
         device = torch.device("cuda")
 
     spec = str(args.dataset_path or "")
-    if not spec.startswith("synthetic"):
-        raise NotImplementedError("image-folder datasets (reference utils.get_data_superres*) are outside the hot "
-                                  "path; use --dataset_path synthetic[:N] or synthetic_u8[:N]")
-    length = int(spec.split(":")[1]) if ":" in spec else 4 * args.batch_size
     ch = args.inp_out_channels
-    train_dataset = SyntheticSuperresDataset(length, ch, args.image_size, args.magnification_factor, seed=1)
-    val_dataset = SyntheticSuperresDataset(max(length // 4, 1), ch, args.image_size, args.magnification_factor, seed=2)
-    if spec.startswith("synthetic_u8"):
+    r, wsz = (drs_dist.rank(), drs_dist.world_size()) if args.multiple_gpus else (0, 1)
+    device_feed = not spec.startswith("synthetic") or spec.startswith("synthetic_u8")
+    if device_feed:
         # the reference's DownBlur feed (utils.get_data_superres: bicubic down-sampling + Gaussian blur per item with
         # Pillow on the host) from a uint8 HR cache on the device, bit-exact (degradation.py); rank r owns every
         # world-th image like DistributedSampler
-        from .degradation import DeviceSuperresFeed
+        from .degradation import DeviceSuperresFeed, load_image_folder_u8
         if args.Degradation_type.lower() not in ("downblur", "downblurnoise"):
-            raise NotImplementedError("the on-device feed implements Degradation_type=DownBlur and DownBlurNoise")
+            raise NotImplementedError("the on-device feed implements Degradation_type=DownBlur and DownBlurNoise "
+                                      "(the BSRGAN degradation is outside the hot path)")
         gauss_noise = args.Degradation_type.lower() == "downblurnoise"  # (reference :612-616: Gauss_noise=True)
         radius = args.Blur_radius if args.Blur_radius == "random" else float(args.Blur_radius)
-        r, wsz = (drs_dist.rank(), drs_dist.world_size()) if args.multiple_gpus else (0, 1)
 
-        def feed(ds):
-            # equal shard sizes on every rank (DistributedSampler pads; here the remainder is dropped): ranks must run
-            # the same number of steps, or the per-step all-reduce of the longer shard never completes
-            per_rank = len(ds) // wsz
-            if per_rank == 0:
-                raise ValueError(f"dataset of {len(ds)} images cannot be sharded over {wsz} ranks")
-            u8 = (ds.hr[r::wsz][:per_rank] * 255).round().clamp(0, 255).to(torch.uint8).to(device)
-            return DeviceSuperresFeed(u8, args.magnification_factor, radius, args.batch_size, shuffle=True,
+        def make_feed(u8):
+            return DeviceSuperresFeed(u8.to(device), args.magnification_factor, radius, args.batch_size, shuffle=True,
                                       Gauss_noise=gauss_noise)
-        train_loader, val_loader = feed(train_dataset), feed(val_dataset)
-    elif args.multiple_gpus:
-        train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=False,
-                                  sampler=DistributedSampler(train_dataset))
-        val_loader = DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
-                                sampler=DistributedSampler(val_dataset))
+    if not spec.startswith("synthetic"):
+        # an image folder, laid out as the reference expects it (:597-598): <dataset_path>/train_original, /val_original.
+        # Decoded once with Pillow into the uint8 cache (this rank's shard only); resize / blur / noise per batch on the device
+        if not os.path.isdir(os.path.join(spec, "train_original")) or not os.path.isdir(os.path.join(spec, "val_original")):
+            raise FileNotFoundError(f"--dataset_path {spec!r}: expected the folders train_original/ and val_original/ "
+                                    "(or synthetic[:N] / synthetic_u8[:N])")
+        train_loader = make_feed(load_image_folder_u8(os.path.join(spec, "train_original"), args.image_size, r, wsz))
+        val_loader = make_feed(load_image_folder_u8(os.path.join(spec, "val_original"), args.image_size, r, wsz))
+        if train_loader.hr.shape[1] != ch:
+            raise ValueError(f"the images have {train_loader.hr.shape[1]} channels, --inp_out_channels is {ch}")
+        n_final = min(5, train_loader.hr.shape[0])
+        final_lr = [train_loader.item(i)[0] for i in range(n_final)]
     else:
-        train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True)
-        val_loader = DataLoader(val_dataset, batch_size=args.batch_size, shuffle=True)
+        length = int(spec.split(":")[1]) if ":" in spec else 4 * args.batch_size
+        train_dataset = SyntheticSuperresDataset(length, ch, args.image_size, args.magnification_factor, seed=1)
+        val_dataset = SyntheticSuperresDataset(max(length // 4, 1), ch, args.image_size, args.magnification_factor, seed=2)
+        final_lr = [train_dataset[i][0] for i in range(min(5, len(train_dataset)))]
+        if device_feed:
+            def feed(ds):
+                # equal shard sizes on every rank (DistributedSampler pads; here the remainder is dropped): ranks must run
+                # the same number of steps, or the per-step all-reduce of the longer shard never completes
+                per_rank = len(ds) // wsz
+                if per_rank == 0:
+                    raise ValueError(f"dataset of {len(ds)} images cannot be sharded over {wsz} ranks")
+                return make_feed((ds.hr[r::wsz][:per_rank] * 255).round().clamp(0, 255).to(torch.uint8))
+            train_loader, val_loader = feed(train_dataset), feed(val_dataset)
+        elif args.multiple_gpus:
+            train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=False,
+                                      sampler=DistributedSampler(train_dataset))
+            val_loader = DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
+                                    sampler=DistributedSampler(val_dataset))
+        else:
+            train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True)
+            val_loader = DataLoader(val_dataset, batch_size=args.batch_size, shuffle=True)
 
     print("Using Residual Attention UNet")
     model = Residual_Attention_UNet_superres(ch, ch, device).to(device)
@@ -369,8 +386,8 @@ def launch(args):
                     verbose=True)
     if args.multiple_gpus:
         drs_dist.destroy_process_group()
-    outs = [diffusion.sample(n=1, model=model, lr_img=train_dataset[i][0], input_channels=ch,
-                             generate_video=args.generate_video) for i in range(min(5, len(train_dataset)))]
+    outs = [diffusion.sample(n=1, model=model, lr_img=lr_i, input_channels=ch, generate_video=args.generate_video)
+            for lr_i in final_lr]
     torch.save(torch.cat(outs).cpu(), os.path.join(os.getcwd(), "models_run", args.model_name, "results",
                                                   "superres_results.pt"))
 

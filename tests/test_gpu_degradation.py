@@ -99,3 +99,60 @@ def test_cli_launch_with_device_feed(dev, tmp_path, monkeypatch, degradation):
     assert set(snap) == {"MODEL_STATE", "EPOCHS_RUN"} and len(snap["MODEL_STATE"]) == 299
     res = torch.load(tmp_path / "models_run" / "cli_test" / "results" / "superres_results.pt")
     assert res.shape == (5, 3, 32, 32) and torch.isfinite(res).all()
+
+
+def _write_folder(root, n_train, n_val, size=32, odd=None):
+    """<root>/train_original and /val_original of RGB PNGs (one of them `odd`-sized: the launch transform resizes it)."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    for sub, n in (("train_original", n_train), ("val_original", n_val)):
+        os.makedirs(os.path.join(root, sub))
+        for i in range(n):
+            s_ = odd if (odd and sub == "train_original" and i == 1) else (size, size)
+            Image.fromarray(rng.integers(0, 256, s_ + (3,), dtype=np.uint8)).save(os.path.join(root, sub, f"p{i:03d}.png"))
+
+
+def test_image_folder_feed_matches_oracle(dev, tmp_path):
+    """The device feed over an image folder == the reference's dataset items: Image.open -> Resize((S, S)) -> bicubic down
+    -> GaussianBlur -> ToTensor (utils.py:126-166 under train_diffusion_superres.py:594-605), bit for bit; the Pillow
+    arithmetic after the decode comes from oracle/degradation_oracle.py (pinned by Pillow fixtures)."""
+    from PIL import Image
+    from diffusionremotesensing_amd.degradation import DeviceSuperresFeed, load_image_folder_u8
+    from oracle import degradation_oracle as G
+    _write_folder(str(tmp_path), 6, 2, size=32, odd=(48, 40))
+    root = os.path.join(str(tmp_path), "train_original")
+    u8 = load_image_folder_u8(root, 32)
+    feed = DeviceSuperresFeed(u8.to(dev), 2, blur_radius=0.8, batch_size=4, shuffle=False)
+    got = list(feed)
+    decoded = []
+    for name in sorted(os.listdir(root)):
+        y = Image.open(os.path.join(root, name))
+        if y.size != (32, 32):
+            y = y.resize((32, 32), Image.BILINEAR)  # torchvision's Resize on a PIL image
+        decoded.append(np.moveaxis(np.asarray(y), -1, 0))
+    decoded = np.stack(decoded)
+    wx, wy = G.downblur(decoded, 16, 16, 0.8)
+    assert torch.equal(torch.cat([b[0] for b in got]).cpu(), torch.from_numpy(wx))
+    assert torch.equal(torch.cat([b[1] for b in got]).cpu(), torch.from_numpy(wy))
+    x1, y1 = feed.item(1)
+    assert torch.equal(x1.cpu(), torch.from_numpy(wx[1])) and torch.equal(y1.cpu(), torch.from_numpy(wy[1]))
+
+
+def test_cli_launch_on_image_folder(dev, tmp_path, monkeypatch):
+    """The reference's CLI on the reference's dataset layout (`--dataset_path <dir>` with train_original/ and
+    val_original/): one epoch, validation, snapshot, final sampling from the first five training images."""
+    from diffusionremotesensing_amd import train_diffusion_superres as T
+    data = tmp_path / "data"
+    _write_folder(str(data), 8, 4, size=32)
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    T.main(["--epochs", "1", "--batch_size", "4", "--image_size", "32", "--model_name", "cli_folder", "--noise_steps", "10",
+            "--loss", "MSE", "--magnification_factor", "2", "--dataset_path", str(data), "--Degradation_type", "DownBlur",
+            "--Blur_radius", "0.5", "--check_preds_epoch", "1"])
+    snap = torch.load(tmp_path / "models_run" / "cli_folder" / "weights" / "snapshot.pt")
+    assert set(snap) == {"MODEL_STATE", "EPOCHS_RUN"} and len(snap["MODEL_STATE"]) == 299
+    res = torch.load(tmp_path / "models_run" / "cli_folder" / "results" / "superres_results.pt")
+    assert res.shape == (5, 3, 32, 32) and torch.isfinite(res).all()
+    with pytest.raises(FileNotFoundError):
+        T.main(["--epochs", "1", "--batch_size", "4", "--image_size", "32", "--model_name", "cli_folder", "--noise_steps", "10",
+                "--loss", "MSE", "--magnification_factor", "2", "--dataset_path", str(tmp_path / "nowhere")])

@@ -204,3 +204,41 @@ def test_video_maker_without_cv2(tmp_path):
     saved = torch.load(path + ".frames.pt") if os.path.exists(path + ".frames.pt") else None
     assert saved is None or (saved.shape == (3, 8, 8, 3) and saved.dtype == torch.uint8)
     assert saved is not None or os.path.exists(path)
+
+
+def test_image_folder_loader_decodes_like_the_reference_dataset(tmp_path):
+    """`load_image_folder_u8` = Image.open in sorted(os.listdir) order + the launch transform's Resize((S, S)) (Pillow
+    BILINEAR, what torchvision does on PIL images; reference utils.py:93-138, train_diffusion_superres.py:594-605), with
+    DistributedSampler-like sharding."""
+    import numpy as np
+    from PIL import Image
+    from diffusionremotesensing_amd.degradation import load_image_folder_u8
+    rng = np.random.default_rng(3)
+    imgs = {}
+    for i, size in enumerate([(32, 32), (40, 48), (32, 32), (64, 64), (32, 32)]):
+        a = rng.integers(0, 256, size + (3,), dtype=np.uint8)
+        name = f"img_{9 - i}.png"  # written in reverse lexical order: the loader must sort
+        Image.fromarray(a).save(tmp_path / name)
+        imgs[name] = a
+    got = load_image_folder_u8(str(tmp_path), 32)
+    assert got.shape == (5, 3, 32, 32) and got.dtype == torch.uint8
+    for k, name in enumerate(sorted(imgs)):
+        y = Image.fromarray(imgs[name])
+        if y.size != (32, 32):
+            y = y.resize((32, 32), Image.BILINEAR)
+        assert np.array_equal(got[k].numpy(), np.moveaxis(np.asarray(y), -1, 0)), name
+    # two ranks: every second file, equal shard sizes (the odd one out is dropped)
+    r0, r1 = load_image_folder_u8(str(tmp_path), 32, 0, 2), load_image_folder_u8(str(tmp_path), 32, 1, 2)
+    assert r0.shape[0] == r1.shape[0] == 2
+    assert torch.equal(r0, got[0::2][:2]) and torch.equal(r1, got[1::2][:2])
+    with pytest.raises(ValueError):
+        load_image_folder_u8(str(tmp_path))  # mixed sizes and no image_size
+    gray = tmp_path / "gray"
+    gray.mkdir()
+    g = rng.integers(0, 256, (8, 8), dtype=np.uint8)
+    Image.fromarray(g).save(gray / "a.png")
+    one = load_image_folder_u8(str(gray), 8)
+    assert one.shape == (1, 1, 8, 8) and np.array_equal(one[0, 0].numpy(), g)  # mode L: one channel, like ToTensor
+    Image.fromarray(g.astype(np.uint16) * 200).save(gray / "b.png")  # mode I;16: not an 8-bit image
+    with pytest.raises(ValueError):
+        load_image_folder_u8(str(gray), 8)

@@ -78,6 +78,31 @@ def test_end_to_end_sample(golden, seeded_sd):
     assert abs(x.double().sum().item() - golden["g7_small_checksum"][0]) < 1e-2
 
 
+def test_full_length_chain(golden, seeded_sd):
+    """G10: the reference's own `sample` over the full configs[1] schedule (T = 1500, 1499 updates,
+    train_diffusion_superres.py:234-249) at 32x32, n = 2, damped output projection: final x and the states entering
+    steps 1400 / 1000 / 500 / 100 / 1."""
+    from conftest import LONGCHAIN_STEPS, longchain_state_dict
+    from diffusionremotesensing_amd import synthetic
+    a, ah, b = D.schedule("cosine", 1500)
+    seen = {}
+    inner = U.OracleUNet(longchain_state_dict(seeded_sd))
+
+    class Recorder(torch.nn.Module):
+        def forward(self, x, t, lr_img, mag):
+            if int(t[0]) in LONGCHAIN_STEPS:
+                seen[int(t[0])] = x.clone()
+            return inner(x, t, lr_img, mag)
+
+    lr1 = synthetic.tensor_uniform("g10.lr", (3, 16, 16))
+    x = D.sample(Recorder(), 2, lr1, 1500, a, ah, b, 2, 32, noise_source=replay_noise_source(1010))
+    for i in LONGCHAIN_STEPS:
+        ref = torch.from_numpy(golden[f"g10_x_entering_{i}"])
+        assert torch.allclose(seen[i], ref, rtol=0, atol=1e-6 * ref.abs().max().item()), i
+    ref = torch.from_numpy(golden["g10_x"])
+    assert torch.allclose(x, ref, rtol=0, atol=1e-6 * ref.abs().max().item())
+
+
 # ---- SAR -> NDVI and class-conditional generation variants (tools/make_golden_variants.py) ----
 def test_sar_variant(vgolden, seeded_sd_sar):
     from diffusionremotesensing_amd import synthetic

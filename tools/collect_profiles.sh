@@ -11,12 +11,7 @@ cd $R
 DRS_BENCH_OPS=$O/bench_ops.txt rocprofv3 --kernel-trace --stats -d /tmp/kt -o b -- python3 bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.log || exit 1
 python3 tools/rocpd_sequence.py $(find /tmp/kt -name "b_results.db" | head -1) 40 > $O/step_kernel_sequence.txt || exit 1
 python3 tools/rocpd_stats.py $(find /tmp/kt -name "b_results.db" | head -1) 40 --csv > $O/bench_kernel_stats.csv || exit 1
-# (3 chain steps + the logged forward = 4 forwards per pass; every pass writes the same launch log)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/f -- python3 tools/profile_forward.py --steps 3 --launch-log $O/launch_log.txt > $O/f.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/w -- python3 tools/profile_forward.py --steps 3 --launch-log $O/launch_log_w.txt > $O/w.log 2>&1 || exit 1
-cmp $O/launch_log.txt $O/launch_log_w.txt || exit 1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/sq -- python3 tools/profile_forward.py --steps 3 --launch-log $O/launch_log_sq.txt > $O/sq.log 2>&1 || exit 1
-python3 tools/collect_pmc.py $O/pmc_traffic.json 4 /tmp/f /tmp/w /tmp/sq --ops=$O/launch_log.txt || exit 1
+bash tools/collect_pmc_passes.sh $O || exit 1
 # configs[2] per-rank train step (exact-fp32 MFMA): kernel stats + the bench line
 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o t -- python3 bench.py --workload train --steps 8 --warmup 2 > $O/train_under_rocprof.json 2> $O/kt2.log || exit 1
 python3 tools/rocpd_stats.py $(find /tmp/kt2 -name "t_results.db" | head -1) 40 --csv > $O/train_kernel_stats.csv || exit 1
