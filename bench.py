@@ -99,7 +99,7 @@ def psnr_vs_reference(model, dev, impl):
     mse = ((x.clamp(0, 1) - ref.clamp(0, 1)) ** 2).mean().item()
     rel_l2 = ((x - ref).norm() / ref.norm()).item()
     return {"psnr_db": round(-10 * torch.log10(torch.tensor(max(mse, 1e-20))).item(), 2), "rel_l2": float(f"{rel_l2:.3e}"),
-            "chain": "configs[0]: n=4, 64x64->128x128, T=50, reference noise replayed; fixture stored as fp16"}
+            "chain": "configs[0]: n=4, 64x64->128x128, T=50, reference noise replayed (fp32 fixture from the reference's own run)"}
 
 
 def _build_workload(wl, impl, dev, rank, multi):
@@ -125,7 +125,7 @@ def _build_workload(wl, impl, dev, rank, multi):
         timpl = os.environ.get("DRS_TRAIN_IMPL", "mfma_f32")
         return (step, "train_steps/s (16 images per rank)", 16, 3 * 454.39,
                 f"BASELINE configs[2] per-rank shape: superres 256x256 train step, batch 16 per GPU, MSE, Adam, train_impl={timpl}",
-                "f32 (v_mfma_f32_16x16x4_f32)" if timpl == "mfma_f32" else DTYPE.get(timpl, timpl))
+                "f32 (v_mfma_f32_16x16x4_f32)" if timpl == "mfma_f32" else DTYPE.get(timpl, timpl), m)
     if wl == "sar":
         from diffusionremotesensing_amd.train_diffusion_SAR_TO_NDVI import Diffusion
         from diffusionremotesensing_amd.UNet_model_SAR_TO_NDVI import Residual_Attention_UNet_SAR_TO_NDVI
@@ -146,7 +146,7 @@ def _build_workload(wl, impl, dev, rank, multi):
             state["i"] -= 1
             state["first"] = False
         return (step, "batch32_steps/s", 32, 32 * 7.088,
-                "BASELINE configs[3]: SAR->NDVI UNet 128x128, 1-ch out / 2-ch SAR, batch 32 per GPU, sampling step", DTYPE[impl])
+                "BASELINE configs[3]: SAR->NDVI UNet 128x128, 1-ch out / 2-ch SAR, batch 32 per GPU, sampling step", DTYPE[impl], m)
     from diffusionremotesensing_amd.generate_new_imgs.train_diffusion_generation import Diffusion
     from diffusionremotesensing_amd.generate_new_imgs.UNet_model_generation import Residual_Attention_UNet_generation
     m = Residual_Attention_UNet_generation(3, 3, 10, dev)
@@ -169,11 +169,11 @@ def _build_workload(wl, impl, dev, rank, multi):
         state["first"] = False
     return (step, "batch64_cfg_steps/s", 64, 2 * 64 * 1.771,
             "BASELINE configs[4]: class-conditional generation UNet 64x64, 10 classes, batch 64 per GPU, one CFG "
-            "sampling step = conditional + unconditional forward (one 128-row batch) + guided update", DTYPE[impl])
+            "sampling step = conditional + unconditional forward (one 128-row batch) + guided update", DTYPE[impl], m)
 
 
 def _time_workload(wl, impl, dev, rank, steps, warmup, sync):
-    step, unit, batch, gflop, desc, dtype = _build_workload(wl, impl, dev, rank, torch.distributed.is_initialized())
+    step, unit, batch, gflop, desc, dtype, m = _build_workload(wl, impl, dev, rank, torch.distributed.is_initialized())
     ctx = torch.enable_grad() if wl == "train" else torch.no_grad()
     with ctx:
         for _ in range(max(warmup, 1)):
@@ -184,7 +184,7 @@ def _time_workload(wl, impl, dev, rank, steps, warmup, sync):
             step()
         sync()
         elapsed = time.perf_counter() - t0
-    engine.check_faults()  # (outside the timed region) a forward whose wave-specialised kernels gave up on a counter is not a measurement
+    m.hip_engine().check_faults()  # (outside the timed region) a forward whose wave-specialised kernels gave up on a counter is not a measurement
     return elapsed, unit, batch, gflop, desc, dtype
 
 
