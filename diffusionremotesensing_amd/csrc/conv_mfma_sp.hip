@@ -109,6 +109,15 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
   const int nck = g.nchunks + (HAS2 ? g.nchunks2 : 0);
   const int S = my_items * nck;
   if (S == 0) return;
+  // K-step order of an item with a second input (the block's 1x1 shortcut): its one-tap steps FOLLOW the 3x3 steps.  They
+  // cost 3 - 3.7 us each for 0.6 us of MFMAs (a mover starts the loads of step k + 1 when it is done with step k, so a short
+  // step exposes a memory round trip).  Interleaving them with the 3x3 steps (L S L S ..., round 4) made it worse - conv2 +
+  // shortcut of block 1: 74 -> 93 us - because every 3x3 window then lands in the SAME buffer and its 41 KB store can only
+  // start when the previous 3x3 step ends: the double buffering is gone.
+  auto step_kind = [&](int c_, bool& second_, int& cc_) __attribute__((always_inline)) {
+    second_ = HAS2 && c_ >= g.nchunks;
+    cc_ = second_ ? c_ - g.nchunks : c_;
+  };
   auto item_of = [&](int ordinal, int& n_, int& ty0_, int& tx0_, int& n0_) __attribute__((always_inline)) {
     int it = lo_item + ordinal * nb8 + j8;
     n0_ = (it % ngroups) * BNB;
@@ -212,7 +221,9 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const bool second = HAS2 && c >= g.nchunks;
+      bool second;
+      int cc_unused;
+      step_kind(c, second, cc_unused);
       const char* buf = sWin + (k & 1) * WBUF;
       const unsigned ltarget = 4u * (unsigned)(k + 1);  // four movers per column and step
       SP_STAMP(7);
