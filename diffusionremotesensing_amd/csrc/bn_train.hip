@@ -4,18 +4,44 @@
 //   conv (raw weights) -> Z  ->  bn_stats(Z)  ->  bn_finalize  ->  bn_apply(Z) with the block's activation / adds.
 #include "drs_common.h"
 
+template <typename T>
+__device__ __forceinline__ T sum16(T (*red)[64], int cl) {  // the 16 row-group partials of channel column cl
+  T v = 0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) v += red[g][cl];
+  return v;
+}
+
 // Per-channel sum and sum of squares.  Thread = (pixel row in block, group of 4 channels): float4 loads, fp32 partials
-// over a few thousand elements per thread, LDS reduction over the block, then ONE fp64 atomic per channel per block.
+// over a few thousand elements per thread, LDS reduction over the block, then the block's 2 x C fp64 partial sums go to
+// ITS row of `partials` (gridDim.x rows); bn_finalize_kernel adds the rows up.  (Atomics onto 2 x C shared addresses
+// serialise: 512 blocks x ~90 ns = 46 us per launch at ANY tensor size.)
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, long long npix, int C, int cs,
-                                                       int co, double* __restrict__ sums) {
+                                                       int co, double* __restrict__ partials) {
   __shared__ float red[2][256][4];
   const int c4n = C >> 2;             // channel groups
   const int rows = 256 / c4n;         // pixel rows handled concurrently by the block (C <= 1024)
   const int cg = threadIdx.x % c4n, row = threadIdx.x / c4n;
   float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
   if (row < rows) {
-    for (long long p = (long long)blockIdx.x * rows + row; p < npix; p += (long long)gridDim.x * rows) {
-      const float4 v = *reinterpret_cast<const float4*>(z + p * cs + co + cg * 4);
+    // four independent 16-byte loads in flight per thread (with one, 512 blocks keep 2 MB in flight: 1.0 - 1.6 TB/s measured)
+    const long long stride = (long long)gridDim.x * rows;
+    const float* base = z + co + cg * 4;
+    long long p = (long long)blockIdx.x * rows + row;
+    for (; p + 3 * stride < npix; p += 4 * stride) {
+      const float4 v0 = *reinterpret_cast<const float4*>(base + p * cs);
+      const float4 v1 = *reinterpret_cast<const float4*>(base + (p + stride) * cs);
+      const float4 v2 = *reinterpret_cast<const float4*>(base + (p + 2 * stride) * cs);
+      const float4 v3 = *reinterpret_cast<const float4*>(base + (p + 3 * stride) * cs);
+      s[0] += (v0.x + v1.x) + (v2.x + v3.x); s[1] += (v0.y + v1.y) + (v2.y + v3.y);
+      s[2] += (v0.z + v1.z) + (v2.z + v3.z); s[3] += (v0.w + v1.w) + (v2.w + v3.w);
+      q[0] += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
+      q[1] += (v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y);
+      q[2] += (v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z);
+      q[3] += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
+    }
+    for (; p < npix; p += stride) {
+      const float4 v = *reinterpret_cast<const float4*>(base + p * cs);
       s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
       q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
     }
@@ -31,21 +57,38 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
         ds[j] += (double)red[0][r * c4n + threadIdx.x][j];
         dq[j] += (double)red[1][r * c4n + threadIdx.x][j];
       }
+    double* row = partials + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      atomicAdd(&sums[threadIdx.x * 4 + j], ds[j]);
-      atomicAdd(&sums[C + threadIdx.x * 4 + j], dq[j]);
+      row[threadIdx.x * 4 + j] = ds[j];
+      row[C + threadIdx.x * 4 + j] = dq[j];
     }
   }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, long long npix, int C, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double m = sums[c] / (double)npix;
-  double var = sums[C + c] / (double)npix - m * m;  // biased
+// Adds up the `nrows` partial rows and finalises: block = 64 channels x 4 row groups.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ partials, int nrows, long long npix, int C,
+                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var) {
+  __shared__ double red[2][16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s = 0, q = 0;
+  if (c < C)
+#pragma unroll 8
+    for (int r = rg; r < nrows; r += 16) {
+      s += partials[(size_t)r * 2 * C + c];
+      q += partials[(size_t)r * 2 * C + C + c];
+    }
+  red[0][rg][cl] = s;
+  red[1][rg][cl] = q;
+  __syncthreads();
+  if (rg != 0 || c >= C) return;
+  s = sum16(red[0], cl);
+  q = sum16(red[1], cl);
+  const double m = s / (double)npix;
+  double var = q / (double)npix - m * m;  // biased
   if (var < 0) var = 0;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -99,15 +142,13 @@ int drs_launch_bn_train(const float* z, int z_cs, int z_co, long long npix, long
   DRS_REQUIRE(C % 4 == 0 && C <= 1024, DRS_ERR_SHAPE, "bn_train: C=%d", C);
   DRS_REQUIRE((z_cs & 3) == 0 && (z_co & 3) == 0 && (out_cs & 3) == 0 && (out_co & 3) == 0, DRS_ERR_SHAPE,
               "bn_train: unaligned channel slices");
-  DRS_CHECK_HIP(hipMemsetAsync(sums_scratch, 0, 2 * (size_t)C * sizeof(double), s));
+  // (sums_scratch: DRS_RED_BLOCKS rows of 2 x C fp64 partial sums, rewritten by every call: calls must be stream-ordered)
   const int rows = 256 / (C >> 2);
   long long blocks = (npix + rows - 1) / rows;
-  // every block ends with 2*C fp64 atomics on the same 2*C addresses: 2048 blocks made those the whole cost (182 us
-  // at any size); 512 blocks still cover the chip twice
-  if (blocks > 512) blocks = 512;
+  if (blocks > DRS_RED_BLOCKS) blocks = DRS_RED_BLOCKS;
   if (blocks < 1) blocks = 1;
   DRS_LAUNCH(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, npix, C, z_cs, z_co, sums_scratch);
-  DRS_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_scratch, npix, C, eps, momentum, mean,
+  DRS_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, sums_scratch, (int)blocks, npix, C, eps, momentum, mean,
                      rstd, running_mean, running_var);
   long long total = npix * (C >> 2);
   long long ab = (total + 255) / 256;

@@ -111,6 +111,7 @@ struct DrsErr {
   } while (0)
 
 static inline int drs_cdiv(int a, int b) { return (a + b - 1) / b; }
+#define DRS_RED_BLOCKS 512  // most blocks a partial-sum reduction of the training kernels uses (size of the partials buffer)
 
 // Every kernel of the library is launched through DRS_LAUNCH (same arguments as hipLaunchKernelGGL).  While a plan runs a
 // PROFILED forward (drs_unet_profile_enable) on this host thread, the launch is also appended to that plan's launch log
@@ -287,21 +288,25 @@ int drs_launch_wgrad_mfma(const WgradDesc& d, float* partial, size_t partial_byt
 // the same on the bf16 matrix pipe, operands split hi + lo (wgrad_mfma_bf16.hip); DRS_TRAIN_WGRAD_IMPL=mfma_f32 disables it
 bool drs_wgrad_mfma_bf16_supported(const WgradDesc& d);
 int drs_launch_wgrad_mfma_bf16(const WgradDesc& d, float* partial, size_t partial_bytes, hipStream_t s);
+// `partials`: optional DRS_RED_BLOCKS x C floats of scratch (stream-ordered use): whole-tensor sums then run without atomics
 int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, long long pix_per_image, int per_image,
-                      int out_stride, float* out, hipStream_t s);
+                      int out_stride, float* out, hipStream_t s, float* partials = nullptr);
 int drs_launch_relu_mask(float* g, int g_cs, int g_co, const float* y, int y_cs, int y_co, int C, long long npix,
                          hipStream_t s);
 int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s_cs, int s_co, int C, long long npix,
                          int accumulate, hipStream_t s);
 int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float* mean, const float* rstd,
-                      const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* sums_scratch,
-                      float* dgamma, float* dbeta, hipStream_t s);
+                      const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* partials,
+                      double* sums, float* dgamma, float* dbeta, hipStream_t s);
 int drs_launch_gate_bwd(const float* x, const float* E, const float* psi, float* dx, float* dpsi_pre, int N, int LH,
                         int LW, int C, hipStream_t s);
 int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre, float* dP, float* dw, float* db, int C,
-                       long long npix, hipStream_t s);
-int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
-                            const float* temb, const float* dtemb, int stride, int B, int dim, float* dW1, float* db1,
-                            float* dW2, float* db2, const float* label_emb, const long long* labels, int label_batch,
-                            int num_classes, float* dlabel, hipStream_t s);
+                       long long npix, float* partials, hipStream_t s);
+// one entry per time MLP of the network (at most 8): parameters, the MLP's slice of the embedding / its gradient, gradient outputs
+struct DrsMlpBwd { const float *W1, *b1, *W2, *temb, *dtemb; float *dW1, *db1, *dW2, *db2; int dim; };
+struct DrsMlpBwdTable { DrsMlpBwd m[8]; int n; };
+int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const DrsMlpBwdTable& tab, int stride, int B,
+                            const float* label_emb, const long long* labels, int label_batch, int num_classes, float* dlabel,
+                            hipStream_t s);
+int drs_launch_stem_dgrad(const float* g, int g_cs, const float* w, float* dx, int N, int H, int W, int C, hipStream_t s);
 int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, hipStream_t s);

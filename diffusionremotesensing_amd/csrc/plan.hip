@@ -336,6 +336,7 @@ struct ConvLayer {
   size_t w_off = 0, b_off = 0;
   int t_Z = -1;         // train plans: pre-BatchNorm tensor
   size_t stats_off = 0;  // train plans: saved batch mean / rstd (2 x Cout floats) in the workspace
+  size_t sums_off = 0;   // train plans: this layer's fp64 reduction slots (2 x Cout) inside the forward / backward sums regions
 };
 struct PlanarConv { int w = -1, b = -1; int Cout = 0, Cin = 0; size_t w_off = 0, b_off = 0; };
 struct Mlp { int w1, b1, w2, b2, dim; size_t o_w1, o_b1, o_w2, o_b2; int temb_off; };
@@ -397,7 +398,12 @@ struct drs_plan {
   int temb_total = 0;
   std::vector<long long> mlp_table_host;
   std::vector<const void*> param_ptrs;  // as given to the last drs_unet_pack_weights
-  size_t o_bn_sums = 0;                  // train plans: fp64 scratch for the BatchNorm reductions
+  // train plans: fp64 totals of the BatchNorm reductions, one (2 x Cout) slot per layer, a region for the forward statistics
+  // followed by one for the backward sums; o_red = per-block partial sums of whichever reduction is running on the main
+  // stream (BatchNorm statistics, BatchNorm backward, bias-gradient column sums: kRedBlocks x 2 x 1024 doubles).  Partials +
+  // a small finishing kernel replaced per-block atomics onto the same 2 x Cout addresses: 512 blocks x 90 ns per serialised
+  // atomic = a 46 us floor under every one of those launches, whatever the tensor size (round 3: 63 of them per step).
+  size_t o_bn_sums = 0, bn_sums_bytes = 0, o_red = 0;
   bool packed_ok = false;
   const void* packed_ptr = nullptr;
   unsigned* fault_ptr = nullptr;  // device word of the current forward's packed buffer (TapConv::fault)
@@ -477,6 +483,7 @@ struct drs_plan {
 };
 
 static const size_t kWgradPartialBytes = 64ull << 20;
+static const int kRedBlocks = DRS_RED_BLOCKS;  // blocks of a partial-sum reduction (drs_common.h)
 static const int kDown[5] = {16, 32, 64, 128, 256};
 static const int kUp[5] = {256, 128, 64, 32, 16};
 
@@ -724,9 +731,10 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
         if (t.off == p->tensors[p->t_CAT[i]].off) t.sp = true;
   }
   if (cfg->flags & DRS_PLAN_TRAIN) {
-    p->o_bn_sums = ws; ws += align_up(2 * 1024 * sizeof(double));
+    size_t sums_cur = 0;
     auto addz = [&](ConvLayer& L, const std::string& nm, int hh, int ww) {
       L.stats_off = ws; ws += align_up(2 * (size_t)L.Cout * 4);
+      L.sums_off = sums_cur; sums_cur += 2 * (size_t)L.Cout * sizeof(double);
       L.t_Z = p->T(nm + ".pre_bn", ws, B, L.Cout, hh, ww);
     };
     for (int i = 0; i < 4; ++i) {
@@ -742,6 +750,9 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
       addz(p->dec[i].result, "attention_blocks." + si + ".result", 2 * lh, 2 * lw);
       addz(p->dec[i].conv, "ups." + si + ".conv_bn", lh, lw);
     }
+    p->bn_sums_bytes = align_up(sums_cur);
+    p->o_bn_sums = ws; ws += 2 * p->bn_sums_bytes;  // [forward | backward]
+    p->o_red = ws; ws += align_up((size_t)kRedBlocks * 2 * 1024 * sizeof(double));
   }
   if (cfg->flags & DRS_PLAN_TRAIN) {
     p->o_dtemb = ws; ws += align_up((size_t)B * p->temb_total * 4);
@@ -1016,7 +1027,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
     return drs_launch_bn_train(zc.out, L.Cout, 0, (long long)d.N * ppi, ppi, L.Cout,
                                (const float*)plan->param_ptrs[L.bn], (const float*)plan->param_ptrs[L.bn + 1],
                                (float*)plan->param_ptrs[L.bn + 2], (float*)plan->param_ptrs[L.bn + 3], c.bn_eps, 0.1f,
-                               (double*)((char*)ws + plan->o_bn_sums), stats, stats + L.Cout, d.post_add, d.post_cs, d.res,
+                               (double*)((char*)ws + plan->o_red), stats, stats + L.Cout, d.post_add, d.post_cs, d.res,
                                d.res_cs, d.res_co, d.out, d.out_cs, d.out_co, d.relu_pre, d.relu_post, s);
   };
   int rc;

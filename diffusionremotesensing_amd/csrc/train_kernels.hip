@@ -4,6 +4,14 @@
 // weights and run on the forward kernels (conv_mfma.hip / conv_direct.hip).
 #include "drs_common.h"
 
+template <typename T>
+__device__ __forceinline__ T sum16(T (*red)[64], int cl) {  // the 16 row-group partials of channel column cl
+  T v = 0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) v += red[g][cl];
+  return v;
+}
+
 static inline unsigned grid1d(long long total, int per_block, int cap) {
   long long b = (total + per_block - 1) / per_block;
   if (b > cap) b = cap;
@@ -168,15 +176,77 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
     }
   }
 }
+// whole-tensor column sums without atomics: block b sums its rows into partials[b][C] (grid-stride over row groups), the
+// finish kernel adds the rows into out
+__global__ __launch_bounds__(256) void colsum4_partial_kernel(const float* __restrict__ t, int cs, int co, int C, long long npix,
+                                                              float* __restrict__ partials) {
+  __shared__ float red[256][4];
+  const int qn = C >> 2;
+  const int rows = 256 / qn;
+  const int q = threadIdx.x % qn, row = threadIdx.x / qn;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) {
+    const float* base = t + co + q * 4;
+    const long long stride = (long long)gridDim.x * rows;
+    long long p = (long long)blockIdx.x * rows + row;
+    for (; p + 3 * stride < npix; p += 4 * stride) {
+      const float4 a = *reinterpret_cast<const float4*>(base + p * cs);
+      const float4 b = *reinterpret_cast<const float4*>(base + (p + stride) * cs);
+      const float4 c2 = *reinterpret_cast<const float4*>(base + (p + 2 * stride) * cs);
+      const float4 d = *reinterpret_cast<const float4*>(base + (p + 3 * stride) * cs);
+      s[0] += (a.x + b.x) + (c2.x + d.x); s[1] += (a.y + b.y) + (c2.y + d.y);
+      s[2] += (a.z + b.z) + (c2.z + d.z); s[3] += (a.w + b.w) + (c2.w + d.w);
+    }
+    for (; p < npix; p += stride) {
+      const float4 a = *reinterpret_cast<const float4*>(base + p * cs);
+      s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < qn) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = 0.f;
+      for (int r = 0; r < rows; ++r) v += red[r * qn + threadIdx.x][j];
+      partials[(size_t)blockIdx.x * C + threadIdx.x * 4 + j] = v;
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partials, int nrows, int C,
+                                                            float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float v = 0.f;
+  if (c < C)
+#pragma unroll 8
+    for (int r = rg; r < nrows; r += 16) v += partials[(size_t)r * C + c];
+  red[rg][cl] = v;
+  __syncthreads();
+  if (rg == 0 && c < C) out[c] += sum16(red, cl);
+}
 int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, long long pix_per_image, int per_image,
-                      int out_stride, float* out, hipStream_t s) {
+                      int out_stride, float* out, hipStream_t s, float* partials) {
   if (npix == 0) return DRS_OK;
-  long long rpb = 2048;
+  const bool vec4 = C % 4 == 0 && cs % 4 == 0 && co % 4 == 0 && C <= 1024 && 256 % (C >> 2) == 0;
+  if (partials && !per_image && vec4) {
+    // whole-tensor sums (bias gradients): every block would end in C float atomics onto the same C addresses - 2048 blocks x
+    // ~90 ns per serialised atomic set the launch time (95 - 210 us), not the 134 MB it reads
+    const int rows = 256 / (C >> 2);
+    const unsigned blocks = grid1d(npix, rows, DRS_RED_BLOCKS);
+    DRS_LAUNCH(colsum4_partial_kernel, dim3(blocks), dim3(256), 0, s, t, cs, co, C, npix, partials);
+    DRS_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, (int)blocks, C, out);
+    DRS_CHECK_HIP(hipGetLastError());
+    return DRS_OK;
+  }
+  long long rpb = per_image ? 512 : 2048;  // per-image sums: pix_per_image / rpb atomics per address (128 at 256 x 256)
   if (per_image) {  // blocks must not straddle images
     while (pix_per_image % rpb) rpb >>= 1;
   }
   const long long blocks = (npix + rpb - 1) / rpb;
-  if (C % 4 == 0 && cs % 4 == 0 && co % 4 == 0 && C <= 1024 && 256 % (C >> 2) == 0) {
+  if (vec4) {
     DRS_LAUNCH(colsum4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, cs, co, C, npix, pix_per_image, per_image,
                        out_stride, out, (int)rpb);
     DRS_CHECK_HIP(hipGetLastError());
@@ -233,76 +303,128 @@ int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s
 //   dbeta = sum g, dgamma = sum g*zhat, dz = gamma*rstd*(g - dbeta/M - zhat*dgamma/M).
 // Pass 1 reduces (fp64 atomics), pass 2 writes dz IN PLACE over z.
 // ---------------------------------------------------------------------------------------------------------------
+// thread = (pixel row in block, group of 4 channels): 16-byte loads, two pixels in flight per thread
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, int g_cs, int g_co,
                                                             const float* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu_pre, int C,
-                                                            long long npix, double* __restrict__ sums) {
-  __shared__ float red[2][256];
-  const int lanes_c = C < 256 ? C : 256;
-  const int rows = 256 / lanes_c;
-  const int c = threadIdx.x % lanes_c, row = threadIdx.x / lanes_c;
-  float s1 = 0.f, s2 = 0.f;
+                                                            long long npix, double* __restrict__ partials) {
+  __shared__ float red[2][256][4];
+  const int c4n = C >> 2;
+  const int rows = 256 / c4n;
+  const int cg = threadIdx.x % c4n, row = threadIdx.x / c4n;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (row < rows) {
-    const float m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
-    for (long long p = (long long)blockIdx.x * rows + row; p < npix; p += (long long)gridDim.x * rows) {
-      const float zh = (z[p * C + c] - m) * r;
-      float gv = g[p * g_cs + g_co + c];
-      if (relu_pre && !(zh * ga + be > 0.f)) gv = 0.f;
-      s1 += gv;
-      s2 += gv * zh;
+    const int c = cg * 4;
+    const float4 m = *reinterpret_cast<const float4*>(mean + c), r = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    const float mm[4] = {m.x, m.y, m.z, m.w}, rr[4] = {r.x, r.y, r.z, r.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w},
+                bb[4] = {be.x, be.y, be.z, be.w};
+    auto one = [&](const float4& zv, const float4& gv4) __attribute__((always_inline)) {
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+      float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float zh = (zz[j] - mm[j]) * rr[j];
+        if (relu_pre && !(zh * gg[j] + bb[j] > 0.f)) gv[j] = 0.f;
+        s1[j] += gv[j];
+        s2[j] += gv[j] * zh;
+      }
+    };
+    const long long stride = (long long)gridDim.x * rows;
+    long long p = (long long)blockIdx.x * rows + row;
+    for (; p + stride < npix; p += 2 * stride) {
+      const float4 z0 = *reinterpret_cast<const float4*>(z + p * C + c);
+      const float4 g0 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
+      const float4 z1 = *reinterpret_cast<const float4*>(z + (p + stride) * C + c);
+      const float4 g1 = *reinterpret_cast<const float4*>(g + (p + stride) * g_cs + g_co + c);
+      one(z0, g0);
+      one(z1, g1);
+    }
+    for (; p < npix; p += stride)
+      one(*reinterpret_cast<const float4*>(z + p * C + c), *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < c4n) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double d1 = 0, d2 = 0;
+      for (int r = 0; r < rows; ++r) { d1 += (double)red[0][r * c4n + threadIdx.x][j]; d2 += (double)red[1][r * c4n + threadIdx.x][j]; }
+      // this block's row of the partials buffer (no atomics: see bn_stats_kernel); bn_bwd_finish_kernel adds the rows up
+      partials[(size_t)blockIdx.x * 2 * C + threadIdx.x * 4 + j] = d1;
+      partials[(size_t)blockIdx.x * 2 * C + C + threadIdx.x * 4 + j] = d2;
     }
   }
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
+}
+// sums[c] = sum of the partial rows (dbeta | dgamma), also written out as the parameter gradients; block = 64 channels x 4 row groups
+__global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const double* __restrict__ partials, int nrows, int C,
+                                                            double* __restrict__ sums, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  __shared__ double red[2][16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s1 = 0, s2 = 0;
+  if (c < C)
+#pragma unroll 8
+    for (int r = rg; r < nrows; r += 16) {
+      s1 += partials[(size_t)r * 2 * C + c];
+      s2 += partials[(size_t)r * 2 * C + C + c];
+    }
+  red[0][rg][cl] = s1;
+  red[1][rg][cl] = s2;
   __syncthreads();
-  if (row == 0) {
-    double d1 = 0, d2 = 0;
-    for (int r = 0; r < rows; ++r) { d1 += (double)red[0][r * lanes_c + c]; d2 += (double)red[1][r * lanes_c + c]; }
-    atomicAdd(&sums[c], d1);
-    atomicAdd(&sums[C + c], d2);
-  }
+  if (rg != 0 || c >= C) return;
+  s1 = sum16(red[0], cl);
+  s2 = sum16(red[1], cl);
+  sums[c] = s1;
+  sums[C + c] = s2;
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, int g_cs, int g_co,
                                                            float* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int relu_pre, int C,
-                                                           long long npix, const double* __restrict__ sums,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const long long total = npix * C;
+                                                           long long npix, const double* __restrict__ sums) {
+  const int c4n = C >> 2;
+  const long long total = npix * c4n;
   const double inv = 1.0 / (double)npix;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const long long p = i / C;
-    const float m = mean[c], r = rstd[c], ga = gamma[c];
-    const float zh = (z[i] - m) * r;
-    float gv = g[p * g_cs + g_co + c];
-    if (relu_pre && !(zh * ga + beta[c] > 0.f)) gv = 0.f;
-    z[i] = ga * r * (gv - (float)(sums[c] * inv) - zh * (float)(sums[C + c] * inv));
-  }
-  if (blockIdx.x == 0)
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      dbeta[c] = (float)sums[c];
-      dgamma[c] = (float)sums[C + c];
+    const int c = (int)(i % c4n) * 4;
+    const long long p = i / c4n;
+    const float4 m = *reinterpret_cast<const float4*>(mean + c), r = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    const float4 zv = *reinterpret_cast<const float4*>(z + p * C + c);
+    const float4 gv4 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
+    const float mm[4] = {m.x, m.y, m.z, m.w}, rr[4] = {r.x, r.y, r.z, r.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w},
+                bb[4] = {be.x, be.y, be.z, be.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
+    float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float zh = (zz[j] - mm[j]) * rr[j];
+      if (relu_pre && !(zh * gg[j] + bb[j] > 0.f)) gv[j] = 0.f;
+      o[j] = gg[j] * rr[j] * (gv[j] - (float)(sums[c + j] * inv) - zh * (float)(sums[C + c + j] * inv));
     }
+    *reinterpret_cast<float4*>(z + p * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
 }
 int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float* mean, const float* rstd,
-                      const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* sums_scratch,
-                      float* dgamma, float* dbeta, hipStream_t s) {
-  DRS_REQUIRE(C <= 1024 && (C >= 256 ? C % 256 == 0 : 256 % C == 0), DRS_ERR_SHAPE, "bn_bwd: C=%d", C);
-  DRS_CHECK_HIP(hipMemsetAsync(sums_scratch, 0, 2 * (size_t)C * sizeof(double), s));
-  if (C <= 256) {
-    const int rows = 256 / C;
-    DRS_LAUNCH(bn_bwd_reduce_kernel, dim3(grid1d(npix, rows, 512)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
-                       gamma, beta, relu_pre, C, npix, sums_scratch);
-  } else {
-    DrsErr::set("bn_bwd: C > 256 not needed by this network");
-    return DRS_ERR_SHAPE;
-  }
-  DRS_LAUNCH(bn_bwd_apply_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
-                     gamma, beta, relu_pre, C, npix, sums_scratch, dgamma, dbeta);
+                      const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* partials,
+                      double* sums, float* dgamma, float* dbeta, hipStream_t s) {
+  // partials: DRS_RED_BLOCKS rows of 2 x C doubles (rewritten by every call: calls must be stream-ordered); sums: this layer's 2 x C totals
+  DRS_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C >> 2) == 0 && (g_cs & 3) == 0 && (g_co & 3) == 0, DRS_ERR_SHAPE,
+              "bn_bwd: C=%d g_cs=%d g_co=%d", C, g_cs, g_co);
+  const int rows = 256 / (C >> 2);
+  const unsigned blocks = grid1d(npix, rows, DRS_RED_BLOCKS);
+  DRS_LAUNCH(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd, gamma, beta, relu_pre, C, npix,
+             partials);
+  DRS_LAUNCH(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, (int)blocks, C, sums, dgamma, dbeta);
+  DRS_LAUNCH(bn_bwd_apply_kernel, dim3(grid1d(npix * (C >> 2), 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
+                     gamma, beta, relu_pre, C, npix, sums);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -347,45 +469,73 @@ int drs_launch_gate_bwd(const float* x, const float* E, const float* psi, float*
 // psi conv backward (1x1 conv to one channel, reference :78,:104):  psi_pre = sum_c wpsi[c] P[p][c] + b.
 //   dP[p][c] = wpsi[c] * dpsi_pre[p] * (P[p][c] > 0)   (P is a ReLU output: its mask is applied here)
 //   dw[c] += sum_p P[p][c] * dpsi_pre[p],  db += sum_p dpsi_pre[p]
+// thread = (pixel row in block, group of 4 channels); the block's sums go to ITS row of `partials` ([C] dw | db), the finish
+// kernel adds the rows into dw / db (no atomics onto C + 1 shared addresses: see bn_stats_kernel)
 __global__ __launch_bounds__(256) void psi_bwd_kernel(const float* __restrict__ Pm, const float* __restrict__ wpsi,
                                                       const float* __restrict__ dpsi_pre, float* __restrict__ dP,
-                                                      float* __restrict__ dw, float* __restrict__ db, int C,
-                                                      long long npix, int rows_per_block) {
-  __shared__ float red[256];
-  const int lanes_c = C < 256 ? C : 256, rows = 256 / lanes_c;
-  const int c = threadIdx.x % lanes_c, row = threadIdx.x / lanes_c;
+                                                      float* __restrict__ partials, int C, long long npix, int rows_per_block) {
+  __shared__ float red[256][5];
+  const int c4n = C >> 2, rows = 256 / c4n;
+  const int q = threadIdx.x % c4n, row = threadIdx.x / c4n;
   const long long p_begin = (long long)blockIdx.x * rows_per_block, p_end = min(npix, p_begin + rows_per_block);
-  float sw = 0.f, sb = 0.f;
+  float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
   if (row < rows) {
-    const float w = wpsi[c];
+    const float4 w = *reinterpret_cast<const float4*>(wpsi + q * 4);
     for (long long p = p_begin + row; p < p_end; p += rows) {
-      const float dp = dpsi_pre[p], pv = Pm[p * C + c];
-      dP[p * C + c] = pv > 0.f ? w * dp : 0.f;
-      sw += pv * dp;
-      if (c == 0) sb += dp;
+      const float dp = dpsi_pre[p];
+      const float4 pv = *reinterpret_cast<const float4*>(Pm + p * C + q * 4);
+      *reinterpret_cast<float4*>(dP + p * C + q * 4) =
+          make_float4(pv.x > 0.f ? w.x * dp : 0.f, pv.y > 0.f ? w.y * dp : 0.f, pv.z > 0.f ? w.z * dp : 0.f, pv.w > 0.f ? w.w * dp : 0.f);
+      sw[0] += pv.x * dp; sw[1] += pv.y * dp; sw[2] += pv.z * dp; sw[3] += pv.w * dp;
+      if (q == 0) sb += dp;
     }
   }
-  red[threadIdx.x] = sw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = sw[j];
+  red[threadIdx.x][4] = sb;
   __syncthreads();
-  if (row == 0) {
-    for (int r = 1; r < rows; ++r) sw += red[r * lanes_c + c];
-    atomicAdd(&dw[c], sw);
+  if (threadIdx.x < c4n) {
+    float* prow = partials + (size_t)blockIdx.x * (C + 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = 0.f;
+      for (int r = 0; r < rows; ++r) v += red[r * c4n + threadIdx.x][j];
+      prow[threadIdx.x * 4 + j] = v;
+    }
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += red[r * c4n][4];
+      prow[C] = t;
+    }
   }
+}
+__global__ __launch_bounds__(1024) void psi_bwd_finish_kernel(const float* __restrict__ partials, int nrows, int C,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;  // column C = the bias gradient
+  float v = 0.f;
+  if (c <= C)
+#pragma unroll 8
+    for (int r = rg; r < nrows; r += 16) v += partials[(size_t)r * (C + 1) + c];
+  red[rg][cl] = v;
   __syncthreads();
-  red[threadIdx.x] = (c == 0) ? sb : 0.f;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int r = 0; r < rows; ++r) t += red[r * lanes_c];
-    atomicAdd(db, t);
+  if (rg == 0 && c <= C) {
+    const float t = sum16(red, cl);
+    if (c < C) dw[c] += t;
+    else *db += t;
   }
 }
 int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre, float* dP, float* dw, float* db, int C,
-                       long long npix, hipStream_t s) {
-  DRS_REQUIRE(C <= 256 && 256 % C == 0, DRS_ERR_SHAPE, "psi_bwd: C=%d", C);
-  const int rpb = 1024;
-  DRS_LAUNCH(psi_bwd_kernel, dim3((unsigned)((npix + rpb - 1) / rpb)), dim3(256), 0, s, Pm, wpsi, dpsi_pre, dP, dw,
-                     db, C, npix, rpb);
+                       long long npix, float* partials, hipStream_t s) {
+  // partials: at most 2048 rows of C + 1 floats of scratch (stream-ordered use)
+  DRS_REQUIRE(C % 4 == 0 && C <= 256 && 256 % (C >> 2) == 0, DRS_ERR_SHAPE, "psi_bwd: C=%d", C);
+  if (npix == 0) return DRS_OK;
+  long long rpb = 256;
+  while ((npix + rpb - 1) / rpb > 2048) rpb *= 2;
+  const unsigned blocks = (unsigned)((npix + rpb - 1) / rpb);
+  DRS_LAUNCH(psi_bwd_kernel, dim3(blocks), dim3(256), 0, s, Pm, wpsi, dpsi_pre, dP, partials, C, npix, (int)rpb);
+  DRS_LAUNCH(psi_bwd_finish_kernel, dim3((C + 1 + 63) / 64), dim3(1024), 0, s, partials, (int)blocks, C, dw, db);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
@@ -396,15 +546,24 @@ int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre
 // (already summed over pixels by the caller).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __restrict__ t,
-                                                           const float* __restrict__ inv_freq,
-                                                           const float* __restrict__ W1, const float* __restrict__ b1,
-                                                           const float* __restrict__ W2, const float* __restrict__ temb,
-                                                           const float* __restrict__ dtemb, int stride, int B, int dim,
-                                                           float* __restrict__ dW1, float* __restrict__ db1,
-                                                           float* __restrict__ dW2, float* __restrict__ db2,
-                                                           const float* __restrict__ label_emb,
+                                                           const float* __restrict__ inv_freq, DrsMlpBwdTable tab,
+                                                           int stride, int B, const float* __restrict__ label_emb,
                                                            const long long* __restrict__ labels, int label_batch,
                                                            int num_classes, float* __restrict__ dlabel) {
+  // blockIdx.y = which of the network's time MLPs (all of them in ONE launch: they were seven 73 us launches, each a
+  // handful of latency-bound blocks, at the end of the backward's main stream)
+  const DrsMlpBwd& e_ = tab.m[blockIdx.y];
+  const int dim = e_.dim;
+  if ((int)blockIdx.x * 8 >= dim) return;
+  const float* __restrict__ W1 = e_.W1;
+  const float* __restrict__ b1 = e_.b1;
+  const float* __restrict__ W2 = e_.W2;
+  const float* __restrict__ temb = e_.temb;
+  const float* __restrict__ dtemb = e_.dtemb;
+  float* __restrict__ dW1 = e_.dW1;
+  float* __restrict__ db1 = e_.db1;
+  float* __restrict__ dW2 = e_.dW2;
+  float* __restrict__ db2 = e_.db2;
   // Block `blockIdx.x` owns rows [r0, r0 + RB) of dW2 / db2 (index c) and of dW1 / db1 (index k): it re-derives the
   // cheap per-sample vectors (e, pre1, h1, d2: dim x 100 MACs) and keeps its rows' sums over the batch in registers.
   constexpr int RB = 8;
@@ -485,20 +644,28 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const long long* __re
     db1[r0 + tid - 128] += accb1;
   }
 }
-int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
-                            const float* temb, const float* dtemb, int stride, int B, int dim, float* dW1, float* db1,
-                            float* dW2, float* db2, const float* label_emb, const long long* labels, int label_batch,
-                            int num_classes, float* dlabel, hipStream_t s) {
-  DRS_REQUIRE(dim <= 256, DRS_ERR_SHAPE, "time_mlp_bwd: dim=%d", dim);
-  DRS_LAUNCH(time_mlp_bwd_kernel, dim3((dim + 7) / 8), dim3(256), 0, s, t, inv_freq, W1, b1, W2, temb, dtemb, stride, B, dim, dW1,
-                     db1, dW2, db2, label_emb, labels, label_batch, num_classes, dlabel);
+int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const DrsMlpBwdTable& tab, int stride, int B,
+                            const float* label_emb, const long long* labels, int label_batch, int num_classes, float* dlabel,
+                            hipStream_t s) {
+  if (tab.n == 0) return DRS_OK;
+  int max_dim = 0;
+  for (int i = 0; i < tab.n; ++i) {
+    DRS_REQUIRE(tab.m[i].dim <= 256, DRS_ERR_SHAPE, "time_mlp_bwd: dim=%d", tab.m[i].dim);
+    max_dim = tab.m[i].dim > max_dim ? tab.m[i].dim : max_dim;
+  }
+  // (the label-embedding gradient is accumulated with atomics by every MLP's blocks, as before)
+  DRS_LAUNCH(time_mlp_bwd_kernel, dim3((max_dim + 7) / 8, tab.n), dim3(256), 0, s, t, inv_freq, tab, stride, B, label_emb, labels,
+             label_batch, num_classes, dlabel);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Adjoint of the bicubic up-sampling (channels-last, C channels): every output-gradient pixel scatters into its 16
-// source pixels with the same clamped indices / weights as the forward (small tensors: float atomics).
+// Adjoint of the bicubic up-sampling (channels-last, C channels; forward: F.interpolate(mode='bicubic'), A = -0.75,
+// align_corners=False, source indices clamped at the borders, reference UNet_model_superres.py:349).  GATHER form: one
+// thread per element of dx collects the output-gradient pixels whose (clamped) taps land on it - at most 5*scale per
+// axis - with the forward's own weights.  No atomics, no zero-fill, deterministic; the scatter form this replaces issued
+// 16 float atomics per output element onto 3-channel rows (611 us per configs[2] step).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void cubic_w(float t, float c[4]) {
   const float A = -0.75f;
@@ -508,33 +675,99 @@ __device__ __forceinline__ void cubic_w(float t, float c[4]) {
   c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
   c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
 }
-__global__ void bicubic_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int C, int H, int W,
-                                   int scale) {
+// weight with which output position o (of a size * scale axis) reads source index j (clamped taps summed)
+__device__ __forceinline__ float bicubic_adjoint_w(int o, int j, int size, float rs) {
+  const float sv = rs * ((float)o + 0.5f) - 0.5f;
+  const float fv = floorf(sv);
+  float cw[4];
+  cubic_w(sv - fv, cw);
+  float w = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) w += (min(max((int)fv - 1 + a, 0), size - 1) == j) ? cw[a] : 0.f;
+  return w;
+}
+__global__ __launch_bounds__(256) void bicubic_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int C,
+                                                          int H, int W, int scale) {
   const int OH = H * scale, OW = W * scale;
-  const long long total = (long long)N * OH * OW * C;
+  const long long total = (long long)N * H * W * C;
   const float rs = 1.f / (float)scale;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
-    const int ox = (int)((i / C) % OW), oy = (int)((i / ((long long)C * OW)) % OH);
-    const int n = (int)(i / ((long long)C * OW * OH));
-    const float sy = rs * ((float)oy + 0.5f) - 0.5f, sx = rs * ((float)ox + 0.5f) - 0.5f;
-    const float fy = floorf(sy), fx = floorf(sx);
-    float cy[4], cx[4];
-    cubic_w(sy - fy, cy);
-    cubic_w(sx - fx, cx);
-    const float g = dy[i];
-    for (int a = 0; a < 4; ++a) {
-      const int yy = min(max((int)fy - 1 + a, 0), H - 1);
-      for (int b = 0; b < 4; ++b) {
-        const int xx = min(max((int)fx - 1 + b, 0), W - 1);
-        atomicAdd(&dx[(((long long)n * H + yy) * W + xx) * C + c], g * cy[a] * cx[b]);
-      }
+    const int xx = (int)((i / C) % W), yy = (int)((i / ((long long)C * W)) % H);
+    const int n = (int)(i / ((long long)C * W * H));
+    // an output row oy reads source rows floor(sy) - 1 .. floor(sy) + 2 (then clamped): row yy is reached from
+    // oy in [(yy - 2) * scale, (yy + 3) * scale); the exact weight (zero for most of that range's ends) decides
+    const int oy0 = max((yy - 2) * scale, 0), oy1 = min((yy + 3) * scale, OH);
+    const int ox0 = max((xx - 2) * scale, 0), ox1 = min((xx + 3) * scale, OW);
+    float acc = 0.f;
+    for (int oy = oy0; oy < oy1; ++oy) {
+      const float wy = bicubic_adjoint_w(oy, yy, H, rs);
+      if (wy == 0.f) continue;
+      const float* row = dy + (((long long)n * OH + oy) * OW) * C + c;
+      float racc = 0.f;
+      for (int ox = ox0; ox < ox1; ++ox) racc = fmaf(bicubic_adjoint_w(ox, xx, W, rs), row[(long long)ox * C], racc);
+      acc = fmaf(wy, racc, acc);
     }
+    dx[i] = acc;
   }
 }
 int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, hipStream_t s) {
-  const long long total = (long long)N * H * W * scale * scale * C;
-  DRS_LAUNCH(bicubic_bwd_kernel, dim3(grid1d(total, 256, 8192)), dim3(256), 0, s, dy, dx, N, C, H, W, scale);
+  const long long total = (long long)N * H * W * C;
+  if (total == 0) return DRS_OK;
+  DRS_LAUNCH(bicubic_bwd_kernel, dim3(grid1d(total, 256, 16384)), dim3(256), 0, s, dy, dx, N, C, H, W, scale);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Data gradient of a stem convolution (3x3, pad 1, C <= 4 image-like channels -> 16; reference conv_upsampled_lr_img /
+// conv0, UNet_model_superres.py:281,287):  dx[n][y][x][c] = sum_{ky,kx,o} g[n][y+1-ky][x+1-kx][o] * w[o][c][ky][kx], zero
+// outside the image.  Block = 16 x 16 pixels; the 18 x 18 x 16 tile of g goes through LDS once (the direct tap kernel this
+// replaces re-read every pixel's 16 channels for each of the 9 taps from L1 / L2: 610 us per configs[2] step for a
+// 3-channel result).  g: channels-last with pixel stride g_cs (16 used); w: the layer's own (16, C, 3, 3) parameter.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_dgrad_kernel(const float* __restrict__ g, int g_cs, const float* __restrict__ w,
+                                                         float* __restrict__ dx, int H, int W, int C) {
+  __shared__ float sg[18 * 18][17];  // (+1: a lane's 16-float rows start in different banks)
+  __shared__ float sw[16 * 4 * 9];   // [o][c (padded to 4)][tap]
+  const int n = blockIdx.z, y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
+  for (int i = threadIdx.x; i < 16 * 4 * 9; i += 256) {
+    const int tap = i % 9, c = (i / 9) & 3, o = i / 36;
+    sw[i] = c < C ? w[(o * C + c) * 9 + tap] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 18 * 18 * 4; i += 256) {  // one float4 (4 of the 16 channels) per step
+    const int q = i & 3, pix = i >> 2;
+    const int py = pix / 18, px = pix - py * 18;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y >= 0 && y < H && x >= 0 && x < W)
+      v = *reinterpret_cast<const float4*>(g + (((long long)n * H + y) * W + x) * g_cs + q * 4);
+    sg[pix][q * 4] = v.x; sg[pix][q * 4 + 1] = v.y; sg[pix][q * 4 + 2] = v.z; sg[pix][q * 4 + 3] = v.w;
+  }
+  __syncthreads();
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int y = y0 + ty, x = x0 + tx;
+  if (y >= H || x >= W) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float* gp = sg[(ty + 2 - ky) * 18 + (tx + 2 - kx)];  // g at (y + 1 - ky, x + 1 - kx)
+#pragma unroll
+      for (int o = 0; o < 16; ++o) {
+        const float gv = gp[o];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(gv, sw[(o * 4 + c) * 9 + ky * 3 + kx], acc[c]);
+      }
+    }
+  float* out = dx + (((long long)n * H + y) * W + x) * C;
+  for (int c = 0; c < C; ++c) out[c] = acc[c];
+}
+int drs_launch_stem_dgrad(const float* g, int g_cs, const float* w, float* dx, int N, int H, int W, int C, hipStream_t s) {
+  DRS_REQUIRE(C >= 1 && C <= 4 && (g_cs & 3) == 0 && g_cs >= 16, DRS_ERR_SHAPE, "stem_dgrad: C=%d g_cs=%d", C, g_cs);
+  if ((long long)N * H * W == 0) return DRS_OK;
+  DRS_LAUNCH(stem_dgrad_kernel, dim3((W + 15) / 16, (H + 15) / 16, N), dim3(256), 0, s, g, g_cs, w, dx, H, W, C);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

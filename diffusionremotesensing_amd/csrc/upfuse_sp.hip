@@ -168,17 +168,22 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         for (int i = 0; i < NPW - 1; ++i) ww[i] = *reinterpret_cast<const u32x4*>(base + (unsigned)off1[i]);
         if (pw == 0) ww[NPW - 1] = *reinterpret_cast<const u32x4*>(tail_ok ? base + (unsigned)off1[NPW - 1] : zero);
       } else {
-        // border tiles: per-lane validity; anything outside the image reads the zero line
+        // border tiles: the window offsets of the fast path hold for every pixel inside the image, the others read the zero
+        // line.  32-bit validity arithmetic per piece on an OPAQUE copy of the lane coordinate (conv_sp_movers.inc, round 4:
+        // the 64-bit per-lane address chain cost ~400 cycles per piece, and everything derived from the lane id is
+        // loop-invariant - hoisted out of the step loop it occupied two dozen registers).
+        const char* base = reinterpret_cast<const char*>(d.in) +
+                           ((((long long)n_ * d.LH + (ty_ - 1)) * d.LW + (tx_ - 1)) * d.in_cs + d.in_co) * 4 + c_ * 128;
+        int lpx = l_px;
+        asm volatile("" : "+v"(lpx));
 #pragma unroll
         for (int i = 0; i < NPW; ++i)
           if (i < nwin) {
-            const int p = (pw + 4 * i) * 8 + l_px;
+            const int p = (pw + 4 * i) * 8 + lpx;
             const int py = (p * 3641) >> 16, px = p - py * IW;
             const int iy = ty_ - 1 + py, ix = tx_ - 1 + px;
-            const bool ok = p < G::NPIX && iy >= 0 && iy < d.LH && ix >= 0 && ix < d.LW;
-            const char* src = reinterpret_cast<const char*>(d.in) +
-                              ((((long long)n_ * d.LH + iy) * d.LW + ix) * d.in_cs + d.in_co) * 4 + c_ * 128 + l_off1;
-            ww[i] = *reinterpret_cast<const u32x4*>(ok ? src : zero);
+            const bool ok = p < G::NPIX && (unsigned)iy < (unsigned)d.LH && (unsigned)ix < (unsigned)d.LW;
+            ww[i] = *reinterpret_cast<const u32x4*>(ok ? base + (unsigned)off1[i] : zero);
           }
       }
     };
