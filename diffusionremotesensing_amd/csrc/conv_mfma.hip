@@ -534,6 +534,7 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_sp_supported(d, impl)) {
     return drs_launch_tapconv_sp(d, g, s);
   }
+  if (mode == MODE_CONV3X3 && drs_tapconv_sp_f32out_supported(d, impl)) return drs_launch_tapconv_sp(d, g, s);
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_ws_supported(d, impl))
     return drs_launch_tapconv_ws(d, g, impl, s);
   DRS_REQUIRE(!d.dual, DRS_ERR_SHAPE, "tapconv_mfma: the fused conv1 + skip op needs the wave-specialised kernel");

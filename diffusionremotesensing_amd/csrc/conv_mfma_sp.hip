@@ -27,7 +27,10 @@
 // Lane addresses come from 2 x 8 per-wave tables (one per residue of the window offset mod 8) plus immediates.
 // Flavours (template arguments): BNB = 64 (2 channel groups x 4 row-waves) / 32 (1 x 8 row-waves); HAS2 = the block's 1x1
 // shortcut input as extra one-tap K-chunks; FUSE = up_convs.2 with the fused `output` projection (fp32 NCHW result);
-// DUAL = conv1 + skip convolution of the first residual block from one 64-channel operand image.
+// DUAL = conv1 + skip convolution of the first residual block from one 64-channel operand image; F32OUT = SP-format input,
+// fp32 channels-last output through the general epilogue (residual accumulate included): the data-gradient convolutions of
+// the training step, whose inputs (dZ of a BatchNorm backward) are written in SP form by bn_bwd_apply_kernel and whose
+// outputs feed fp32 consumers (train_bwd.inc).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -69,7 +72,7 @@ struct SpGeom {
   static constexpr int LDS = 2 * WBUF + 2 * W_IMAGE + 64 + 2 * EPI;
 };
 
-template <bool HAS2, int BNB_, bool FUSE, bool DUAL>
+template <bool HAS2, int BNB_, bool FUSE, bool DUAL, bool F32OUT = false>
 __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
@@ -292,9 +295,9 @@ bool sp_std3x3(const TapConv& d) {
   return true;
 }
 
-template <bool HAS2, int BNB, bool FUSE = false, bool DUAL = false>
+template <bool HAS2, int BNB, bool FUSE = false, bool DUAL = false, bool F32OUT = false>
 int sp_launch(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
-  auto kern = tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL>;
+  auto kern = tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL, F32OUT>;
   constexpr size_t kLds = SpGeom<BNB>::LDS;
   static_assert(kLds <= 160 * 1024, "LDS budget");
   int num_cu = 0;
@@ -361,8 +364,23 @@ bool drs_tapconv_sp_supported(const TapConv& d, int impl) {
   return true;
 }
 
+// SP-format input, fp32 channels-last output (general epilogue: bias, ReLUs, per-image add, fp32 residual): 3x3 stride 1 on
+// 16-row patches, no second input / second output / fused projection.
+bool drs_tapconv_sp_f32out_supported(const TapConv& d, int impl) {
+  if (impl != DRS_IMPL_MFMA_BF16X3) return false;
+  if (!d.in || !d.in_sp || !sp_std3x3(d) || !d.zero_line || d.TH <= 8) return false;
+  if (d.gate || d.in_add || d.sigmoid || d.out_nchw || d.dual || d.in2 || d.fuse_out || d.out2 || d.out_sp || d.res_sp) return false;
+  if ((d.in_co & 31) || (d.in_cs & 31) || d.Cin % 32 != 0 || d.Cout % 32 != 0) return false;
+  if (!d.out || (d.out_cs & 3) || (d.out_co & 3)) return false;
+  if (d.res && ((d.res_cs & 3) || (d.res_co & 3))) return false;
+  if (d.post_add && (d.post_cs & 3)) return false;
+  return true;
+}
+
 int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
   DRS_REQUIRE(g.IH == 18 && g.IW == 18, DRS_ERR_SHAPE, "tapconv_sp: geometry");
+  if (!d.out_sp && !d.fuse_out && !d.dual)
+    return d.Cout % 64 == 0 ? sp_launch<false, 64, false, false, true>(d, g, s) : sp_launch<false, 32, false, false, true>(d, g, s);
   if (d.dual) return sp_launch<false, 64, false, true>(d, g, s);
   if (d.fuse_out) return sp_launch<false, 32, true>(d, g, s);
   if (d.Cout % 64 == 0) return d.in2 ? sp_launch<true, 64>(d, g, s) : sp_launch<false, 64>(d, g, s);

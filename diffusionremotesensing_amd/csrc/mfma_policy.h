@@ -86,6 +86,7 @@ bool drs_tapconv_ws_supported(const TapConv& d, int impl);
 int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStream_t s);
 // wave-specialised 3x3 kernel over SP-format activations (conv_mfma_sp.hip); eligibility: drs_tapconv_sp_supported (drs_common.h)
 int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s);
+bool drs_tapconv_sp_f32out_supported(const TapConv& d, int impl);  // the same kernel with the fp32 channels-last epilogue
 // 3x3 stride-2 convolution over SP tensors, operands straight from global memory (conv_s2_sp.hip; DRS_S2K=0 disables)
 bool drs_conv_s2_sp_supported(const TapConv& d, int impl);
 int drs_launch_conv_s2_sp(const TapConv& d, hipStream_t s);

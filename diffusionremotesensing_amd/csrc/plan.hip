@@ -335,6 +335,7 @@ struct ConvLayer {
   bool out_sp = false;  // this layer stores its output in SP format: weights packed with the output-channel permutation
   size_t w_off = 0, b_off = 0;
   int t_Z = -1;         // train plans: pre-BatchNorm tensor
+  int t_Zsp = -1;       // train plans, 3x3 stride-1 layers: SP-format copy of dZ for the wave-specialised data-gradient convolution
   size_t stats_off = 0;  // train plans: saved batch mean / rstd (2 x Cout floats) in the workspace
   size_t sums_off = 0;   // train plans: this layer's fp64 reduction slots (2 x Cout) inside the forward / backward sums regions
 };
@@ -736,6 +737,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
       L.stats_off = ws; ws += align_up(2 * (size_t)L.Cout * 4);
       L.sums_off = sums_cur; sums_cur += 2 * (size_t)L.Cout * sizeof(double);
       L.t_Z = p->T(nm + ".pre_bn", ws, B, L.Cout, hh, ww);
+      if (L.taps == 9 && L.Cout % 32 == 0 && hh > 8) L.t_Zsp = p->T(nm + ".dz_sp", ws, B, L.Cout, hh, ww);
     };
     for (int i = 0; i < 4; ++i) {
       const std::string nm = i < 3 ? "conv_blocks." + std::to_string(i) : std::string("bottle_neck");

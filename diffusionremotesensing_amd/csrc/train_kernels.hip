@@ -2,6 +2,7 @@
 // loss.backward() through Residual_Attention_UNet_superres).  First correct versions: fp32, LDS-tiled, float atomics
 // for the cross-block sums.  Data gradients (dgrad) do not live here: they are tap-convolutions with re-packed
 // weights and run on the forward kernels (conv_mfma.hip / conv_direct.hip).
+#include "conv_epilogue.h"  // drs_sp_split4
 #include "drs_common.h"
 
 template <typename T>
@@ -389,7 +390,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int relu_pre, int C,
-                                                           long long npix, const double* __restrict__ sums) {
+                                                           long long npix, const double* __restrict__ sums,
+                                                           char* __restrict__ z_sp) {
+  // z_sp: optional second copy of dz in SP format (split bf16 hi | lo per 32-channel group, drs_common.h): the operand form
+  // of the wave-specialised data-gradient convolution that reads it next (C % 32 == 0)
   const int c4n = C >> 2;
   const long long total = npix * c4n;
   const double inv = 1.0 / (double)npix;
@@ -410,11 +414,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       o[j] = gg[j] * rr[j] * (gv[j] - (float)(sums[c + j] * inv) - zh * (float)(sums[C + c + j] * inv));
     }
     *reinterpret_cast<float4*>(z + p * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (z_sp) {
+      unsigned hi[2], lo[2];
+      drs_sp_split4(o, hi, lo);
+      char* gp = z_sp + ((size_t)p * C + (c & ~31)) * 4 + (c & 31) * 2;  // the group's hi half; the lo half 64 bytes further
+      *reinterpret_cast<uint2*>(gp) = make_uint2(hi[0], hi[1]);
+      *reinterpret_cast<uint2*>(gp + 64) = make_uint2(lo[0], lo[1]);
+    }
   }
 }
 int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* partials,
-                      double* sums, float* dgamma, float* dbeta, hipStream_t s) {
+                      double* sums, float* dgamma, float* dbeta, hipStream_t s, float* z_sp) {
+  DRS_REQUIRE(!z_sp || C % 32 == 0, DRS_ERR_SHAPE, "bn_bwd: an SP copy needs C %% 32 == 0 (C=%d)", C);
   // partials: DRS_RED_BLOCKS rows of 2 x C doubles (rewritten by every call: calls must be stream-ordered); sums: this layer's 2 x C totals
   DRS_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C >> 2) == 0 && (g_cs & 3) == 0 && (g_co & 3) == 0, DRS_ERR_SHAPE,
               "bn_bwd: C=%d g_cs=%d g_co=%d", C, g_cs, g_co);
@@ -424,7 +436,7 @@ int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float*
              partials);
   DRS_LAUNCH(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, (int)blocks, C, sums, dgamma, dbeta);
   DRS_LAUNCH(bn_bwd_apply_kernel, dim3(grid1d(npix * (C >> 2), 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
-                     gamma, beta, relu_pre, C, npix, sums);
+                     gamma, beta, relu_pre, C, npix, sums, reinterpret_cast<char*>(z_sp));
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
