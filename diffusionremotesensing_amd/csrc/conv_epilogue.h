@@ -315,7 +315,8 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
   const bool lo = lr < 8;
   const int pl = lr & 7;
   // (the two optional ReLUs as max(v, bound) with a launch-uniform bound, 0 or -inf: one instruction per value instead of a
-  // max and a select on the flag)
+  // max and a select on the flag.  fmaxf drops a NaN operand, so with the ReLU off a NaN accumulator leaves as -inf rather
+  // than NaN: divergence still shows - the callers' checks are isfinite(), which rejects both)
   const float lo_pre = d.relu_pre ? 0.f : -__builtin_inff(), lo_post = d.relu_post ? 0.f : -__builtin_inff();
   const int tyb = ty0 + wave * RPW;
   const size_t pix0 = ((size_t)n * d.OH + tyb) * d.OW + tx0 + pl;  // (out_scale 1, no phase offset: 3x3 stride 1)

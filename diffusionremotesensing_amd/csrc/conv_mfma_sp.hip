@@ -383,6 +383,9 @@ int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
     return d.Cout % 64 == 0 ? sp_launch<false, 64, false, false, true>(d, g, s) : sp_launch<false, 32, false, false, true>(d, g, s);
   if (d.dual) return sp_launch<false, 64, false, true>(d, g, s);
   if (d.fuse_out) return sp_launch<false, 32, true>(d, g, s);
+  // (32-channel groups on the levels with ONE 64-channel item per CU - twice the items, so that an item's stores could meet
+  //  the next item's first step - measured in round 4: bottleneck conv2 65 -> 85 us, ups.0.conv 54 -> 64 us.  The window is
+  //  then fetched twice per patch and a step has half the MFMAs over the same mover work.)
   if (d.Cout % 64 == 0) return d.in2 ? sp_launch<true, 64>(d, g, s) : sp_launch<false, 64>(d, g, s);
   return d.in2 ? sp_launch<true, 32>(d, g, s) : sp_launch<false, 32>(d, g, s);
 }

@@ -1086,6 +1086,8 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       // producer: the bottleneck's conv2 on the wave-specialised SP kernel (16-row patches), or the composite kernel of stage i - 1
       const bool producer = i == 0 ? (H >> 3) > 8 && (W >> 3) > 8 : plan->dec[i - 1].upfuse;
       xt_only[i] = st.fused_gate && producer;
+      // (stage 0: the bottleneck's conv2 may still decline the second output at its own probe below and clear xt_only[0]; the
+      //  bias table launched here is then one unused 5 us side-stream launch, not an error)
       if (xt_only[i])
         RUN(drs_launch_gate_bias((const float*)(pk + st.gf_w_off), (const float*)(pk + st.gf_b_off), temb + st.mlp.temb_off,
                                  plan->temb_total, (float*)((char*)ws + st.o_gbias), B, kUp[i], kUp[i + 1], st_mlp));

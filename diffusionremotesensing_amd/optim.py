@@ -35,9 +35,14 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        if grad_ready is not None and any(p.grad is None and getattr(p, "_drs_maybe_unused", False)
-                                          for g in self.param_groups for p in g["params"]):
-            grad_ready()  # which gradients exist is only known after the exchange
+        owner = getattr(grad_ready, "__self__", None) if grad_ready is not None else None
+        has_flag_tail = owner is not None and hasattr(owner, "flat") and owner.flat.numel() > getattr(owner, "n_grad", 0)
+        if grad_ready is not None and (has_flag_tail or any(p.grad is None and getattr(p, "_drs_maybe_unused", False)
+                                                            for g in self.param_groups for p in g["params"])):
+            # which gradients exist is only known after the exchange: whenever it carries "used" flags (some parameter may be
+            # unused on some rank) it is waited for BEFORE any table is built - on every rank alike, so no rank can end up
+            # with a gradient that has no row (the condition _late_wait still checks, now unreachable through dist.py)
+            grad_ready()
             grad_ready = None
         for gi, group in enumerate(self.param_groups):
             params = group["params"]
