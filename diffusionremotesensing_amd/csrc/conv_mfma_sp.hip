@@ -116,7 +116,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
   // cost 3 - 3.7 us each for 0.6 us of MFMAs (a mover starts the loads of step k + 1 when it is done with step k, so a short
   // step exposes a memory round trip).  Interleaving them with the 3x3 steps (L S L S ..., round 4) made it worse - conv2 +
   // shortcut of block 1: 74 -> 93 us - because every 3x3 window then lands in the SAME buffer and its 41 KB store can only
-  // start when the previous 3x3 step ends: the double buffering is gone.
+  // start when the previous 3x3 step ends: the double buffering is gone.  The one-tap steps FIRST (their load chains under the
+  // previous item's epilogue): 84 -> 89 us in the build that had the switch - no gain either.
   auto step_kind = [&](int c_, bool& second_, int& cc_) __attribute__((always_inline)) {
     second_ = HAS2 && c_ >= g.nchunks;
     cc_ = second_ ? c_ - g.nchunks : c_;

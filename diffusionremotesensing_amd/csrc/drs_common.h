@@ -297,7 +297,8 @@ int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s
                          int accumulate, hipStream_t s);
 int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* partials,
-                      double* sums, float* dgamma, float* dbeta, hipStream_t s, float* z_sp = nullptr);
+                      double* sums, float* dgamma, float* dbeta, hipStream_t s, float* z_sp = nullptr,
+                      const float* mask_y = nullptr, int my_cs = 0, int my_co = 0);
 int drs_launch_gate_bwd(const float* x, const float* E, const float* psi, float* dx, float* dpsi_pre, int N, int LH,
                         int LW, int C, hipStream_t s);
 int drs_launch_psi_bwd(const float* Pm, const float* wpsi, const float* dpsi_pre, float* dP, float* dw, float* db, int C,

@@ -304,13 +304,19 @@ int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s
 //   dbeta = sum g, dgamma = sum g*zhat, dz = gamma*rstd*(g - dbeta/M - zhat*dgamma/M).
 // Pass 1 reduces (fp64 atomics), pass 2 writes dz IN PLACE over z.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 drs_mask4(const float4& g, const float4& y) {  // g * (y > 0)
+  return make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+}
 // thread = (pixel row in block, group of 4 channels): 16-byte loads, two pixels in flight per thread
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, int g_cs, int g_co,
                                                             const float* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu_pre, int C,
-                                                            long long npix, double* __restrict__ partials) {
+                                                            long long npix, double* __restrict__ partials,
+                                                            const float* __restrict__ mask_y, int my_cs, int my_co) {
+  // mask_y: optional output of a ReLU that sat on top of g's tensor (g is taken as g * (mask_y > 0)): the residual block's
+  // final ReLU, whose masking pass over gR this replaces
   __shared__ float red[2][256][4];
   const int c4n = C >> 2;
   const int rows = 256 / c4n;
@@ -337,14 +343,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     long long p = (long long)blockIdx.x * rows + row;
     for (; p + stride < npix; p += 2 * stride) {
       const float4 z0 = *reinterpret_cast<const float4*>(z + p * C + c);
-      const float4 g0 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
+      float4 g0 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
       const float4 z1 = *reinterpret_cast<const float4*>(z + (p + stride) * C + c);
-      const float4 g1 = *reinterpret_cast<const float4*>(g + (p + stride) * g_cs + g_co + c);
+      float4 g1 = *reinterpret_cast<const float4*>(g + (p + stride) * g_cs + g_co + c);
+      if (mask_y) {
+        const float4 y0 = *reinterpret_cast<const float4*>(mask_y + p * my_cs + my_co + c);
+        const float4 y1 = *reinterpret_cast<const float4*>(mask_y + (p + stride) * my_cs + my_co + c);
+        g0 = drs_mask4(g0, y0);
+        g1 = drs_mask4(g1, y1);
+      }
       one(z0, g0);
       one(z1, g1);
     }
-    for (; p < npix; p += stride)
-      one(*reinterpret_cast<const float4*>(z + p * C + c), *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c));
+    for (; p < npix; p += stride) {
+      float4 g0 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
+      if (mask_y) g0 = drs_mask4(g0, *reinterpret_cast<const float4*>(mask_y + p * my_cs + my_co + c));
+      one(*reinterpret_cast<const float4*>(z + p * C + c), g0);
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
@@ -391,7 +406,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int relu_pre, int C,
                                                            long long npix, const double* __restrict__ sums,
-                                                           char* __restrict__ z_sp) {
+                                                           char* __restrict__ z_sp, const float* __restrict__ mask_y,
+                                                           int my_cs, int my_co) {
   // z_sp: optional second copy of dz in SP format (split bf16 hi | lo per 32-channel group, drs_common.h): the operand form
   // of the wave-specialised data-gradient convolution that reads it next (C % 32 == 0)
   const int c4n = C >> 2;
@@ -403,7 +419,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float4 m = *reinterpret_cast<const float4*>(mean + c), r = *reinterpret_cast<const float4*>(rstd + c);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
     const float4 zv = *reinterpret_cast<const float4*>(z + p * C + c);
-    const float4 gv4 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
+    float4 gv4 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
+    if (mask_y) gv4 = drs_mask4(gv4, *reinterpret_cast<const float4*>(mask_y + p * my_cs + my_co + c));
     const float mm[4] = {m.x, m.y, m.z, m.w}, rr[4] = {r.x, r.y, r.z, r.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w},
                 bb[4] = {be.x, be.y, be.z, be.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
     float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, o[4];
@@ -425,18 +442,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* partials,
-                      double* sums, float* dgamma, float* dbeta, hipStream_t s, float* z_sp) {
+                      double* sums, float* dgamma, float* dbeta, hipStream_t s, float* z_sp, const float* mask_y, int my_cs,
+                      int my_co) {
   DRS_REQUIRE(!z_sp || C % 32 == 0, DRS_ERR_SHAPE, "bn_bwd: an SP copy needs C %% 32 == 0 (C=%d)", C);
+  DRS_REQUIRE(!mask_y || ((my_cs & 3) == 0 && (my_co & 3) == 0), DRS_ERR_SHAPE, "bn_bwd: unaligned mask slice");
   // partials: DRS_RED_BLOCKS rows of 2 x C doubles (rewritten by every call: calls must be stream-ordered); sums: this layer's 2 x C totals
   DRS_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C >> 2) == 0 && (g_cs & 3) == 0 && (g_co & 3) == 0, DRS_ERR_SHAPE,
               "bn_bwd: C=%d g_cs=%d g_co=%d", C, g_cs, g_co);
   const int rows = 256 / (C >> 2);
   const unsigned blocks = grid1d(npix, rows, DRS_RED_BLOCKS);
   DRS_LAUNCH(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd, gamma, beta, relu_pre, C, npix,
-             partials);
+             partials, mask_y, my_cs, my_co);
   DRS_LAUNCH(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, (int)blocks, C, sums, dgamma, dbeta);
   DRS_LAUNCH(bn_bwd_apply_kernel, dim3(grid1d(npix * (C >> 2), 256, 8192)), dim3(256), 0, s, g, g_cs, g_co, z, mean, rstd,
-                     gamma, beta, relu_pre, C, npix, sums, reinterpret_cast<char*>(z_sp));
+                     gamma, beta, relu_pre, C, npix, sums, reinterpret_cast<char*>(z_sp), mask_y, my_cs, my_co);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
