@@ -21,10 +21,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _torchrun(script_args, extra_env=None, timeout=600):
+def _torchrun(script_args, extra_env=None, timeout=600, nproc=1):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     env.update(extra_env or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port())] + script_args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
@@ -51,3 +51,13 @@ def test_bench_py_under_torchrun_initialises_rccl():
     line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"].get("process_group") == "nccl"
+
+
+def test_two_ranks_share_one_gpu_train_step():
+    """World size 2 on device memory: two processes on the one leased GPU (gloo process group: RCCL needs a device per rank),
+    each running the HIP training step on its own shard - the flat in-place gradient exchange, FusedAdam behind it, identical
+    parameters on both ranks afterwards (tests/_gloo2_gpu_child.py).  BASELINE configs[2]'s data-parallel step at reduced size."""
+    out = _torchrun([os.path.join(ROOT, "tests", "_gloo2_gpu_child.py")], nproc=2)
+    line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["ok"] and res["params_identical_across_ranks"] and res["grad_elements"] == 4383058 - 387520  # SURVEY 8(e): all parameters minus the 6 structurally unused tensors

@@ -212,6 +212,23 @@ def test_generation_sample_golden(dev, seeded_sd_gen, vgolden, impl):
         assert e_l2 <= (3e-5 if impl == "mfma_f32" else 5e-4), tag  # ~10x the measured chain error
 
 
+@pytest.mark.parametrize("impl", ["mfma_f32", "mfma_bf16x3"])
+def test_generation_full_length_guided_chain_golden(dev, seeded_sd_gen, vgolden, impl):
+    """G11: BASELINE configs[4]'s sampling schedule end to end (cosine T = 1000, cfg_scale 3: 999 steps of one 2n-row forward +
+    the fused lerp / update kernel) at 32x32, n = 2, against the reference's own chain with its CPU-generator draws replayed
+    (`output` scaled by 1e-2: tools/make_golden_variants.py)."""
+    from conftest import longchain_state_dict
+    from diffusionremotesensing_amd.generate_new_imgs.train_diffusion_generation import Diffusion
+    m = _gen_model(dev, longchain_state_dict(seeded_sd_gen)).eval()
+    m.hip_engine().set_impl(impl)
+    d = Diffusion("cosine", m, "/nonexistent/snapshot.pt", noise_steps=1000, device=dev, image_size=32)
+    x = d.sample(2, m, target_class=torch.tensor([2, 5]), cfg_scale=3, input_channels=3,
+                 noise_source=replay_noise_source(1111)).cpu()
+    e_max, e_l2 = rel_errors(x, torch.from_numpy(vgolden["g11_x"]))
+    print(f"999-step guided chain [{impl}]: max-rel {e_max:.3e} rel-L2 {e_l2:.3e}")
+    assert e_max <= 1e-4 and e_l2 <= 1e-4, (e_max, e_l2)
+
+
 def test_variant_train_loops(dev, seeded_sd_sar, seeded_sd_gen, tmp_path):
     """Diffusion.train of both variants on seeded data: loss decreases, snapshots carry the variant's state_dict."""
     from torch.utils.data import DataLoader

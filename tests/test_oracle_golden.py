@@ -146,6 +146,17 @@ def test_generation_variant(vgolden, seeded_sd_gen):
         assert torch.allclose(xs, ref, rtol=0, atol=1e-5 * ref.abs().max().item()), tag
 
 
+def test_full_length_guided_chain(vgolden, seeded_sd_gen):
+    """G11: the reference's classifier-free-guided `sample` over configs[4]'s full schedule (cosine T = 1000: 999 x (two forwards,
+    torch.lerp, update), train_diffusion_generation.py:229-259) at 32x32, n = 2, damped output projection."""
+    from conftest import longchain_state_dict
+    a, ah, b = D.schedule("cosine", 1000)
+    x = D.sample_generation(U.OracleUNetGeneration(longchain_state_dict(seeded_sd_gen)), 2, torch.tensor([2, 5]), 3, 1000, a, ah, b, 32,
+                            noise_source=replay_noise_source(1111))
+    ref = torch.from_numpy(vgolden["g11_x"])
+    assert torch.allclose(x, ref, rtol=0, atol=1e-6 * ref.abs().max().item())
+
+
 def test_aggregation_sampling(vgolden, seeded_sd):
     """Tile split, Gaussian weights and blend of Aggregation_Sampling.py against what the imported reference class
     produced around the reference Diffusion.sample (G10), noise replayed in the reference's tile-major order."""
