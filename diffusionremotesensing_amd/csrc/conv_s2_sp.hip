@@ -11,6 +11,13 @@
 // (one 32-channel K-chunk of one 16-pixel row segment) are in flight while step s is multiplied (two register sets).
 // Blocks of one XCD (blockIdx % 8) walk a contiguous eighth of the output rows, so the vertical re-use (input row 2y + 1
 // serves output rows y and y + 1) hits that XCD's L2.
+// Round 4 built the alternative the round-3 notes asked for on the 64- / 128-channel levels (window staged in LDS with whole-line
+// loads, a block = 4 x 16 or 8 x 16 output pixels x ALL output channels, the weights streamed through LDS 64 output channels
+// and one K-chunk at a time; parity-green): downs.1 33 -> 31 us, downs.2 38 -> 33 (4-row tiles) / 42 (8-row tiles, 128 blocks).
+// Every tile then pulls the layer's whole weight image from L2 (151 MB per launch), 110 - 146 KB per CU and step for 54 - 108
+// MFMAs per wave: the same bytes per step as the deep 3x3 kernel moves for 432, i.e. L2-bound at ~5 us per step.  With resident
+// weights (this file) the input is re-read per channel group instead; both sit at 115 - 195 MB of L2 -> CU traffic for a 47 MB
+// layer, and 256 independent CUs cannot share a weight stream.  Not kept.
 #include <stdio.h>
 #include <stdlib.h>
 
