@@ -27,6 +27,8 @@
 #include <stdlib.h>
 
 #include "conv_epilogue.h"
+#include <vector>
+
 #include "mfma_policy.h"
 
 enum { MODE_GENERIC = 0, MODE_CONV3X3 = 1, MODE_CONVT = 2, MODE_CONV3X3_FUSE = 3 };
@@ -548,13 +550,34 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
 // ---- weight packing for the MFMA kernels ------------------------------------------------------------------------
 // dst image layout: [chunk][tap][kgroup(4)][Cout][SLOT_CH] elements, ci = chunk*KC + kgroup*SLOT_CH + j, zero-padded
 // beyond Cin; BatchNorm (eval) folded like pack_conv_kernel.
+// One layer's packing job.  The jobs of a whole plan (37 forward images after every optimizer step, as many data-gradient images
+// per backward) are queued on the host and run as a few batched launches: blockIdx.y = job (drs_pack_queue_*, below).
+struct PackJob {
+  const float *w, *b, *gamma, *beta, *rmean, *rvar;
+  char* dst_w;
+  float* dst_b;
+  size_t image_bytes;
+  float eps;
+  int Cout, Cin, taps, transposed, nchunks, cout_src, flip_taps, co_off, partial, perm, cin_total, cin_off;
+};
+constexpr int kPackBatch = 24;  // jobs per launch (the descriptors travel as kernel arguments: 24 x 120 bytes)
+struct PackBatch { PackJob job[kPackBatch]; };
+
 template <class P>
-__global__ void pack_conv_mfma_kernel(const float* __restrict__ w, const float* __restrict__ b,
-                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
-                                      char* __restrict__ dst_w, float* __restrict__ dst_b, int Cout, int Cin, int taps,
-                                      int transposed, int nchunks, size_t image_bytes, int cout_src, int flip_taps, int co_off,
-                                      int partial, int perm, int cin_total, int cin_off) {
+__global__ void pack_conv_mfma_kernel(PackBatch batch) {
+  const PackJob& e = batch.job[blockIdx.y];
+  const float* __restrict__ w = e.w;
+  const float* __restrict__ b = e.b;
+  const float* __restrict__ gamma = e.gamma;
+  const float* __restrict__ beta = e.beta;
+  const float* __restrict__ rmean = e.rmean;
+  const float* __restrict__ rvar = e.rvar;
+  char* __restrict__ dst_w = e.dst_w;
+  float* __restrict__ dst_b = e.dst_b;
+  const float eps = e.eps;
+  const int Cout = e.Cout, Cin = e.Cin, taps = e.taps, transposed = e.transposed, nchunks = e.nchunks, cout_src = e.cout_src,
+            flip_taps = e.flip_taps, co_off = e.co_off, partial = e.partial, perm = e.perm, cin_total = e.cin_total, cin_off = e.cin_off;
+  const size_t image_bytes = e.image_bytes;
   // cin_total > 0: the source has cin_total input channels of which [cin_off, cin_off + Cin) are packed (one half of a
   // convolution over a channel concatenation); not for transposed sources
   // cout_src < Cout: the source has only cout_src output channels; the rest of the image is zero (a 16-channel
@@ -614,6 +637,61 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl) {
   return (size_t)images(impl) * drs_cdiv(Cin, KC) * taps * 4 * Cout * 16;
 }
 
+// ---- packing queue (per host thread) -------------------------------------------------------------------------------
+// Between drs_pack_queue_begin and drs_pack_queue_flush every drs_launch_pack_conv_mfma call only records its job; the
+// flush launches the recorded jobs of each operand policy kPackBatch at a time.  Jobs that write into the same image
+// (`partial`) touch disjoint channels, so their order inside a launch does not matter.
+namespace {
+struct PackQueue {
+  bool open = false;
+  std::vector<PackJob> jobs[3];  // by policy: fp32, fp16, split bf16
+  std::vector<int> blocks[3];
+};
+thread_local PackQueue g_pack_queue;
+
+template <class P>
+int pack_launch(const PackJob* jobs, const int* blocks, int n, hipStream_t s) {
+  for (int i0 = 0; i0 < n; i0 += kPackBatch) {
+    PackBatch batch = {};
+    const int m = n - i0 < kPackBatch ? n - i0 : kPackBatch;
+    int bx = 1;
+    for (int i = 0; i < m; ++i) { batch.job[i] = jobs[i0 + i]; bx = blocks[i0 + i] > bx ? blocks[i0 + i] : bx; }
+    // (every job of the launch gets the largest job's block count: the kernel's slot loop is grid-strided, extra blocks exit)
+    DRS_LAUNCH(pack_conv_mfma_kernel<P>, dim3(bx, m), dim3(256), 0, s, batch);
+  }
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+int pack_dispatch(int pol, const PackJob* jobs, const int* blocks, int n, hipStream_t s) {
+  if (n == 0) return DRS_OK;
+  if (pol == 0) return pack_launch<PolicyF32>(jobs, blocks, n, s);
+  if (pol == 1) return pack_launch<PolicyF16>(jobs, blocks, n, s);
+  return pack_launch<PolicyBF16X3>(jobs, blocks, n, s);
+}
+}  // namespace
+
+void drs_pack_queue_begin() {
+  PackQueue& q = g_pack_queue;
+  q.open = true;
+  for (int p = 0; p < 3; ++p) { q.jobs[p].clear(); q.blocks[p].clear(); }
+}
+void drs_pack_queue_abandon() {
+  PackQueue& q = g_pack_queue;
+  q.open = false;
+  for (int p = 0; p < 3; ++p) { q.jobs[p].clear(); q.blocks[p].clear(); }
+}
+int drs_pack_queue_flush(hipStream_t s) {
+  PackQueue& q = g_pack_queue;
+  q.open = false;
+  for (int p = 0; p < 3; ++p) {
+    const int rc = pack_dispatch(p, q.jobs[p].data(), q.blocks[p].data(), (int)q.jobs[p].size(), s);
+    q.jobs[p].clear();
+    q.blocks[p].clear();
+    if (rc) return rc;
+  }
+  return DRS_OK;
+}
+
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
                               int transposed, int impl, hipStream_t s, int cout_src, int flip_taps, int co_off, int partial,
@@ -626,14 +704,14 @@ int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma
   int blocks = (int)((nslots + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-#define DRS_PACK(P)                                                                                                   \
-  DRS_LAUNCH(pack_conv_mfma_kernel<P>, dim3(blocks), dim3(256), 0, s, w, b, gamma, beta, rmean, rvar, eps,    \
-                     (char*)dst_w, dst_b, Cout, Cin, taps, transposed, nchunks, image, cout_src, flip_taps, co_off, partial, perm, \
-                     cin_total, cin_off)
-  if (impl == DRS_IMPL_MFMA_F32) DRS_PACK(PolicyF32);
-  else if (impl == DRS_IMPL_MFMA_F16) DRS_PACK(PolicyF16);
-  else DRS_PACK(PolicyBF16X3);
-#undef DRS_PACK
-  DRS_CHECK_HIP(hipGetLastError());
-  return DRS_OK;
+  const PackJob job{w, b, gamma, beta, rmean, rvar, (char*)dst_w, dst_b, image, eps, Cout, Cin, taps, transposed, nchunks,
+                    cout_src, flip_taps, co_off, partial, perm, cin_total, cin_off};
+  const int pol = impl == DRS_IMPL_MFMA_F32 ? 0 : (impl == DRS_IMPL_MFMA_F16 ? 1 : 2);
+  PackQueue& q = g_pack_queue;
+  if (q.open) {
+    q.jobs[pol].push_back(job);
+    q.blocks[pol].push_back(blocks);
+    return DRS_OK;
+  }
+  return pack_dispatch(pol, &job, &blocks, 1, s);
 }

@@ -144,6 +144,17 @@ int drs_launch_pack_conv(const float* w, const float* b, const float* gamma, con
 
 // MFMA-family packing: dst image(s) [chunk][tap][kgroup][Cout][slot]; see conv_mfma.hip
 size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl);
+// Packing queue of the calling host thread: between begin and flush, drs_launch_pack_conv_mfma only records its job; the flush
+// runs the recorded jobs as a few batched launches (a plan re-packs ~40 layers after every optimizer step, and as many
+// data-gradient images per backward: one 4 - 8 us launch each before round 4).
+void drs_pack_queue_begin();
+int drs_pack_queue_flush(hipStream_t s);
+void drs_pack_queue_abandon();  // drop whatever is recorded and close the queue (error paths)
+struct DrsPackQueueScope {  // opens the queue; an early return abandons it, the regular path calls flush()
+  DrsPackQueueScope() { drs_pack_queue_begin(); }
+  ~DrsPackQueueScope() { drs_pack_queue_abandon(); }
+  int flush(hipStream_t s) { return drs_pack_queue_flush(s); }
+};
 int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma, const float* beta, const float* rmean,
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
                               int transposed, int impl, hipStream_t s, int cout_src = 0, int flip_taps = 0, int co_off = 0,

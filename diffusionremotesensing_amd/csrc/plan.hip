@@ -831,6 +831,7 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
   int rc;
   DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_inv_freq, inv_freq_host, 50 * 4, hipMemcpyHostToDevice, s));
   const int impl = plan->cfg.impl;
+  DrsPackQueueScope pack_queue;  // the MFMA operand images of all layers: a few batched launches at the end (drs_common.h)
   for (ConvLayer* L : plan->convs) {
     // kernel family per layer: decided on shape alone
     TapConv probe = {};
@@ -853,8 +854,8 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     const ConvLayer& a = rb.conv1;  // channels [0, 32): conv1 with BatchNorm1 folded; [32, 64): the skip convolution
     const ConvLayer& b = rb.skip;
     if ((rc = drs_launch_pack_conv_mfma(F(a.w), F(a.b), F(a.bn), F(a.bn + 1), F(a.bn + 2), F(a.bn + 3), plan->cfg.bn_eps,
-                                        base + rb.dual_w_off, (float*)(base + rb.dual_b_off), 64, a.Cin, 9, 0, impl, s, 32, 0, 0, 0,
-                                        plan->sp ? 1 : 0)))
+                                        base + rb.dual_w_off, (float*)(base + rb.dual_b_off), 64, a.Cin, 9, 0, impl, s, 32, 0, 0, 1,
+                                        plan->sp ? 1 : 0)))  // (partial, like the skip half: the two jobs share a launch and an image)
       return rc;
     if ((rc = drs_launch_pack_conv_mfma(F(b.w), F(b.b), nullptr, nullptr, nullptr, nullptr, 0.f, base + rb.dual_w_off,
                                         (float*)(base + rb.dual_b_off), 64, b.Cin, 9, 0, impl, s, 32, 0, 32, 1,
@@ -918,6 +919,7 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_b, F(plan->output.b), (size_t)plan->cfg.out_dim * 4,
                                  hipMemcpyDeviceToDevice, s));
   }
+  if ((rc = pack_queue.flush(s))) return rc;
   DRS_CHECK_HIP(hipMemsetAsync(base + plan->o_zero, 0, 512, s));  // zero line + fault word
   plan->param_ptrs.assign(params, params + plan->params.size());
   plan->packed_ok = true;
