@@ -147,6 +147,11 @@ size_t drs_pack_conv_mfma_bytes(int Cout, int Cin, int taps, int impl);
 // Packing queue of the calling host thread: between begin and flush, drs_launch_pack_conv_mfma only records its job; the flush
 // runs the recorded jobs as a few batched launches (a plan re-packs ~40 layers after every optimizer step, and as many
 // data-gradient images per backward: one 4 - 8 us launch each before round 4).
+// several small fp32 device-to-device copies in one launch (small_kernels.hip)
+#define DRS_COPY_BATCH 64
+struct DrsCopyJob { const float* src; float* dst; long long words; };
+struct DrsCopyBatch { DrsCopyJob job[DRS_COPY_BATCH]; };
+int drs_launch_gather_copy(const DrsCopyJob* jobs, int n, hipStream_t s);
 void drs_pack_queue_begin();
 int drs_pack_queue_flush(hipStream_t s);
 void drs_pack_queue_abandon();  // drop whatever is recorded and close the queue (error paths)

@@ -891,15 +891,18 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
                                         (float*)(base + d.ah_b_off), Ch, Ch, 9, 0, impl, s, 0, 0, 0, 0, i < 2 ? 1 : 0, Cc + Ch, Cc)))
       return rc;
   }
+  // parameters kept verbatim in the packed image: one gather-copy launch (44 hipMemcpyAsync calls before round 4)
+  std::vector<DrsCopyJob> copies;
+  auto keep = [&](size_t off, int param, long long words) { copies.push_back({F(param), (float*)(base + off), words}); };
   for (PlanarConv* L : plan->planars) {
-    DRS_CHECK_HIP(hipMemcpyAsync(base + L->w_off, F(L->w), (size_t)L->Cout * L->Cin * 9 * 4, hipMemcpyDeviceToDevice, s));
-    DRS_CHECK_HIP(hipMemcpyAsync(base + L->b_off, F(L->b), (size_t)L->Cout * 4, hipMemcpyDeviceToDevice, s));
+    keep(L->w_off, L->w, (long long)L->Cout * L->Cin * 9);
+    keep(L->b_off, L->b, L->Cout);
   }
   for (Mlp* m : plan->mlps) {
-    DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_w1, F(m->w1), (size_t)m->dim * 100 * 4, hipMemcpyDeviceToDevice, s));
-    DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_b1, F(m->b1), (size_t)m->dim * 4, hipMemcpyDeviceToDevice, s));
-    DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_w2, F(m->w2), (size_t)m->dim * m->dim * 4, hipMemcpyDeviceToDevice, s));
-    DRS_CHECK_HIP(hipMemcpyAsync(base + m->o_b2, F(m->b2), (size_t)m->dim * 4, hipMemcpyDeviceToDevice, s));
+    keep(m->o_w1, m->w1, (long long)m->dim * 100);
+    keep(m->o_b1, m->b1, m->dim);
+    keep(m->o_w2, m->w2, (long long)m->dim * m->dim);
+    keep(m->o_b2, m->b2, m->dim);
   }
   {
     std::vector<long long> table;
@@ -911,14 +914,11 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     plan->mlp_table_host = table;  // must outlive the async copy
     DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_mlp_table, plan->mlp_table_host.data(), table.size() * sizeof(long long),
                                  hipMemcpyHostToDevice, s));
-    if (plan->label_emb >= 0)
-      DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_label, F(plan->label_emb), (size_t)plan->cfg.num_classes * 100 * 4,
-                                   hipMemcpyDeviceToDevice, s));
-    DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_w, F(plan->output.w), (size_t)plan->cfg.out_dim * kUp[3] * 4,
-                                 hipMemcpyDeviceToDevice, s));
-    DRS_CHECK_HIP(hipMemcpyAsync(base + plan->o_out_b, F(plan->output.b), (size_t)plan->cfg.out_dim * 4,
-                                 hipMemcpyDeviceToDevice, s));
+    if (plan->label_emb >= 0) keep(plan->o_label, plan->label_emb, (long long)plan->cfg.num_classes * 100);
+    keep(plan->o_out_w, plan->output.w, (long long)plan->cfg.out_dim * kUp[3]);
+    keep(plan->o_out_b, plan->output.b, plan->cfg.out_dim);
   }
+  if ((rc = drs_launch_gather_copy(copies.data(), (int)copies.size(), s))) return rc;
   if ((rc = pack_queue.flush(s))) return rc;
   DRS_CHECK_HIP(hipMemsetAsync(base + plan->o_zero, 0, 512, s));  // zero line + fault word
   plan->param_ptrs.assign(params, params + plan->params.size());

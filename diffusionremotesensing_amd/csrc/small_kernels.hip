@@ -688,3 +688,27 @@ extern "C" int drs_time_mlp(const int64_t* t, const float* inv_freq, const float
   DRS_REQUIRE(t && inv_freq && W1 && b1 && W2 && b2 && out, DRS_ERR_ARG, "time_mlp: null pointer");
   return drs_launch_time_mlp(t, inv_freq, W1, b1, W2, b2, out, dim_out, B, dim_in, dim_out, (hipStream_t)stream);
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gather copy: up to kCopyBatch small device-to-device copies (fp32 words) in ONE launch: the parameters a plan keeps
+// verbatim in its packed image (RRDB / stem weights, the time MLPs, the output projection: 44 hipMemcpyAsync calls per
+// re-pack before round 4, i.e. per training step).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_copy_kernel(DrsCopyBatch b) {
+  const DrsCopyJob e = b.job[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < e.words; i += (long long)gridDim.x * 256) e.dst[i] = e.src[i];
+}
+int drs_launch_gather_copy(const DrsCopyJob* jobs, int n, hipStream_t s) {
+  for (int i0 = 0; i0 < n; i0 += DRS_COPY_BATCH) {
+    DrsCopyBatch b = {};
+    const int m = n - i0 < DRS_COPY_BATCH ? n - i0 : DRS_COPY_BATCH;
+    long long most = 1;
+    for (int i = 0; i < m; ++i) { b.job[i] = jobs[i0 + i]; most = jobs[i0 + i].words > most ? jobs[i0 + i].words : most; }
+    long long bx = (most + 255) / 256;
+    if (bx > 64) bx = 64;
+    DRS_LAUNCH(gather_copy_kernel, dim3((unsigned)bx, m), dim3(256), 0, s, b);
+  }
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
