@@ -309,8 +309,6 @@ int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, lon
                       int out_stride, float* out, hipStream_t s, float* partials = nullptr);
 int drs_launch_relu_mask(float* g, int g_cs, int g_co, const float* y, int y_cs, int y_co, int C, long long npix,
                          hipStream_t s);
-int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s_cs, int s_co, int C, long long npix,
-                         int accumulate, hipStream_t s);
 int drs_launch_bn_bwd(const float* g, int g_cs, int g_co, float* z, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int relu_pre, int C, long long npix, double* partials,
                       double* sums, float* dgamma, float* dbeta, hipStream_t s, float* z_sp = nullptr,

@@ -278,26 +278,6 @@ int drs_launch_relu_mask(float* g, int g_cs, int g_co, const float* y, int y_cs,
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
-// dst[p][c] = (accumulate ? dst : 0) + src[p][c]
-__global__ void add_slice_kernel(float* dst, int d_cs, int d_co, const float* src, int s_cs, int s_co, int C,
-                                 long long npix, int accumulate) {
-  const long long total = npix * C;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const long long p = i / C;
-    const float v = src[p * s_cs + s_co + c];
-    float* q = dst + p * d_cs + d_co + c;
-    *q = accumulate ? *q + v : v;
-  }
-}
-int drs_launch_add_slice(float* dst, int d_cs, int d_co, const float* src, int s_cs, int s_co, int C, long long npix,
-                         int accumulate, hipStream_t s) {
-  DRS_LAUNCH(add_slice_kernel, dim3(grid1d(npix * C, 256, 8192)), dim3(256), 0, s, dst, d_cs, d_co, src, s_cs, s_co,
-                     C, npix, accumulate);
-  DRS_CHECK_HIP(hipGetLastError());
-  return DRS_OK;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm backward (training statistics).  g = gradient w.r.t. the BatchNorm output (after the optional ReLU mask
 // that sat directly on it: relu_pre), zhat = (z - mean) * rstd:
