@@ -526,6 +526,7 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   DRS_REQUIRE(d.in && d.w && (d.out || d.fuse_out || d.out2), DRS_ERR_ARG, "tapconv_mfma: null tensor");
   DRS_REQUIRE(drs_tapconv_mfma_supported(d, impl), DRS_ERR_SHAPE, "tapconv_mfma: unsupported shape");
   if ((size_t)d.N * d.TH * d.TW == 0) return DRS_OK;
+  if (drs_tapconv_sp8_supported(d, impl)) return drs_launch_tapconv_sp8(d, s);
   MfmaGeom g; int bn, rpw, mode; size_t lds;
   geom(d, impl, &g, &bn, &rpw, &mode, &lds);
   if (mode == MODE_GENERIC && drs_down_sp_supported(d, impl)) return drs_launch_down_sp(d, s);

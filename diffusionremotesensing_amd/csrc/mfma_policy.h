@@ -87,6 +87,9 @@ int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStre
 // wave-specialised 3x3 kernel over SP-format activations (conv_mfma_sp.hip); eligibility: drs_tapconv_sp_supported (drs_common.h)
 int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s);
 bool drs_tapconv_sp_f32out_supported(const TapConv& d, int impl);  // the same kernel with the fp32 channels-last epilogue
+// the same structure for 8 x 8 images, four images per item (conv_mfma_sp8.hip): the bottleneck level of 64 x 64 models
+bool drs_tapconv_sp8_supported(const TapConv& d, int impl);
+int drs_launch_tapconv_sp8(const TapConv& d, hipStream_t s);
 // 3x3 stride-2 convolution over SP tensors, operands straight from global memory (conv_s2_sp.hip; DRS_S2K=0 disables)
 bool drs_conv_s2_sp_supported(const TapConv& d, int impl);
 int drs_launch_conv_s2_sp(const TapConv& d, hipStream_t s);
