@@ -387,6 +387,18 @@ int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s) {
   // (32-channel groups on the levels with ONE 64-channel item per CU - twice the items, so that an item's stores could meet
   //  the next item's first step - measured in round 4: bottleneck conv2 65 -> 85 us, ups.0.conv 54 -> 64 us.  The window is
   //  then fetched twice per patch and a step has half the MFMAs over the same mover work.)
-  if (d.Cout % 64 == 0) return d.in2 ? sp_launch<true, 64>(d, g, s) : sp_launch<false, 64>(d, g, s);
+  if (d.Cout % 64 == 0) {
+    // fewer 64-channel items than half the CUs (small batches; the 16 x 16 level of configs[3]: 128 items): 32-channel groups
+    // double the items - every CU then has one, and a step moves 78 KB instead of 113.  (With an item per CU or more the
+    // 64-channel groups win: see the note above.)
+    int num_cu = 0;
+    {
+      const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(tapconv_sp_kernel<false, 64, false, false, false>), 160 * 1024, &num_cu);
+      if (rc) return rc;
+    }
+    const long long items64 = (long long)d.N * g.tiles_x * g.tiles_y * (d.Cout / 64);
+    if (2 * items64 <= num_cu) return d.in2 ? sp_launch<true, 32>(d, g, s) : sp_launch<false, 32>(d, g, s);
+    return d.in2 ? sp_launch<true, 64>(d, g, s) : sp_launch<false, 64>(d, g, s);
+  }
   return d.in2 ? sp_launch<true, 32>(d, g, s) : sp_launch<false, 32>(d, g, s);
 }
