@@ -258,6 +258,14 @@ __global__ __launch_bounds__(256, DRS_STEM_BPC) void stem_kernel(const float* __
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   char* tb = sT[wave];
+  // The per-wave image is touched two ways: per pixel (lane p, 16-byte chunk q of its 64 bytes: a 64-byte lane stride, 4-way
+  // bank conflicts in a plain layout - SQ_LDS_BANK_CONFLICT 0.07 of the kernel's LDS cycles in round 3) and linearly (lane L
+  // takes bytes [16 L, 16 L + 16) of a 1 KB piece).  Chunk q of pixel p therefore sits at position q ^ ((p >> 2) & 3): the 16
+  // lanes of a pass then hit 16 different 16-byte bank groups either way.  The linear side undoes the swizzle in its GLOBAL
+  // address (same 1 KB per instruction, permuted inside each pixel's 64 bytes).
+  const int sw_px = (lane >> 2) & 3;                       // per-pixel access: swizzle of this lane's pixel (p = lane)
+  const int lin_q = (lane & 3) ^ ((lane >> 4) & 3);        // linear access: logical chunk behind physical position lane & 3 of pixel j * 16 + lane / 4
+  const int lin_off = (lane >> 2) * 64 + lin_q * 16;       // ... and its byte offset inside the 1 KB piece of the tensor
   const int64_t hw = (int64_t)H * W;
   const int xbs = (W + 63) / 64, ygs = (H + R - 1) / R;
   const int units = N * ygs * xbs;  // (the launcher checks that this fits 31 bits)
@@ -277,8 +285,8 @@ __global__ __launch_bounds__(256, DRS_STEM_BPC) void stem_kernel(const float* __
       const char* rp = reinterpret_cast<const char*>(res + (res_batch == 1 ? ((int64_t)y * W + x0) : ((int64_t)n * H + y) * W + x0) * COUT);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        rnext[j] = *reinterpret_cast<const u32x4*>((j * 1024 + lane * 16 < npx * 64) ? rp + j * 1024 + lane * 16
-                                                                                      : reinterpret_cast<const char*>(stem_zero_line));
+        rnext[j] = *reinterpret_cast<const u32x4*>((j * 16 + (lane >> 2) < npx) ? rp + j * 1024 + lin_off
+                                                                                 : reinterpret_cast<const char*>(stem_zero_line));
     };
     if (res) load_res(0);
 #pragma unroll 1
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(256, DRS_STEM_BPC) void stem_kernel(const float* __
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 r4 = *reinterpret_cast<const float4*>(tb + lane * 64 + q * 16);
+          const float4 r4 = *reinterpret_cast<const float4*>(tb + lane * 64 + ((q ^ sw_px) << 4));
           acc[o][q * 4] += r4.x; acc[o][q * 4 + 1] += r4.y; acc[o][q * 4 + 2] += r4.z; acc[o][q * 4 + 3] += r4.w;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is rewritten below
@@ -342,20 +350,20 @@ __global__ __launch_bounds__(256, DRS_STEM_BPC) void stem_kernel(const float* __
             h[j] = (__bf16)acc[o][co + j];
             l[j] = (__bf16)(acc[o][co + j] - (float)h[j]);
           }
-          *reinterpret_cast<bf16x8_t*>(tb + lane * 64 + co * 2) = h;
-          *reinterpret_cast<bf16x8_t*>(tb + lane * 64 + COUT * 2 + co * 2) = l;
+          *reinterpret_cast<bf16x8_t*>(tb + lane * 64 + (((co >> 3) ^ sw_px) << 4)) = h;        // chunks 0, 1: hi halves
+          *reinterpret_cast<bf16x8_t*>(tb + lane * 64 + (((2 + (co >> 3)) ^ sw_px) << 4)) = l;  // chunks 2, 3: lo halves
         }
       } else {
 #pragma unroll
         for (int co = 0; co < COUT; co += 4)
-          *reinterpret_cast<float4*>(tb + lane * 64 + co * 4) = make_float4(acc[o][co], acc[o][co + 1], acc[o][co + 2], acc[o][co + 3]);
+          *reinterpret_cast<float4*>(tb + lane * 64 + (((co >> 2) ^ sw_px) << 4)) = make_float4(acc[o][co], acc[o][co + 1], acc[o][co + 2], acc[o][co + 3]);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       char* op = reinterpret_cast<char*>(out + p0 * COUT);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(tb + j * 1024 + lane * 16);
-        if (j * 1024 + lane * 16 < npx * 64) *reinterpret_cast<u32x4*>(op + j * 1024 + lane * 16) = v;
+        if (j * 16 + (lane >> 2) < npx) *reinterpret_cast<u32x4*>(op + j * 1024 + lin_off) = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next row rewrites the image)
     }
