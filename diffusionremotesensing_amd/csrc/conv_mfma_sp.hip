@@ -117,7 +117,10 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp_kernel(TapConv d, MfmaGeom 
   // step exposes a memory round trip).  Interleaving them with the 3x3 steps (L S L S ..., round 4) made it worse - conv2 +
   // shortcut of block 1: 74 -> 93 us - because every 3x3 window then lands in the SAME buffer and its 41 KB store can only
   // start when the previous 3x3 step ends: the double buffering is gone.  The one-tap steps FIRST (their load chains under the
-  // previous item's epilogue): 84 -> 89 us in the build that had the switch - no gain either.
+  // previous item's epilogue): 84 -> 89 us in the build that had the switch - no gain either.  Third attempt: interleaved, with the
+  // one-tap windows in the weight ring's column-1 / -2 slots (free during a one-tap step) so that the 3x3 windows keep
+  // alternating buffers - parity-green, 68 / 64 / 63 -> 79 / 70 / 70 us, and the 64- and 32-channel flavours would then sum their
+  // K-chunks in different orders (batch independence 7e-6 instead of exact).  The appended order stays.
   auto step_kind = [&](int c_, bool& second_, int& cc_) __attribute__((always_inline)) {
     second_ = HAS2 && c_ >= g.nchunks;
     cc_ = second_ ? c_ - g.nchunks : c_;
