@@ -462,7 +462,8 @@ bool drs_tapconv_mfma_supported(const TapConv& d, int impl) {
   // An fp32 OUTPUT from SP inputs (w_g, w_x: their results feed fp32 consumers) is the SP kernel with the fp32 epilogue.
   if (d.out_sp && !d.in_sp) return false;
   if (d.in2 && d.in2_sp != d.in_sp) return false;
-  if ((d.out2 || d.dual) && !drs_tapconv_sp_supported(d, impl) && !(d.dual && drs_tapconv_ws_supported(d, impl)))
+  if ((d.out2 || d.dual) && !drs_tapconv_sp_supported(d, impl) && !(d.dual && drs_tapconv_ws_supported(d, impl)) &&
+      !(d.out2 && !d.dual && drs_tapconv_sp8_supported(d, impl)))
     return false;  // second outputs / fused pairs come from the wave-specialised kernels only (plan.hip has the fallbacks)
   if (d.in_sp && (d.in_add || (d.in_co & 31) || (d.in_cs != 16 && (d.in_cs & 31)))) return false;
   if (d.in2_sp && ((d.in2_co & 31) || (d.in2_cs != 16 && (d.in2_cs & 31)))) return false;

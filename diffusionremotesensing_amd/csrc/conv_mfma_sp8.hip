@@ -261,11 +261,10 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp8_kernel(TapConv d, int nchu
           for (int j = 0; j < 8; ++j) kc.bias[j] += b2[j];
         }
         ld8(d.post_add ? d.post_add + (size_t)nn * d.post_cs + cg + kg * 8 : nullptr, kc.post);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) kc.post2[j] = 0.f;
+        ld8(d.out2 ? d.post2 + (size_t)nn * d.post2_cs + cg + kg * 8 : nullptr, kc.post2);  // second output: value + post2 (x + temb)
         TapConv de = d;
         de.OH = d.N * 4; de.OW = 16; de.TH = d.N * 4; de.TW = 16;
-        tile_epilogue_sp_pre<RPW, false>(de, acc, kc, 0, cg, n * 4 + (rw & 1) * 2, 0, 0, lr, kg);
+        tile_epilogue_sp_pre<RPW, true>(de, acc, kc, 0, cg, n * 4 + (rw & 1) * 2, 0, 0, lr, kg);
       }
     }
   }
@@ -307,7 +306,8 @@ bool drs_tapconv_sp8_supported(const TapConv& d, int impl) {
   if (!env || impl != DRS_IMPL_MFMA_BF16X3) return false;
   if (!d.in || !d.in_sp || !sp8_std3x3(d) || !d.zero_line || !d.out || !d.out_sp) return false;
   if (d.H != 8 || d.W != 8 || d.TH != 8 || d.TW != 8 || d.OH != 8 || d.OW != 8) return false;
-  if (d.gate || d.in_add || d.res || d.sigmoid || d.out_nchw || d.dual || d.fuse_out || d.out2) return false;
+  if (d.gate || d.in_add || d.res || d.sigmoid || d.out_nchw || d.dual || d.fuse_out) return false;
+  if (d.out2 && (!d.post2 || (d.out2_co & 31) || (d.out2_cs & 31) || (d.post2_cs & 3))) return false;
   if (d.Cin % 32 || d.Cout % 32 || (d.in_cs & 31) || (d.in_co & 31) || (d.out_cs & 31) || (d.out_co & 31)) return false;
   if (d.in2 && (!d.in2_sp || !d.w2 || d.Cin2 % 32 || (d.in2_cs & 31) || (d.in2_co & 31) || d.H2 != 8 || d.W2 != 8)) return false;
   if (d.post_add && (d.post_cs & 3)) return false;

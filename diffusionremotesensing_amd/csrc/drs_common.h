@@ -264,6 +264,7 @@ int drs_launch_nchw_to_sp(const float* src, float* dst, int N, int C, int H, int
 
 int drs_launch_sp_add_rowvec(const float* src, float* dst, const float* vec, int vec_stride, int N, long long pix_per_image,
                              int C, hipStream_t s);
+bool drs_tapconv_sp8_supported(const TapConv& d, int impl);  // its 8 x 8-image instance (conv_mfma_sp8.hip)
 bool drs_tapconv_sp_supported(const TapConv& d, int impl);  // wave-specialised SP-format 3x3 kernel (conv_mfma_sp.hip) takes this op
 
 // planar (NCHW) small-channel kernels

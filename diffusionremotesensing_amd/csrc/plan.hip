@@ -965,7 +965,7 @@ static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d_in, hi
   // take get it from a separate pass over the first output
   TapConv d = d_in;
   d.fault = plan->fault_ptr;
-  const bool split_out2 = d.out2 && !drs_tapconv_sp_supported(d, plan->cfg.impl);
+  const bool split_out2 = d.out2 && !drs_tapconv_sp_supported(d, plan->cfg.impl) && !drs_tapconv_sp8_supported(d, plan->cfg.impl);
   if (split_out2) d.out2 = nullptr;
   std::string name = plan->params[L.w].name;
   name = name.substr(0, name.size() - 7);  // strip ".weight"
