@@ -1389,9 +1389,10 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         e.eh = eh; e.ev = ev;
         e.wimg = pk + st.uf_edge_off; e.zero_line = zero_line;
         const double epix = (double)B * 2.0 * (lh + lw);
-        prof_begin(plan, "up_convs." + std::to_string(i) + ".edges", 2.0 * epix * 2.5 * Cc * Ch, 4.0 * epix * (Cc + 4.0 * Ch), s);
-        rc = drs_launch_upfuse_edges(e, edges_aside ? plan->side : s);
-        prof_end(plan, s);
+        hipStream_t se = edges_aside ? plan->side : s;  // (profiled forwards have no side stream: edges_aside is false there)
+        prof_begin(plan, "up_convs." + std::to_string(i) + ".edges", 2.0 * epix * 2.5 * Cc * Ch, 4.0 * epix * (Cc + 4.0 * Ch), se);
+        rc = drs_launch_upfuse_edges(e, se);
+        prof_end(plan, se);
         if (rc) return rc;
         if (edges_aside) DRS_CHECK_HIP(hipEventRecord(plan->ev_edge_out[i], plan->side));
       }

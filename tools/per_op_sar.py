@@ -22,4 +22,3 @@ tot = sum(r[1] for r in rows)
 for name, ms, fl, by in rows:
     print(f"{name:36s} {ms:8.4f} {100*ms/tot:5.1f} {fl/ms/1e9 if ms else 0:8.1f} TF {by/ms/1e6 if ms else 0:8.0f} GB/s")
 print("total", tot)
-print("kernels:", sorted({k.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "") for _, k in eng.last_launch_log}))
