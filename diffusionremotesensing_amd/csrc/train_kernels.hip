@@ -235,15 +235,21 @@ int drs_launch_colsum(const float* t, int cs, int co, int C, long long npix, lon
   if (partials && !per_image && vec4) {
     // whole-tensor sums (bias gradients): every block would end in C float atomics onto the same C addresses - 2048 blocks x
     // ~90 ns per serialised atomic set the launch time (95 - 210 us), not the 134 MB it reads
+    // (1024 blocks: with 512, 8 waves per CU x 4 loads in flight moved 1 TB/s - 154 us for the 268 MB slice of grad.cat2;
+    //  the partials buffer holds DRS_RED_BLOCKS x 2 x 1024 doubles, i.e. 4096 rows of <= 1024 floats)
     const int rows = 256 / (C >> 2);
-    const unsigned blocks = grid1d(npix, rows, DRS_RED_BLOCKS);
+    const unsigned blocks = grid1d(npix, rows, 2 * DRS_RED_BLOCKS);
     DRS_LAUNCH(colsum4_partial_kernel, dim3(blocks), dim3(256), 0, s, t, cs, co, C, npix, partials);
     DRS_LAUNCH(colsum_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, (int)blocks, C, out);
     DRS_CHECK_HIP(hipGetLastError());
     return DRS_OK;
   }
   long long rpb = per_image ? 512 : 2048;  // per-image sums: pix_per_image / rpb atomics per address (128 at 256 x 256)
-  if (per_image) {  // blocks must not straddle images
+  if (per_image) {
+    // at least ~2048 blocks (the 17 - 67 MB tensors of the deep levels ran one block per CU at 1 TB/s), a block's rows a
+    // multiple of 4 loads x the pixel rows it covers per pass; blocks must not straddle images
+    const long long pass = vec4 ? 4LL * (256 / (C >> 2)) : 1;
+    while (rpb > pass && npix / rpb < 2048) rpb >>= 1;
     while (pix_per_image % rpb) rpb >>= 1;
   }
   const long long blocks = (npix + rpb - 1) / rpb;
@@ -321,19 +327,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     };
     const long long stride = (long long)gridDim.x * rows;
     long long p = (long long)blockIdx.x * rows + row;
-    for (; p + stride < npix; p += 2 * stride) {
-      const float4 z0 = *reinterpret_cast<const float4*>(z + p * C + c);
-      float4 g0 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
-      const float4 z1 = *reinterpret_cast<const float4*>(z + (p + stride) * C + c);
-      float4 g1 = *reinterpret_cast<const float4*>(g + (p + stride) * g_cs + g_co + c);
-      if (mask_y) {
-        const float4 y0 = *reinterpret_cast<const float4*>(mask_y + p * my_cs + my_co + c);
-        const float4 y1 = *reinterpret_cast<const float4*>(mask_y + (p + stride) * my_cs + my_co + c);
-        g0 = drs_mask4(g0, y0);
-        g1 = drs_mask4(g1, y1);
+    // four pixels in flight per thread (8 - 12 sixteen-byte loads): with two, the 134 MB layers ran at 2.1 TB/s (150 - 187 us)
+    for (; p + 3 * stride < npix; p += 4 * stride) {
+      float4 zv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        zv[u] = *reinterpret_cast<const float4*>(z + (p + u * stride) * C + c);
+        gv[u] = *reinterpret_cast<const float4*>(g + (p + u * stride) * g_cs + g_co + c);
       }
-      one(z0, g0);
-      one(z1, g1);
+      if (mask_y) {
+        float4 yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yv[u] = *reinterpret_cast<const float4*>(mask_y + (p + u * stride) * my_cs + my_co + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gv[u] = drs_mask4(gv[u], yv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(zv[u], gv[u]);
     }
     for (; p < npix; p += stride) {
       float4 g0 = *reinterpret_cast<const float4*>(g + p * g_cs + g_co + c);
@@ -726,6 +736,134 @@ int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int 
   const long long total = (long long)N * H * W * C;
   if (total == 0) return DRS_OK;
   DRS_LAUNCH(bicubic_bwd_kernel, dim3(grid1d(total, 256, 16384)), dim3(256), 0, s, dy, dx, N, C, H, W, scale);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole backward of ONE few-channel 3x3 layer of the LR / SAR encoder (reference ResidualBlock / RRDB,
+// UNet_model_superres.py:237-260: CC -> CC channels, stride 1, pad 1, CC <= 4; channels-last tensors, pixel stride CC):
+//   dW[co][ci][ky][kx] += sum_p gout[p][co] * in[p + (ky-1, kx-1)][ci]          db[co] += sum_p gout[p][co]
+//   gin[p][ci] (+)= sum_{co,ky,kx} W[co][ci][ky][kx] * gout[p - (ky-1, kx-1)][co], then * (mask_y[p][ci] > 0) if mask_y
+// (zero outside the image).  One thread per pixel, the CC*CC*9 + CC sums in registers -> wave shuffles -> LDS -> this
+// block's row of `partials`; the LAST block to arrive (counter) adds the rows in a fixed order into dW / db and resets
+// the counter.  Replaces, per layer, a weight-gradient launch of the MFMA kernel on the side stream (35 us + a 50 us reduce
+// for 81 sums) that the main stream had to wait for, a weight re-pack, a direct tap convolution and a mask pass: the seven
+// layers were 0.9 ms of a 16.5 ms training step spent almost idle.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CC>
+__global__ __launch_bounds__(256) void small_conv_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                             const float* __restrict__ w, float* __restrict__ gin,
+                                                             int accumulate, const float* __restrict__ mask_y, int N, int H,
+                                                             int W, float* __restrict__ partials,
+                                                             unsigned* __restrict__ counter, float* __restrict__ dW,
+                                                             float* __restrict__ db) {
+  constexpr int NW = CC * CC * 9, NACC = NW + CC;
+  __shared__ float red[4][NACC];
+  __shared__ float fin[256];
+  __shared__ unsigned last_flag;
+  const long long npix = (long long)N * H * W;
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+  float wr[NW];  // launch-uniform: scalar loads
+#pragma unroll
+  for (int i = 0; i < NW; ++i) wr[i] = w[i];
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    float go[3][3][CC], xi[3][3][CC];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const long long q = (p + (long long)(ky - 1) * W + (kx - 1)) * CC;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+          go[ky][kx][c] = ok ? gout[q + c] : 0.f;
+          xi[ky][kx][c] = ok ? in[q + c] : 0.f;
+        }
+      }
+    float o[CC];
+#pragma unroll
+    for (int ci = 0; ci < CC; ++ci) o[ci] = accumulate ? gin[p * CC + ci] : 0.f;
+#pragma unroll
+    for (int co = 0; co < CC; ++co) {
+      acc[NW + co] += go[1][1][co];
+#pragma unroll
+      for (int ci = 0; ci < CC; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int wi = ((co * CC + ci) * 3 + ky) * 3 + kx;
+            acc[wi] += go[1][1][co] * xi[ky][kx][ci];
+            o[ci] += wr[wi] * go[2 - ky][2 - kx][co];
+          }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CC; ++ci) {
+      if (mask_y && !(mask_y[p * CC + ci] > 0.f)) o[ci] = 0.f;
+      gin[p * CC + ci] = o[ci];
+    }
+  }
+  if (!dW && !db) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC)
+    partials[(size_t)blockIdx.x * NACC + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_flag = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last_flag) return;
+  __threadfence();
+  // rows in a fixed order: RG row groups x NACC columns, then the groups
+  constexpr int RG = 256 / NACC;
+  const int col = threadIdx.x % NACC, rg = threadIdx.x / NACC;
+  float s = 0.f;
+  if (rg < RG) {
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    int r = rg, k = 0;
+    for (; r < (int)gridDim.x; r += RG, k = (k + 1) & 3) s4[k] += __hip_atomic_load(&partials[(size_t)r * NACC + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (from L2: other CUs wrote the rows)
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
+  fin[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) v += fin[g * NACC + threadIdx.x];
+    if (threadIdx.x < NW) { if (dW) dW[threadIdx.x] += v; }
+    else if (db) db[threadIdx.x - NW] += v;
+  }
+  if (threadIdx.x == 0) *counter = 0u;
+}
+int drs_launch_small_conv_bwd(const float* in, const float* gout, const float* w, float* gin, int accumulate,
+                              const float* mask_y, int N, int CC, int H, int W, float* partials, unsigned* counter, float* dW,
+                              float* db, hipStream_t s) {
+  DRS_REQUIRE(CC >= 1 && CC <= 4, DRS_ERR_SHAPE, "small_conv_bwd: CC=%d (1..4)", CC);
+  const long long npix = (long long)N * H * W;
+  if (npix == 0) return DRS_OK;
+  const unsigned blocks = grid1d(npix, 256, 256);  // <= 256 partial rows of <= 148 floats
+#define DRS_SCB(K) DRS_LAUNCH(small_conv_bwd_kernel<K>, dim3(blocks), dim3(256), 0, s, in, gout, w, gin, accumulate, mask_y, N, H, \
+                              W, partials, counter, dW, db)
+  switch (CC) {
+    case 1: DRS_SCB(1); break;
+    case 2: DRS_SCB(2); break;
+    case 3: DRS_SCB(3); break;
+    default: DRS_SCB(4); break;
+  }
+#undef DRS_SCB
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
