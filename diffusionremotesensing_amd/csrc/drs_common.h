@@ -324,10 +324,13 @@ struct DrsMlpBwdTable { DrsMlpBwd m[8]; int n; };
 int drs_launch_time_mlp_bwd(const long long* t, const float* inv_freq, const DrsMlpBwdTable& tab, int stride, int B,
                             const float* label_emb, const long long* labels, int label_batch, int num_classes, float* dlabel,
                             hipStream_t s);
+// weight + bias gradient of a 3x3 stem convolution (CI <= 4 -> 16 channels); partials: >= 512 x (144 CI + 16) floats, stream-ordered
+int drs_launch_stem_wgrad(const float* g, int g_cs, const float* x, int N, int CI, int H, int W, float* partials,
+                          size_t partial_bytes, float* dW, float* db, hipStream_t s);
 int drs_launch_stem_dgrad(const float* g, int g_cs, const float* w, float* dx, int N, int H, int W, int C, hipStream_t s);
 int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, hipStream_t s);
 // whole backward of one few-channel 3x3 layer (CC -> CC, CC <= 4): dW / db accumulate, gin (+)= conv^T(gout) [* (mask_y > 0)];
-// partials: >= 256 x (9 CC^2 + CC) floats of stream-ordered scratch; counter: a zeroed word (left zero)
+// partials: >= 1024 x (9 CC^2 + CC) floats of stream-ordered scratch
 int drs_launch_small_conv_bwd(const float* in, const float* gout, const float* w, float* gin, int accumulate,
-                              const float* mask_y, int N, int CC, int H, int W, float* partials, unsigned* counter, float* dW,
-                              float* db, hipStream_t s);
+                              const float* mask_y, int N, int CC, int H, int W, float* partials, float* dW, float* db,
+                              hipStream_t s);

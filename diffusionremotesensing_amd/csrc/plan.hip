@@ -757,7 +757,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
     p->o_red = ws; ws += align_up((size_t)kRedBlocks * 2 * 1024 * sizeof(double));
   }
   if (cfg->flags & DRS_PLAN_TRAIN) {
-    p->o_dtemb = ws; ws += align_up((size_t)B * p->temb_total * 4) + 256;  // (+ a zeroed counter word behind the embedding gradients: cleared by the same memset)
+    p->o_dtemb = ws; ws += align_up((size_t)B * p->temb_total * 4);
     p->o_scratch = ws; ws += align_up(64 * 1024);
     p->o_wgrad = ws; ws += align_up(kWgradPartialBytes);  // partial dW slices of the MFMA weight-gradient kernel
     p->g_out = p->T("grad.out", ws, B, cfg->out_dim, H, W);

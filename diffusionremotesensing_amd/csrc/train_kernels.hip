@@ -746,8 +746,8 @@ int drs_launch_bicubic_bwd(const float* dy, float* dx, int N, int C, int H, int 
 //   dW[co][ci][ky][kx] += sum_p gout[p][co] * in[p + (ky-1, kx-1)][ci]          db[co] += sum_p gout[p][co]
 //   gin[p][ci] (+)= sum_{co,ky,kx} W[co][ci][ky][kx] * gout[p - (ky-1, kx-1)][co], then * (mask_y[p][ci] > 0) if mask_y
 // (zero outside the image).  One thread per pixel, the CC*CC*9 + CC sums in registers -> wave shuffles -> LDS -> this
-// block's row of `partials`; the LAST block to arrive (counter) adds the rows in a fixed order into dW / db and resets
-// the counter.  Replaces, per layer, a weight-gradient launch of the MFMA kernel on the side stream (35 us + a 50 us reduce
+// block's row of `partials`; stem_wgrad_finish_kernel adds the rows in a fixed order into dW / db.  (A first version let the
+// last block to arrive add the rows itself: one block summing 256 rows was a 40 us tail on a 25 us kernel.)  Replaces, per layer, a weight-gradient launch of the MFMA kernel on the side stream (35 us + a 50 us reduce
 // for 81 sums) that the main stream had to wait for, a weight re-pack, a direct tap convolution and a mask pass: the seven
 // layers were 0.9 ms of a 16.5 ms training step spent almost idle.
 // ---------------------------------------------------------------------------------------------------------------
@@ -755,13 +755,10 @@ template <int CC>
 __global__ __launch_bounds__(256) void small_conv_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                              const float* __restrict__ w, float* __restrict__ gin,
                                                              int accumulate, const float* __restrict__ mask_y, int N, int H,
-                                                             int W, float* __restrict__ partials,
-                                                             unsigned* __restrict__ counter, float* __restrict__ dW,
-                                                             float* __restrict__ db) {
+                                                             int W, float* __restrict__ partials, const float* dW,
+                                                             const float* db) {
   constexpr int NW = CC * CC * 9, NACC = NW + CC;
   __shared__ float red[4][NACC];
-  __shared__ float fin[256];
-  __shared__ unsigned last_flag;
   const long long npix = (long long)N * H * W;
   float acc[NACC];
 #pragma unroll
@@ -821,42 +818,18 @@ __global__ __launch_bounds__(256) void small_conv_bwd_kernel(const float* __rest
   if (threadIdx.x < NACC)
     partials[(size_t)blockIdx.x * NACC + threadIdx.x] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last_flag = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!last_flag) return;
-  __threadfence();
-  // rows in a fixed order: RG row groups x NACC columns, then the groups
-  constexpr int RG = 256 / NACC;
-  const int col = threadIdx.x % NACC, rg = threadIdx.x / NACC;
-  float s = 0.f;
-  if (rg < RG) {
-    float s4[4] = {0.f, 0.f, 0.f, 0.f};
-    int r = rg, k = 0;
-    for (; r < (int)gridDim.x; r += RG, k = (k + 1) & 3) s4[k] += __hip_atomic_load(&partials[(size_t)r * NACC + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (from L2: other CUs wrote the rows)
-    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-  }
-  fin[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x < NACC) {
-    float v = 0.f;
-#pragma unroll
-    for (int g = 0; g < RG; ++g) v += fin[g * NACC + threadIdx.x];
-    if (threadIdx.x < NW) { if (dW) dW[threadIdx.x] += v; }
-    else if (db) db[threadIdx.x - NW] += v;
-  }
-  if (threadIdx.x == 0) *counter = 0u;
 }
+__global__ __launch_bounds__(1024) void stem_wgrad_finish_kernel(const float* __restrict__ partials, int nrows, int ncol, int nW,
+                                                                float* __restrict__ dW, float* __restrict__ db);  // (below: adds partial rows into dW | db)
 int drs_launch_small_conv_bwd(const float* in, const float* gout, const float* w, float* gin, int accumulate,
-                              const float* mask_y, int N, int CC, int H, int W, float* partials, unsigned* counter, float* dW,
-                              float* db, hipStream_t s) {
+                              const float* mask_y, int N, int CC, int H, int W, float* partials, float* dW, float* db,
+                              hipStream_t s) {
   DRS_REQUIRE(CC >= 1 && CC <= 4, DRS_ERR_SHAPE, "small_conv_bwd: CC=%d (1..4)", CC);
   const long long npix = (long long)N * H * W;
   if (npix == 0) return DRS_OK;
-  const unsigned blocks = grid1d(npix, 256, 256);  // <= 256 partial rows of <= 148 floats
+  const unsigned blocks = grid1d(npix, 256, 1024);  // <= 1024 partial rows of <= 148 floats
 #define DRS_SCB(K) DRS_LAUNCH(small_conv_bwd_kernel<K>, dim3(blocks), dim3(256), 0, s, in, gout, w, gin, accumulate, mask_y, N, H, \
-                              W, partials, counter, dW, db)
+                              W, partials, dW, db)
   switch (CC) {
     case 1: DRS_SCB(1); break;
     case 2: DRS_SCB(2); break;
@@ -864,6 +837,103 @@ int drs_launch_small_conv_bwd(const float* in, const float* gout, const float* w
     default: DRS_SCB(4); break;
   }
 #undef DRS_SCB
+  if (dW || db) {
+    const int ncol = 9 * CC * CC + CC;
+    DRS_LAUNCH(stem_wgrad_finish_kernel, dim3((ncol + 63) / 64), dim3(1024), 0, s, partials, (int)blocks, ncol, 9 * CC * CC, dW, db);
+  }
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight + bias gradient of a stem convolution (3x3, pad 1, CI <= 4 image-like channels -> 16; reference conv0 /
+// conv_upsampled_lr_img, UNet_model_superres.py:281,287):
+//   dW[co][ci][ky][kx] += sum_p g[p][co] * x[p + (ky-1, kx-1)][ci]      db[co] += sum_p g[p][co]
+// g: channels-last, pixel stride g_cs (16 used); x: channels-last, CI channels.  Wave w of a block owns output channels
+// 4w .. 4w+3 for 64 pixels per pass: 36 CI + 4 sums per lane in registers over the block's pixels, one shuffle reduction at
+// the end, lane 0 writes the wave's columns of the block's partial row (column = flat dW index, then the 16 bias sums);
+// stem_wgrad_finish_kernel adds the rows in a fixed order.  The MFMA weight-gradient kernel spent 230 us + a 35 - 90 us slice
+// reduction per layer on these 432 sums (scalar staging of a 3-channel operand into 16-wide tiles).
+// ---------------------------------------------------------------------------------------------------------------
+template <int CI>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ g, int g_cs, const float* __restrict__ x,
+                                                         int N, int H, int W, float* __restrict__ partials) {
+  constexpr int NW = 4 * CI * 9, NACC = NW + 4, NCOL = 16 * CI * 9 + 16;
+  const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const long long npix = (long long)N * H * W;
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+  for (long long p = (long long)blockIdx.x * 64 + lane; p < npix; p += (long long)gridDim.x * 64) {
+    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    const float4 gv4 = *reinterpret_cast<const float4*>(g + p * g_cs + cg * 4);
+    const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+    float xi[9][CI];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int y2 = yy + ky - 1, x2 = xx + kx - 1;
+        const bool ok = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+        const long long q = (p + (long long)(ky - 1) * W + (kx - 1)) * CI;
+#pragma unroll
+        for (int c = 0; c < CI; ++c) xi[ky * 3 + kx][c] = ok ? x[q + c] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[NW + j] += gv[j];
+#pragma unroll
+      for (int c = 0; c < CI; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[(j * CI + c) * 9 + t] += gv[j] * xi[t][c];
+    }
+  }
+  float* row = partials + (size_t)blockIdx.x * NCOL;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) {
+      if (i < NW) row[cg * NW + i] = v;              // ((4 cg + j) * CI + c) * 9 + t
+      else row[16 * CI * 9 + cg * 4 + (i - NW)] = v;
+    }
+  }
+}
+// dW[c] += sum of the partial rows for c < nW, db[c - nW] += ... for the rest; block = 64 columns x 16 row groups
+__global__ __launch_bounds__(1024) void stem_wgrad_finish_kernel(const float* __restrict__ partials, int nrows, int ncol, int nW,
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float v = 0.f;
+  if (c < ncol)
+#pragma unroll 8
+    for (int r = rg; r < nrows; r += 16) v += partials[(size_t)r * ncol + c];
+  red[rg][cl] = v;
+  __syncthreads();
+  if (rg != 0 || c >= ncol) return;
+  const float s = sum16(red, cl);
+  if (c < nW) { if (dW) dW[c] += s; }
+  else if (db) db[c - nW] += s;
+}
+int drs_launch_stem_wgrad(const float* g, int g_cs, const float* x, int N, int CI, int H, int W, float* partials,
+                          size_t partial_bytes, float* dW, float* db, hipStream_t s) {
+  DRS_REQUIRE(CI >= 1 && CI <= 4 && (g_cs & 3) == 0, DRS_ERR_SHAPE, "stem_wgrad: CI=%d g_cs=%d", CI, g_cs);
+  const long long npix = (long long)N * H * W;
+  if (npix == 0 || (!dW && !db)) return DRS_OK;
+  const int ncol = 16 * CI * 9 + 16;
+  const unsigned blocks = grid1d(npix, 64, 512);
+  DRS_REQUIRE(partial_bytes >= (size_t)blocks * ncol * 4, DRS_ERR_WORKSPACE, "stem_wgrad: partial workspace too small");
+#define DRS_SWG(K) DRS_LAUNCH(stem_wgrad_kernel<K>, dim3(blocks), dim3(256), 0, s, g, g_cs, x, N, H, W, partials)
+  switch (CI) {
+    case 1: DRS_SWG(1); break;
+    case 2: DRS_SWG(2); break;
+    case 3: DRS_SWG(3); break;
+    default: DRS_SWG(4); break;
+  }
+#undef DRS_SWG
+  DRS_LAUNCH(stem_wgrad_finish_kernel, dim3((ncol + 63) / 64), dim3(1024), 0, s, partials, (int)blocks, ncol, 16 * CI * 9, dW, db);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }

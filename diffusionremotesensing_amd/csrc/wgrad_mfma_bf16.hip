@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBf16Args g) {
   // written to LDS after them (registers carry them across; a tile's loads are a memory round trip that nothing else on
   // the CU would cover at 2 blocks per CU).  Layers with an input add / gate or a window beyond the prefetch registers
   // (stride-2 taps) stage in place instead.
-  constexpr int NPF = (RT * CT * QF + 255) / 256, NPV = 7;
+  // (NW == 1, the 32-channel V tile: ten prefetch registers cover the 9 x 33-pixel window of a stride-2 tap set, 2376 pieces)
+  constexpr int NPF = (RT * CT * QF + 255) / 256, NPV = NW == 1 ? 10 : 7;
   const int wtotal = g.WR * g.WC * QV;
   const bool pipe = !g.v_add && !g.v_gate && wtotal <= NPV * 256;
   f32x4 pf[NPF], pv[NPV];
@@ -268,6 +269,10 @@ int launch_cfg(const WgradBf16Args& a0, int target_blocks, size_t partial_bytes,
 template <int NT>
 int launch_nt(const WgradBf16Args& a, size_t partial_bytes, int* nslices, hipStream_t s) {
   const int target = NT == 1 ? 2048 : 1024;
+  // stride-2 tap sets (ConvTranspose / stride-2 convolution: the V window of a 4 x 16 tile is 9 x 33 pixels): a 64-channel V tile
+  // needs 117 KB of LDS - one block per CU, window staged in place with nothing to hide the round trip (255 - 300 us for the
+  // 19 GFLOP of a `transform` layer); a 32-channel V tile runs two blocks per CU with the window prefetched
+  if (a.sv == 2 && a.Cf % 64 == 0 && a.Cv % 32 == 0) return launch_cfg<NT, 2, 1>(a, target, partial_bytes, nslices, s);  // 64 x 32
   if (a.Cf % 64 == 0 && a.Cv % 64 == 0) return launch_cfg<NT, 2, 2>(a, target, partial_bytes, nslices, s);  // 64 x 64
   return launch_cfg<NT, 1, 1>(a, target, partial_bytes, nslices, s);                                        // 32 x 32
 }
@@ -288,8 +293,10 @@ static bool wgrad_bf16_enabled() {
 
 bool drs_wgrad_mfma_bf16_supported(const WgradDesc& d) {
   if (!wgrad_bf16_enabled() || !drs_wgrad_mfma_supported(d)) return false;
-  // 32-channel blocks on both sides, float4-able slices (the few-channel image layers and the 16-channel stem stay on the fp32 form)
-  if (d.Ca % 32 || d.Cb % 32 || (d.a_cs & 3) || (d.a_co & 3) || (d.b_cs & 3) || (d.b_co & 3)) return false;
+  // 32-channel blocks on both sides, float4-able slices (the few-channel image layers have their own kernel: stem_wgrad_kernel)
+  // (a 16-channel side - the first residual block's input - fills half of a 32-channel block with zeros: 57 us instead of the
+  //  fp32 form's 103 + an 89 us reduction of its slices)
+  if ((d.Ca % 32 && d.Ca != 16) || (d.Cb % 32 && d.Cb != 16) || (d.a_cs & 3) || (d.a_co & 3) || (d.b_cs & 3) || (d.b_co & 3)) return false;
   return true;
 }
 
