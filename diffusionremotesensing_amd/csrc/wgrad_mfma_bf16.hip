@@ -55,8 +55,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
   return __builtin_bit_cast(bf16x8, z);
 }
 
-template <int NT, int MW, int NW>  // block = 2 x 2 waves, wave (wm, wn) owns MW x NW blocks of 16 x 16
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBf16Args g) {
+template <int NT, int MW, int NW, int NPV, int MINB, bool VADD = false>  // block = 2 x 2 waves, wave (wm, wn) owns MW x NW blocks of 16 x 16; NPV: window prefetch registers (x 16 bytes); MINB: blocks per CU the register budget is set for
+__global__ __launch_bounds__(256, MINB) void wgrad_bf16_kernel(WgradBf16Args g) {
   using P = PolicyBF16X3;
   constexpr int WM = 2, WN = 2;
   constexpr int CHF = WM * MW * 16, CHV = WN * NW * 16;
@@ -100,11 +100,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBf16Args g) {
   // written to LDS after them (registers carry them across; a tile's loads are a memory round trip that nothing else on
   // the CU would cover at 2 blocks per CU).  Layers with an input add / gate or a window beyond the prefetch registers
   // (stride-2 taps) stage in place instead.
-  // (NW == 1, the 32-channel V tile: ten prefetch registers cover the 9 x 33-pixel window of a stride-2 tap set, 2376 pieces)
-  constexpr int NPF = (RT * CT * QF + 255) / 256, NPV = NW == 1 ? 10 : 7;
+  constexpr int NPF = (RT * CT * QF + 255) / 256;
   const int wtotal = g.WR * g.WC * QV;
-  const bool pipe = !g.v_add && !g.v_gate && wtotal <= NPV * 256;
+  const bool pipe = !g.v_gate && (VADD || !g.v_add) && wtotal <= NPV * 256;
   f32x4 pf[NPF], pv[NPV];
+  // input add (UpConvBlock: x + relu(time_mlp(t)) before its convolution) under the pipeline: a thread's pieces all carry the
+  // same 4 channels (256 % QV == 0), so ONE vector of the image's row rides along with the prefetch and is added at store
+  // time to the pieces that were inside the image (bit u of pv_in).  Adding it at load time - what the in-place staging does -
+  // would wait for every load right after issuing it: those layers ran unpipelined before (167 us against ~100).
+  static_assert(256 % QV == 0, "a thread's window pieces share their channel quad");
+  f32x4 padd = {0.f, 0.f, 0.f, 0.f};
+  unsigned pv_in = 0;
   auto tile_coords = [&](int tile, int& n, int& ty0, int& tx0) __attribute__((always_inline)) {
     tx0 = (tile % g.tiles_x) * CT;
     ty0 = ((tile / g.tiles_x) % g.tiles_y) * RT;
@@ -153,8 +159,26 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBf16Args g) {
     tile_coords(tile, n, ty0, tx0);
 #pragma unroll
     for (int u = 0; u < NPF; ++u) pf[u] = load_f(tid + u * 256, n, ty0, tx0);
+    if constexpr (VADD) {
+      const int c = v0 + (tid % QV) * 4;
+      padd = c < g.Cv ? *reinterpret_cast<const f32x4*>(g.v_add + (long long)n * g.v_add_cs + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      pv_in = 0;
+    }
 #pragma unroll
-    for (int u = 0; u < NPV; ++u) pv[u] = load_v(tid + u * 256, n, ty0, tx0);
+    for (int u = 0; u < NPV; ++u) {
+      if constexpr (VADD) {  // raw load + the in-image bit (the add follows at store time)
+        const int i = tid + u * 256, q = i % QV, p = i / QV;
+        const int wy = (int)__umulhi((unsigned)p, g.wc_magic), wx = p - wy * g.WC;
+        const int y = ty0 * g.sv + g.ymin + wy, x = tx0 * g.sv + g.xmin + wx, c = v0 + q * 4;
+        const bool ok = i < wtotal && y >= 0 && y < g.VH && x >= 0 && x < g.VW && c < g.Cv;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(g.V + (((long long)n * g.VH + y) * g.VW + x) * g.v_cs + g.v_co + c);
+        pv[u] = v;
+        pv_in |= (ok ? 1u : 0u) << u;
+      } else {
+        pv[u] = load_v(tid + u * 256, n, ty0, tx0);
+      }
+    }
   };
   if (pipe && (int)blockIdx.x < g.ntiles) prefetch(blockIdx.x);
 
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBf16Args g) {
 #pragma unroll
       for (int u = 0; u < NPF; ++u) store_f(tid + u * 256, pf[u]);
 #pragma unroll
-      for (int u = 0; u < NPV; ++u) store_v(tid + u * 256, pv[u]);
+      for (int u = 0; u < NPV; ++u) store_v(tid + u * 256, (VADD && ((pv_in >> u) & 1u)) ? pv[u] + padd : pv[u]);
     } else {
       // ---- stage F: RT x CT positions, CHF channels (zero outside the domain), converted to bf16 hi | lo ----
       for (int i = tid; i < RT * CT * QF; i += 256) store_f(i, load_f(i, n, ty0, tx0));
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradBf16Args g) {
   }
 }
 
-template <int NT, int MW, int NW>
+template <int NT, int MW, int NW, int NPV, int MINB, bool VADD = false>
 int launch_cfg(const WgradBf16Args& a0, int target_blocks, size_t partial_bytes, int* nslices, hipStream_t s) {
   WgradBf16Args a = a0;
   constexpr int CHF = 2 * MW * 16, CHV = 2 * NW * 16;
@@ -258,7 +282,7 @@ int launch_cfg(const WgradBf16Args& a0, int target_blocks, size_t partial_bytes,
   a.vt_bytes = ((a.WR * a.WC + 7) / 8) * 384 + 32;
   const size_t lds = 2 * ((size_t)(CHF / 16) * F_TILE_BYTES + (size_t)(CHV / 16) * a.vt_bytes);
   if (lds > 160 * 1024) return -1;
-  auto kern = wgrad_bf16_kernel<NT, MW, NW>;
+  auto kern = wgrad_bf16_kernel<NT, MW, NW, NPV, MINB, VADD>;
   if (lds > 64 * 1024) DRS_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DRS_LAUNCH(kern, dim3((unsigned)ksplit, ct), dim3(256), lds, s, a);
   DRS_CHECK_HIP(hipGetLastError());
@@ -266,15 +290,25 @@ int launch_cfg(const WgradBf16Args& a0, int target_blocks, size_t partial_bytes,
   return DRS_OK;
 }
 
+// Tile configurations.  Register budget first: the 64 x 64 tile of a 9-tap layer holds 144 accumulators and, with its
+// prefetch registers, needs ~480 registers - ONE 4-wave block per CU (512 registers per lane and SIMD are shared by its waves).
+// The 64 x 32 tile (72 accumulators) fits 256: two blocks per CU, twice the waves to cover the barriers and the staging.
 template <int NT>
 int launch_nt(const WgradBf16Args& a, size_t partial_bytes, int* nslices, hipStream_t s) {
   const int target = NT == 1 ? 2048 : 1024;
   // stride-2 tap sets (ConvTranspose / stride-2 convolution: the V window of a 4 x 16 tile is 9 x 33 pixels): a 64-channel V tile
   // needs 117 KB of LDS - one block per CU, window staged in place with nothing to hide the round trip (255 - 300 us for the
-  // 19 GFLOP of a `transform` layer); a 32-channel V tile runs two blocks per CU with the window prefetched
-  if (a.sv == 2 && a.Cf % 64 == 0 && a.Cv % 32 == 0) return launch_cfg<NT, 2, 1>(a, target, partial_bytes, nslices, s);  // 64 x 32
-  if (a.Cf % 64 == 0 && a.Cv % 64 == 0) return launch_cfg<NT, 2, 2>(a, target, partial_bytes, nslices, s);  // 64 x 64
-  return launch_cfg<NT, 1, 1>(a, target, partial_bytes, nslices, s);                                        // 32 x 32
+  // 19 GFLOP of a `transform` layer); a 32-channel V tile has the window prefetched (ten registers: 2376 pieces): 167 us.
+  // (324 registers, one block per CU; squeezed into 256 for two blocks - 9 spills - it measured 240 - 280 us)
+  if (a.sv == 2 && a.Cf % 64 == 0 && a.Cv % 32 == 0) return launch_cfg<NT, 2, 1, 10, 1>(a, target, partial_bytes, nslices, s);  // 64 x 32
+  // a per-image vector added to the window (UpConvBlock: x + relu(time_mlp(t)) before ups.i.conv): its own instantiation, the
+  // add under the pipeline (167 -> 85 us per layer; in-place staging before)
+  if constexpr (NT == 9)
+    if (a.v_add && !a.v_gate && a.sv == 1 && a.Cf % 64 == 0 && a.Cv % 32 == 0)
+      return launch_cfg<NT, 2, 1, 4, 2, true>(a, target, partial_bytes, nslices, s);
+  // 64 x 32, two blocks per CU (the 64 x 64 tile it replaced - one block per CU - per layer: 264 -> 198 us, 105 -> 78, 60 -> 46)
+  if (a.sv == 1 && a.Cf % 64 == 0 && a.Cv % 32 == 0) return launch_cfg<NT, 2, 1, 4, 2>(a, target, partial_bytes, nslices, s);
+  return launch_cfg<NT, 1, 1, 10, 1>(a, target, partial_bytes, nslices, s);                                 // 32 x 32
 }
 
 }  // namespace
