@@ -40,7 +40,7 @@ __device__ __forceinline__ bf16x8 dpp_shift(const bf16x8& edge, const bf16x8& ow
   return __builtin_bit_cast(bf16x8, o);
 }
 
-template <int NT, bool HAS2, bool DUAL, bool FUSE>
+template <int NT, bool HAS2, bool DUAL, bool FUSE, bool PROJ = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, int nck, unsigned w_gimage, unsigned w2_gimage) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
   char* sW = smem;
   char* sW2 = smem + 2 * img;
   float* sBias = reinterpret_cast<float*>(sW2 + 2 * img2);  // [CW] bias (+ bias2)   (fused projection: + fuse_w[4][32] + fuse_b[4])
-  float* sPost = sBias + (FUSE ? 32 + 128 + 4 : CW);        // [N][Cout] post_add rows, then [N][Cout] post2 rows
-  const int npost = min(d.N, NPOST);
+  float* sPost = sBias + (FUSE ? 32 + 128 + 4 : PROJ ? 32 : CW);  // [N][Cout] post_add rows, then [N][Cout] post2 rows
+  const int npost = PROJ ? 0 : min(d.N, NPOST);
   float* sPost2 = sPost + npost * d.Cout;
   {
     auto copy = [&](char* dst, const char* src, int bytes) __attribute__((always_inline)) {  // 8 loads in flight per thread
@@ -93,7 +93,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
       copy(sW2 + img2, w2 + w2_gimage, img2);
     }
     for (int i = tid; i < CW; i += 512) sBias[i] = (d.bias ? d.bias[i] : 0.f) + ((HAS2 && d.bias2) ? d.bias2[i] : 0.f);
-    if constexpr (FUSE) {
+    if constexpr (PROJ) {
+      if (tid < 4) sBias[16 + tid] = d.fuse_b ? d.fuse_b[min(tid, d.fuse_dim - 1)] : 0.f;
+    } else if constexpr (FUSE) {
       for (int i = tid; i < 128; i += 512) sBias[32 + i] = d.fuse_w[min(i >> 5, d.fuse_dim - 1) * d.Cout + (i & 31)];
       if (tid < 4) sBias[160 + tid] = d.fuse_b[min(tid, d.fuse_dim - 1)];
     } else {
@@ -294,6 +296,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
         TapConv de = d;
         de.relu_pre = 0;
         tile_epilogue_sp_pre<RB, false>(de, comb, kc, n, 0, yb, x0, 0, lr, kg);
+      } else if constexpr (PROJ) {
+        // folded projection: MFMA row 4 j = output j, i.e. register 0 of the lanes of k-group j; one store instruction per row
+        // writes all fuse_dim planes (16 consecutive pixels each)
+        const size_t plane = (size_t)d.OH * d.OW;
+        const float fbk = sBias[16 + kg];
+        if (kg < d.fuse_dim) {
+          float* o = d.fuse_out + ((size_t)n * d.fuse_dim + kg) * plane + (size_t)yb * d.OW + x0 + lr;
+#pragma unroll
+          for (int r = 0; r < RB; ++r) o[(size_t)r * d.OW] = acc[r][0][0] + fbk;
+        }
       } else if constexpr (FUSE) {
         FuseEpiConst kc;
         kc.b0 = *reinterpret_cast<const float4*>(sBias + kg * 4);
@@ -327,13 +339,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
 size_t direct_lds_bytes(const TapConv& d) {
   const int nck = (d.Cin + 31) / 32, CW = d.dual ? 2 * d.Cout : d.Cout;
   size_t b = (d.dual ? (size_t)2 * 5 * 4 * CW * 16 : (size_t)2 * nck * 36 * CW * 16) + (d.in2 ? (size_t)2 * 4 * CW * 16 : 0);
-  b += d.fuse_out ? (32 + 128 + 4) * 4 : (size_t)(CW + 2 * (d.N < NPOST ? d.N : NPOST) * d.Cout) * 4;
+  b += d.proj ? 32 * 4 : d.fuse_out ? (32 + 128 + 4) * 4 : (size_t)(CW + 2 * (d.N < NPOST ? d.N : NPOST) * d.Cout) * 4;
   return b;
 }
 
-template <int NT, bool HAS2, bool DUAL, bool FUSE>
+template <int NT, bool HAS2, bool DUAL, bool FUSE, bool PROJ = false>
 int direct_launch(const TapConv& d, hipStream_t s) {
-  auto kern = conv3x3_direct_sp_kernel<NT, HAS2, DUAL, FUSE>;
+  auto kern = conv3x3_direct_sp_kernel<NT, HAS2, DUAL, FUSE, PROJ>;
   int num_cu = 0;
   {
     const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
@@ -355,7 +367,41 @@ bool std3x3(const TapConv& d) {
   return true;
 }
 
+// W''[4 j][ci][tap] = sum_co fw[j][co] * w[co][cin_off + ci][tap]: the 1x1 projection behind a bare 3x3 convolution folded into
+// its weights (fp32 contraction at pack time, the same class of re-association as the BatchNorm fold and the composite stage)
+__global__ __launch_bounds__(256) void fold_proj_kernel(const float* __restrict__ w, int cin_total, int cin_off, int Cmid, int Cin,
+                                                        const float* __restrict__ fw, int fuse_dim, float* __restrict__ dst) {
+  const int total = 16 * Cin * 9;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int row = i / (Cin * 9), rem = i - row * Cin * 9, ci = rem / 9, tap = rem - ci * 9;
+    const int j = row >> 2;
+    float a = 0.f;
+    if ((row & 3) == 0 && j < fuse_dim)
+      for (int co = 0; co < Cmid; ++co) a += fw[(size_t)j * Cmid + co] * w[((size_t)co * cin_total + cin_off + ci) * 9 + tap];
+    dst[i] = a;
+  }
+}
+
 }  // namespace
+
+int drs_launch_fold_proj(const float* w, int cin_total, int cin_off, int Cmid, int Cin, const float* fw, int fuse_dim, float* dst,
+                         hipStream_t s) {
+  DRS_REQUIRE(w && fw && dst && fuse_dim >= 1 && fuse_dim <= 4 && Cin > 0 && Cmid > 0, DRS_ERR_ARG, "fold_proj: bad arguments");
+  DRS_LAUNCH(fold_proj_kernel, dim3((16 * Cin * 9 + 255) / 256), dim3(256), 0, s, w, cin_total, cin_off, Cmid, Cin, fw, fuse_dim, dst);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// The folded-projection flavour (TapConv::proj): 16-row weight image, one channel tile per wave, planar fp32 output.
+bool drs_conv3x3_direct_sp_proj_supported(const TapConv& d, int impl) {
+  static const bool env = !(getenv("DRS_FOLD_PROJ") && atoi(getenv("DRS_FOLD_PROJ")) == 0);
+  if (!env || impl != DRS_IMPL_MFMA_BF16X3 || !d.proj) return false;
+  if (!d.in || !d.in_sp || !d.zero_line || !std3x3(d) || !d.fuse_out || d.fuse_dim < 1 || d.fuse_dim > 4 || d.Cout != 16) return false;
+  if (d.out || d.out2 || d.in2 || d.dual || d.gate || d.in_add || d.res || d.post_add || d.relu_pre || d.relu_post || d.sigmoid) return false;
+  if ((d.in_co & 31) || (d.in_cs & 31) || d.Cin % 32 != 0) return false;
+  if ((d.W & 15) || (d.H % RB) || d.H < 64 || d.TH != d.H || d.TW != d.W || d.OH != d.H || d.OW != d.W) return false;
+  return direct_lds_bytes(d) <= 156 * 1024;
+}
 
 // Eligibility (shape only, never the batch size: a forward must not change its arithmetic with the batch): what
 // drs_tapconv_sp_supported takes, 32 output channels (the first / last level of every variant: one channel group per wave;
@@ -365,6 +411,7 @@ bool std3x3(const TapConv& d) {
 bool drs_conv3x3_direct_sp_supported(const TapConv& d, int impl) {
   static const int env = getenv("DRS_D3K") ? atoi(getenv("DRS_D3K")) : 15;
   if (!env || impl != DRS_IMPL_MFMA_BF16X3) return false;
+  if (d.proj) return false;  // (its own test: drs_conv3x3_direct_sp_proj_supported)
   if (!(env & (d.dual ? 4 : d.fuse_out ? 8 : d.in2 ? 2 : 1))) return false;
   if (!drs_tapconv_sp_supported(d, impl) || !std3x3(d)) return false;
   if ((d.W & 15) || (d.H % RB) || d.H < 64 || d.TH != d.H || d.TW != d.W || d.OH != d.H || d.OW != d.W) return false;
@@ -377,6 +424,10 @@ bool drs_conv3x3_direct_sp_supported(const TapConv& d, int impl) {
 }
 
 int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s) {
+  if (d.proj) {
+    DRS_REQUIRE(drs_conv3x3_direct_sp_proj_supported(d, DRS_IMPL_MFMA_BF16X3), DRS_ERR_SHAPE, "conv3x3_direct_sp: unsupported folded-projection layer");
+    return direct_launch<1, false, false, false, true>(d, s);
+  }
   if (d.dual) return direct_launch<4, false, true, false>(d, s);
   if (d.fuse_out) return direct_launch<2, false, false, true>(d, s);
   return d.in2 ? direct_launch<2, true, false, false>(d, s) : direct_launch<2, false, false, false>(d, s);

@@ -60,6 +60,10 @@ struct TapConv {
   const float* fuse_b;
   float* fuse_out;
   int fuse_dim;
+  // proj = 1: the projection is FOLDED INTO THE WEIGHTS (both maps are linear and nothing sits between them): `w` is a
+  // 16-row operand image whose MFMA row 4 j carries output j < fuse_dim (drs_launch_fold_proj), Cout == 16, fuse_w unused:
+  //   fuse_out[n][j][oy][ox] = acc[row 4 j] (+ fuse_b[j] if set).  conv3x3_direct_sp.hip only.
+  int proj;
   // launch hint: this op runs next to another one on a second stream: one block per CU (80 KB of LDS each, so a block of
   // either kernel fits on every CU at the same time) and no 512-thread variant; 2 = two blocks per CU for the small-LDS
   // 1x1 flavours (37 KB each next to the partner's 80 KB)
@@ -265,7 +269,15 @@ int drs_launch_nchw_to_sp(const float* src, float* dst, int N, int C, int H, int
 int drs_launch_sp_add_rowvec(const float* src, float* dst, const float* vec, int vec_stride, int N, long long pix_per_image,
                              int C, hipStream_t s);
 bool drs_tapconv_sp8_supported(const TapConv& d, int impl);  // its 8 x 8-image instance (conv_mfma_sp8.hip)
-bool drs_tapconv_sp_supported(const TapConv& d, int impl);  // wave-specialised SP-format 3x3 kernel (conv_mfma_sp.hip) takes this op
+bool drs_tapconv_sp_supported(const TapConv& d, int impl);
+// 3x3 stride 1 for the shallow layers (conv3x3_direct_sp.hip); with TapConv::proj the folded-projection flavour
+int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s);
+// weights of a 3x3 convolution (Cmid outputs; input channels [cin_off, cin_off + Cin) of cin_total) followed by a 1x1
+// projection fw[fuse_dim][Cmid], as ONE 3x3 convolution: dst[16][Cin][9] fp32, row 4 j = output j, other rows zero
+int drs_launch_fold_proj(const float* w, int cin_total, int cin_off, int Cmid, int Cin, const float* fw, int fuse_dim, float* dst,
+                         hipStream_t s);
+bool drs_conv3x3_direct_sp_proj_supported(const TapConv& d, int impl);
+  // wave-specialised SP-format 3x3 kernel (conv_mfma_sp.hip) takes this op
 
 // planar (NCHW) small-channel kernels
 int drs_launch_conv3x3_planar(const float* in, const float* w, const float* b, const float* res, float* out, int N,

@@ -369,6 +369,10 @@ struct DecStage {
   // and the att-half of up_convs.i packed as its own Ch -> Ch 3x3 convolution (no bias: it is in the composite's)
   bool upfuse = false;
   size_t uf_w_off = 0, uf_aux_off = 0, uf_edge_off = 0, ah_w_off = 0, ah_b_off = 0;
+  // stage 2: the `output` projection folded into the att-half's weights (conv3x3_direct_sp.hip, TapConv::proj): a 16-row image,
+  // ah_tmp = the fp32 contraction it is packed from
+  bool ah_proj = false;
+  size_t ah_tmp_off = 0;
   int t_PA = -1;                  // att-half partial sums (SP), B x Ch x 2lh x 2lw
   size_t o_eh = 0, o_ev = 0;      // workspace: edge vectors of this forward
 };
@@ -649,6 +653,13 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
       d.uf_edge_off = cur; cur += align_up(drs_upfuse_edge_image_bytes(Cc, Ch));
       d.ah_w_off = cur; cur += align_up(drs_pack_conv_mfma_bytes(Ch, Ch, 9, DRS_IMPL_MFMA_BF16X3));
       d.ah_b_off = cur; cur += align_up((size_t)Ch * 4);
+      if (i == 2) {
+        TapConv probe = conv_desc((const float*)256, cfg->batch, cfg->height, cfg->width, Ch, Cc + Ch, Cc, (const float*)256, nullptr, nullptr,
+                                  16, 16, 0, 3, 3, 1, 1);
+        probe.in_sp = 1; probe.zero_line = (const void*)256; probe.proj = 1; probe.fuse_out = (float*)256; probe.fuse_dim = cfg->out_dim;
+        d.ah_proj = drs_conv3x3_direct_sp_proj_supported(probe, cfg->impl);
+        if (d.ah_proj) { d.ah_tmp_off = cur; cur += align_up((size_t)16 * Ch * 9 * 4); }
+      }
     }
   }
   for (PlanarConv* L : p->planars) {
@@ -886,7 +897,17 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
                                      (float*)(base + d.uf_aux_off), base + d.uf_edge_off, s)))
       return rc;
     // att-half: input channels [Cc, Cc + Ch) of up_convs.i, zero bias; SP output rows in stages 0 / 1, plain MFMA rows in
-    // stage 2, whose att-half goes through the fused output projection instead of being stored
+    // stage 2, whose att-half goes through the fused output projection instead of being stored - or, where the direct kernel
+    // takes the layer, has the projection folded into its weights: output o up_convs.2[att half] is ONE 3x3 convolution
+    // Ch -> out_dim (reference :377,:379: no activation or normalisation between the two), half the MFMAs of the 32-channel form
+    if (d.ah_proj) {
+      float* tmp = (float*)(base + d.ah_tmp_off);
+      if ((rc = drs_launch_fold_proj(F(d.upconv.w), Cc + Ch, Cc, Ch, Ch, F(plan->output.w), plan->cfg.out_dim, tmp, s))) return rc;
+      if ((rc = drs_launch_pack_conv_mfma(tmp, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + d.ah_w_off,
+                                          (float*)(base + d.ah_b_off), 16, Ch, 9, 0, impl, s, 0, 0, 0, 0, 0)))
+        return rc;
+      continue;
+    }
     if ((rc = drs_launch_pack_conv_mfma(F(d.upconv.w), nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + d.ah_w_off,
                                         (float*)(base + d.ah_b_off), Ch, Ch, 9, 0, impl, s, 0, 0, 0, 0, i < 2 ? 1 : 0, Cc + Ch, Cc)))
       return rc;
@@ -1401,6 +1422,18 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         TapConv d = conv_desc(cat, B, 2 * lh, 2 * lw, Ch, Cc + Ch, Cc, (const float*)(pk + st.ah_w_off),
                               (const float*)(pk + st.ah_b_off), i < 2 ? TP(st.t_PA) : nullptr, Ch, Ch, 0, 3, 3, 1, 1);
         d.in_sp = 1; d.out_sp = 1; d.zero_line = zero_line; d.fault = plan->fault_ptr;
+        const double ah_flops = conv_flops(d), ah_bytes = conv_bytes(d);  // (the reference's op, whatever form runs)
+        if (i == 2 && st.ah_proj) {
+          // projection folded into the weights (pack time): a Ch -> out_dim 3x3 convolution straight into the caller's tensor
+          d.out = nullptr; d.out_sp = 0; d.bias = nullptr;
+          d.Cout = 16; d.out_cs = 16;
+          d.proj = 1;
+          d.fuse_out = out; d.fuse_dim = c.out_dim; d.fuse_b = nullptr;
+          prof_begin(plan, "up_convs.2.att", ah_flops, ah_bytes, s);
+          rc = drs_launch_conv3x3_direct_sp(d, s);
+          prof_end(plan, s);
+          if (rc) return rc;
+        } else {
         if (i == 2) {
           // the `output` projection is linear: the att-half is projected HERE (its own fused-projection epilogue, zero bias)
           // into the caller's output tensor and the composite kernel adds its part: 12.6 MB written and read back instead
@@ -1411,10 +1444,11 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
           d.fuse_out = out;
           d.fuse_dim = c.out_dim;
         }
-        prof_begin(plan, "up_convs." + std::to_string(i) + ".att", conv_flops(d), conv_bytes(d), s);
+        prof_begin(plan, "up_convs." + std::to_string(i) + ".att", ah_flops, ah_bytes, s);
         rc = drs_launch_tapconv_mfma(d, c.impl, s);
         prof_end(plan, s);
         if (rc) return rc;
+        }
       }
       {
         UpFuseDesc u = {};
