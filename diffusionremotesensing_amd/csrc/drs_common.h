@@ -227,9 +227,18 @@ struct UpFuseDesc {
   // fuse_w comp + fuse_w att_half + ...), written by the att-half convolution's own fused-projection epilogue: this kernel
   // adds its part.  12.6 MB instead of the 134 MB of 32-channel partial sums per forward at 256 x 256; `res` is null then.
   int fuse_acc;
+  // proj = 1: the projection is folded into the composite weights (drs_launch_upfuse_fold_proj feeds the pack: a 32-channel
+  // layer whose logical channel 8 j is output j, everything else zero - MFMA row 4 j of the first channel tile): the kernel
+  // multiplies ONE channel tile, streams half of every weight group and stores acc + bias + edge + fuse_out; fuse_w / fuse_b
+  // are unused (the output bias is part of `bias`).
+  int proj;
   const void* zero_line;
   unsigned* fault;
 };
+// (v_w', v_b') of that layer: v_w'[8 j][c][kv] = sum_co fw[j][co] v_w[co][c][kv] for c < Cc (the x-half of up_convs.i),
+// v_b'[8 j] = fb[j] + sum_co fw[j][co] v_b[co]; dst_w: 32 x (Cc + Ch) x 9 floats, dst_b: 32 floats
+int drs_launch_upfuse_fold_proj(const float* v_w, const float* v_b, const float* fw, const float* fb, int fuse_dim, int Cc, int Ch,
+                                float* dst_w, float* dst_b, hipStream_t s);
 
 // The first encoder block (16 -> 32 -> 32 channels) as one launch (resblock0_sp.hip): h = relu(conv1(x)) + temb + skip(x)
 // lives in LDS only, out = relu(conv2(h) + shortcut(x)).  All convolutions BatchNorm-folded, operands in the packed

@@ -373,6 +373,9 @@ struct DecStage {
   // ah_tmp = the fp32 contraction it is packed from
   bool ah_proj = false;
   size_t ah_tmp_off = 0;
+  // ... and into the composite's (UpFuseDesc::proj): the folded up_convs.2 x-half the composite is packed from
+  bool uf_proj = false;
+  size_t uf_tmpw_off = 0, uf_tmpb_off = 0;
   int t_PA = -1;                  // att-half partial sums (SP), B x Ch x 2lh x 2lw
   size_t o_eh = 0, o_ev = 0;      // workspace: edge vectors of this forward
 };
@@ -659,6 +662,13 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
         probe.in_sp = 1; probe.zero_line = (const void*)256; probe.proj = 1; probe.fuse_out = (float*)256; probe.fuse_dim = cfg->out_dim;
         d.ah_proj = drs_conv3x3_direct_sp_proj_supported(probe, cfg->impl);
         if (d.ah_proj) { d.ah_tmp_off = cur; cur += align_up((size_t)16 * Ch * 9 * 4); }
+        // the composite's folded form needs the att-half in the output tensor first (fuse_acc): both or neither
+        static const bool uf_env = !(getenv("DRS_FOLD_PROJ_UF") && atoi(getenv("DRS_FOLD_PROJ_UF")) == 0);
+        d.uf_proj = d.ah_proj && uf_env;
+        if (d.uf_proj) {
+          d.uf_tmpw_off = cur; cur += align_up((size_t)32 * (Cc + Ch) * 9 * 4);
+          d.uf_tmpb_off = cur; cur += align_up((size_t)32 * 4);
+        }
       }
     }
   }
@@ -893,7 +903,14 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     const DecStage& d = plan->dec[i];
     if (!d.upfuse) continue;
     const int Cc = kUp[i], Ch = kUp[i + 1];
-    if ((rc = drs_launch_upfuse_pack(F(d.upconv.w), F(d.upconv.b), F(d.transform.w), F(d.transform.b), Cc, Ch, base + d.uf_w_off,
+    const float *uv_w = F(d.upconv.w), *uv_b = F(d.upconv.b);
+    if (d.uf_proj) {  // `output` folded into up_convs.2: the composite, its edge weights and its bias are built from the folded layer
+      float* tw = (float*)(base + d.uf_tmpw_off);
+      float* tb = (float*)(base + d.uf_tmpb_off);
+      if ((rc = drs_launch_upfuse_fold_proj(uv_w, uv_b, F(plan->output.w), F(plan->output.b), plan->cfg.out_dim, Cc, Ch, tw, tb, s))) return rc;
+      uv_w = tw; uv_b = tb;
+    }
+    if ((rc = drs_launch_upfuse_pack(uv_w, uv_b, F(d.transform.w), F(d.transform.b), Cc, Ch, base + d.uf_w_off,
                                      (float*)(base + d.uf_aux_off), base + d.uf_edge_off, s)))
       return rc;
     // att-half: input channels [Cc, Cc + Ch) of up_convs.i, zero bias; SP output rows in stages 0 / 1, plain MFMA rows in
@@ -1461,8 +1478,12 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         u.zero_line = zero_line; u.fault = plan->fault_ptr;
         if (i == 2) {  // output 1x1 conv (:379) rides in the epilogue; the 32-channel tensor is never written
           u.res = nullptr; u.fuse_acc = 1;
-          u.fuse_w = (const float*)(pk + plan->o_out_w);
-          u.fuse_b = (const float*)(pk + plan->o_out_b);
+          if (st.uf_proj) {
+            u.proj = 1;  // the projection (and its bias) is inside the composite weights / bias / edge vectors
+          } else {
+            u.fuse_w = (const float*)(pk + plan->o_out_w);
+            u.fuse_b = (const float*)(pk + plan->o_out_b);
+          }
           u.fuse_out = out;
           u.fuse_dim = c.out_dim;
           fused_output = true;

@@ -68,8 +68,9 @@ __host__ __device__ constexpr bool uf_pair(int p, int t, int kv, int kw) { retur
 // SP output-row permutation (drs_sp_cout_perm of the pack kernels): MFMA row nn of a 32-channel group carries logical channel
 __host__ __device__ constexpr int uf_perm(int nn) { return ((nn & 15) >> 2) * 8 + (nn >> 4) * 4 + (nn & 3); }
 
-template <bool FUSE>
+template <bool FUSE, bool PROJ = false>
 __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int tiles_y, int tiles_x, int nck, int debug) {
+  constexpr int NT = PROJ ? 1 : 2;  // channel tiles a consumer multiplies (PROJ: rows 16..31 of every weight group are zero)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   using G = UfGeom;
@@ -155,6 +156,13 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
     const bool tail_ok = (NBLK - 1) * 8 + l_px < G::NPIX;  // the last block is half empty
     constexpr int WPC = 5;                                 // weight pieces (1 KB) per mover wave and group
     u32x4 wr[2][WPC], ww[NPW];
+    if constexpr (PROJ) {
+#pragma unroll
+      for (int i = 0; i < WPC; ++i) wr[0][i] = wr[1][i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    // PROJ: a 1 KB weight piece = two (tap, k-group) rows of 32 channel slots; channels 16..31 (lanes with bit 4 set) are the
+    // second channel tile, all zero and never read: those lanes do not load (half the weight traffic of a step)
+    const bool wlane_on = !PROJ || !(lane & 16);
     const int nwin = pw == 0 ? NPW : NPW - 1;
     const char* wg = reinterpret_cast<const char*>(d.w);
     const unsigned my_piece = (unsigned)(pw * WPC) * 1024u + (unsigned)lane * 16u;
@@ -213,7 +221,8 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
       const char* gsrc = wg + ((size_t)(n0 >> 5) * nck + c) * (size_t)(G::NGRP * SLOT) + my_piece;
       auto load_grp = [&](int g, int set) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < WPC; ++i) wr[set][i] = *reinterpret_cast<const u32x4*>(gsrc + (unsigned)(g * SLOT + i * 1024));
+        for (int i = 0; i < WPC; ++i)
+          if (wlane_on) wr[set][i] = *reinterpret_cast<const u32x4*>(gsrc + (unsigned)(g * SLOT + i * 1024));
       };
       // store group g (registers `set`) once its ring slot is free; `after` = vector-memory operations issued after its loads
       auto store_grp = [&](int g, int set, int after) __attribute__((always_inline)) {
@@ -261,8 +270,8 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
     // epilogue, which would otherwise push them into scratch (reloads inside the MFMA loop).
     int tab[8];
     const char* wlane = sW + (kg * 32 + lr) * 16;  // this lane's origin inside a ring slot
-    f32x4 acc[RPW][2][2];                           // [cell row][y-phase][channel tile]
-    typename P::Frag wf[3][2];
+    f32x4 acc[RPW][2][NT];                          // [cell row][y-phase][channel tile]
+    typename P::Frag wf[3][NT];
     auto win_frag = [&](const char* buf, int q) __attribute__((always_inline)) {  // q: compile-time window offset
       return typename P::Frag{*reinterpret_cast<const bf16x8*>(buf + tab[q & 7] + q * 128),
                               *reinterpret_cast<const bf16x8*>(buf + tab[(q & 7) ^ 4] + q * 128)};
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) wf[ty][t] = P::load(sb, W_IMAGE, (size_t)(ty * 2048 + t * 256));
+        for (int t = 0; t < NT; ++t) wf[ty][t] = P::load(sb, W_IMAGE, (size_t)(ty * 2048 + t * 256));
       // pass py0: 3 taps over window rows 0..5.  wf[0] (ty 0) is last used by row 3, wf[1] by row 4: the taps of pass py1
       // (ty 1 -> wf[0], ty 2 -> wf[1]) are read under the tail of this pass.
 #pragma unroll
@@ -288,16 +297,16 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
           const int r = wr - ty;
           if (r >= 0 && r < RPW) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[r][0][t] = P::mma(wf[ty][t], af, acc[r][0][t]);
+            for (int t = 0; t < NT; ++t) acc[r][0][t] = P::mma(wf[ty][t], af, acc[r][0][t]);
           }
         }
         if (wr == RPW - 1) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) wf[0][t] = P::load(sb, W_IMAGE, (size_t)(3 * 2048 + t * 256));
+          for (int t = 0; t < NT; ++t) wf[0][t] = P::load(sb, W_IMAGE, (size_t)(3 * 2048 + t * 256));
         }
         if (wr == RPW) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) wf[1][t] = P::load(sb, W_IMAGE, (size_t)(4 * 2048 + t * 256));
+          for (int t = 0; t < NT; ++t) wf[1][t] = P::load(sb, W_IMAGE, (size_t)(4 * 2048 + t * 256));
         }
       }
       UF_STAMP(2);
@@ -309,11 +318,11 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
         const typename P::Frag af = win_frag(buf, wr * IW + tx);
         if (wr - 1 < RPW) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[wr - 1][1][t] = P::mma(wf[0][t], af, acc[wr - 1][1][t]);
+          for (int t = 0; t < NT; ++t) acc[wr - 1][1][t] = P::mma(wf[0][t], af, acc[wr - 1][1][t]);
         }
         if (wr - 2 >= 0) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[wr - 2][1][t] = P::mma(wf[1][t], af, acc[wr - 2][1][t]);
+          for (int t = 0; t < NT; ++t) acc[wr - 2][1][t] = P::mma(wf[1][t], af, acc[wr - 2][1][t]);
         }
       }
     };
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
 #pragma unroll
           for (int py = 0; py < 2; ++py)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[r][py][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) acc[r][py][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       {
         int lr_s = lr, kg_s = kg;
@@ -354,6 +363,65 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
       UF_STAMP(5);
       sp_release(sWR + (k & 1), lane);  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
       UF_STAMP(6);
+      if constexpr (PROJ) {
+      if (c == nck - 1) {
+        // ---------------- item epilogue, folded projection ----------------
+        // MFMA row 4 kg of the (only) channel tile = logical channel 8 kg (uf_perm) = output kg: register 0 of the lanes of
+        // k-group kg.  value = acc + bias + edge vectors (32-channel vectors whose channel 8 j is output j) + what fuse_out
+        // already holds (the att-half, projected by its own folded weights); all loads before the first store.
+        int lr_e = lr, kg_e = kg;
+        asm volatile("" : "+v"(lr_e), "+v"(kg_e));
+        const int OH = 2 * d.LH, OW = 2 * d.LW;
+        const int ch = kg_e * 8;
+        const int mx = tx0 + lr_e;
+        const bool own_ok = mx < d.LW && kg_e < d.fuse_dim;
+        const int ox_own = 2 * min(mx, d.LW - 1) + px;
+        const int myb = ty0 + rw * RPW;
+        const size_t plane = (size_t)OH * OW;
+        float* obase = d.fuse_out + ((size_t)n * d.fuse_dim + min(kg_e, d.fuse_dim - 1)) * plane + ox_own;
+        const float b = sConst[ch];
+        float add[RPW][2];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            const int oy = 2 * min(myb + r, d.LH - 1) + py;
+            add[r][py] = d.fuse_acc ? obase[(size_t)oy * OW] : 0.f;
+          }
+        if (d.eh) {
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+              const int oy = 2 * (myb + r) + py;
+              if (myb + r < d.LH && (oy == 0 || oy == OH - 1))
+                add[r][py] += d.eh[(((size_t)n * 2 + (oy ? 1 : 0)) * OW + ox_own) * d.Ch + ch];
+            }
+          if (mx < d.LW && (ox_own == 0 || ox_own == OW - 1)) {
+            const float* evp = d.ev + ((size_t)n * 2 + (ox_own ? 1 : 0)) * OH * d.Ch + ch;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+              for (int py = 0; py < 2; ++py) {
+                const int oy = 2 * (myb + r) + py;
+                if (myb + r < d.LH && oy > 0 && oy < OH - 1) add[r][py] += evp[(size_t)oy * d.Ch];  // (rows 0 / OH-1 took the row vectors)
+              }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int py = 0; py < 2; ++py) asm volatile("" :: "v"(add[r][py]));
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const int my = myb + r;
+          if (my < d.LH && own_ok) {
+#pragma unroll
+            for (int py = 0; py < 2; ++py) obase[(size_t)(2 * my + py) * OW] = acc[r][py][0][0] + b + add[r][py];
+          }
+        }
+      }
+      } else
       if (c == nck - 1) {
         // ---------------- item epilogue ----------------
         // lane (lr, kg) holds, per (cell row r, y-phase py), the 8 consecutive logical channels n0 + kg*8 .. +7 (tile 0:
@@ -804,6 +872,34 @@ __global__ void upfuse_edge_pack_kernel(const float* __restrict__ aux, int Cc, i
   }
 }
 
+// `output` folded into up_convs.i (x-half): a 32-channel layer whose logical channel 8 j is output j (MFMA row 4 j of the first
+// channel tile under uf_perm), everything else zero; the pack kernels above then build its composite image, edge weights and bias
+__global__ __launch_bounds__(256) void upfuse_fold_proj_kernel(const float* __restrict__ v_w, const float* __restrict__ v_b,
+                                                               const float* __restrict__ fw, const float* __restrict__ fb,
+                                                               int fuse_dim, int Cc, int Ch, float* __restrict__ dst_w,
+                                                               float* __restrict__ dst_b) {
+  const int cinv = Cc + Ch;
+  const int total = 32 * cinv * 9;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int row = i / (cinv * 9), rem = i - row * cinv * 9, c = rem / 9, kv = rem - c * 9;
+    const int j = row >> 3;
+    float a = 0.f;
+    if ((row & 7) == 0 && j < fuse_dim && c < Cc)
+      for (int co = 0; co < Ch; ++co) a += fw[(size_t)j * Ch + co] * v_w[((size_t)co * cinv + c) * 9 + kv];
+    dst_w[i] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 32) {
+    const int row = threadIdx.x, j = row >> 3;
+    float a = 0.f;
+    if ((row & 7) == 0 && j < fuse_dim) {
+      a = fb ? fb[j] : 0.f;
+      if (v_b)
+        for (int co = 0; co < Ch; ++co) a += fw[(size_t)j * Ch + co] * v_b[co];
+    }
+    dst_b[row] = a;
+  }
+}
+
 // NCHW fp32 -> SP channels-last (operator-level entry / tests only)
 __global__ void nchw_to_sp_kernel(const float* __restrict__ src, char* __restrict__ dst, int N, int C, int H, int W) {
   const int64_t hw = (int64_t)H * W, slots = (int64_t)N * hw * (C / 8);
@@ -851,6 +947,15 @@ int drs_launch_upfuse_pack(const float* v_w, const float* v_b, const float* t_w,
   return DRS_OK;
 }
 
+int drs_launch_upfuse_fold_proj(const float* v_w, const float* v_b, const float* fw, const float* fb, int fuse_dim, int Cc, int Ch,
+                                float* dst_w, float* dst_b, hipStream_t s) {
+  DRS_REQUIRE(v_w && fw && dst_w && dst_b && fuse_dim >= 1 && fuse_dim <= 4, DRS_ERR_ARG, "upfuse_fold_proj: bad arguments");
+  DRS_LAUNCH(upfuse_fold_proj_kernel, dim3((32 * (Cc + Ch) * 9 + 255) / 256), dim3(256), 0, s, v_w, v_b, fw, fb, fuse_dim, Cc, Ch,
+             dst_w, dst_b);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
 size_t drs_upfuse_edge_image_bytes(int Cc, int Ch) { return (size_t)2 * 2 * (Cc / 32) * 7 * 4 * Ch * 16; }
 
 int drs_launch_upfuse_edges(const UpFuseEdgeDesc& d, hipStream_t s) {
@@ -872,16 +977,18 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
   DRS_REQUIRE(!d.out || ((d.out_cs & 31) == 0 && (d.out_co & 31) == 0), DRS_ERR_SHAPE, "upfuse: out slice");
   DRS_REQUIRE(!d.out2 || (d.post2 && (d.out2_cs & 31) == 0 && (d.out2_co & 31) == 0 && (d.post2_cs & 3) == 0),
               DRS_ERR_SHAPE, "upfuse: out2");
-  DRS_REQUIRE(!d.fuse_out || (d.Ch == 32 && d.fuse_dim >= 1 && d.fuse_dim <= 4 && d.fuse_w && d.fuse_b && !d.out && !d.out2),
+  DRS_REQUIRE(!d.fuse_out || (d.Ch == 32 && d.fuse_dim >= 1 && d.fuse_dim <= 4 && (d.proj || (d.fuse_w && d.fuse_b)) && !d.out && !d.out2),
               DRS_ERR_SHAPE, "upfuse: fused projection needs Ch == 32, fuse_dim <= 4 and no wide output");
+  DRS_REQUIRE(!d.proj || (d.fuse_out && !d.res), DRS_ERR_ARG, "upfuse: the folded projection writes fuse_out and takes no residual");
   DRS_REQUIRE(!d.fuse_acc || (d.fuse_out && !d.res), DRS_ERR_ARG, "upfuse: fuse_acc takes the att-half from fuse_out, not from res");
   DRS_REQUIRE((d.eh == nullptr) == (d.ev == nullptr), DRS_ERR_ARG, "upfuse: edge vectors");
   if ((size_t)d.N * d.LH * d.LW == 0) return DRS_OK;
   const int tiles_y = drs_cdiv(d.LH, 16), tiles_x = drs_cdiv(d.LW, 16), nck = d.Cc / 32;
   const long long nitems = (long long)d.N * tiles_y * tiles_x * (d.Ch / 32);
   int num_cu = 0;
-  const void* kern = d.fuse_out ? reinterpret_cast<const void*>(upfuse_sp_kernel<true>)
-                                : reinterpret_cast<const void*>(upfuse_sp_kernel<false>);
+  const void* kern = d.proj ? reinterpret_cast<const void*>(upfuse_sp_kernel<false, true>)
+                            : d.fuse_out ? reinterpret_cast<const void*>(upfuse_sp_kernel<true>)
+                                         : reinterpret_cast<const void*>(upfuse_sp_kernel<false>);
   static_assert(UfGeom::LDS <= 160 * 1024, "LDS budget");
   {
     const int rc = drs_kernel_prepare(kern, 160 * 1024, &num_cu);
@@ -891,7 +998,9 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
   static const int dbg = getenv("DRS_DEBUG_FLAGS") ? atoi(getenv("DRS_DEBUG_FLAGS")) : 0;  // timeline builds: 1 no stores, 2 no residual loads
-  if (d.fuse_out)
+  if (d.proj)
+    DRS_LAUNCH((upfuse_sp_kernel<false, true>), dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
+  else if (d.fuse_out)
     DRS_LAUNCH(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
   else
     DRS_LAUNCH(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
