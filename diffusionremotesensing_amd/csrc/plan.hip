@@ -663,8 +663,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
         d.ah_proj = drs_conv3x3_direct_sp_proj_supported(probe, cfg->impl);
         if (d.ah_proj) { d.ah_tmp_off = cur; cur += align_up((size_t)16 * Ch * 9 * 4); }
         // the composite's folded form needs the att-half in the output tensor first (fuse_acc): both or neither
-        static const bool uf_env = !(getenv("DRS_FOLD_PROJ_UF") && atoi(getenv("DRS_FOLD_PROJ_UF")) == 0);
-        d.uf_proj = d.ah_proj && uf_env;
+        d.uf_proj = d.ah_proj;
         if (d.uf_proj) {
           d.uf_tmpw_off = cur; cur += align_up((size_t)32 * (Cc + Ch) * 9 * 4);
           d.uf_tmpb_off = cur; cur += align_up((size_t)32 * 4);
