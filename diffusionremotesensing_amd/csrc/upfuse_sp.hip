@@ -1012,7 +1012,9 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
     float ms = 0.f;
     DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
     DRS_CHECK_HIP(hipEventRecord(e0, s));
-    if (d.fuse_out)  // timed repeat (same result)
+    if (d.proj)  // timed repeat (fuse_acc: adds its part once more - timing runs only)
+      DRS_LAUNCH((upfuse_sp_kernel<false, true>), dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
+    else if (d.fuse_out)
       DRS_LAUNCH(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
     else
       DRS_LAUNCH(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
