@@ -295,7 +295,9 @@ int launch_cfg(const WgradBf16Args& a0, int target_blocks, size_t partial_bytes,
 // The 64 x 32 tile (72 accumulators) fits 256: two blocks per CU, twice the waves to cover the barriers and the staging.
 template <int NT>
 int launch_nt(const WgradBf16Args& a, size_t partial_bytes, int* nslices, hipStream_t s) {
-  const int target = NT == 1 ? 2048 : 1024;
+  // blocks per launch = K-slices x channel tiles: one resident wave of blocks (two per CU); twice as many measured 0.5 % slower
+  // per training step (twice the partial slices to write and to reduce)
+  const int target = NT == 1 ? 1024 : 512;
   // stride-2 tap sets (ConvTranspose / stride-2 convolution: the V window of a 4 x 16 tile is 9 x 33 pixels): a 64-channel V tile
   // needs 117 KB of LDS - one block per CU, window staged in place with nothing to hide the round trip (255 - 300 us for the
   // 19 GFLOP of a `transform` layer); a 32-channel V tile has the window prefetched (ten registers: 2376 pieces): 167 us.
