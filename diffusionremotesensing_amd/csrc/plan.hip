@@ -225,7 +225,7 @@ extern "C" int drs_conv2d_nchw(const float* x, const float* w, const float* b, f
 // ------------------------------------------------------------------------------------------------
 static size_t upfused_sizes(int N, int Cc, int Ch, int LH, int LW, size_t* o) {
   // o[0] h (SP), o[1] att (SP), o[2] att-half partial sums, o[3] result (SP), o[4] composite image, o[5] aux, o[6] att-half
-  // weights, o[7] att-half bias, o[8] eh, o[9] ev, o[10] zero line + fault word, o[11] edge operand image
+  // weights, o[7] att-half bias, o[8] eh, o[9] ev, o[10] zero line + fault word, o[11] edge operand image, o[12..14] fold scratch
   const size_t hi = (size_t)N * 4 * LH * LW;
   size_t b = 0;
   o[0] = b; b += align_up((size_t)N * LH * LW * Cc * 4);
@@ -240,10 +240,14 @@ static size_t upfused_sizes(int N, int Cc, int Ch, int LH, int LW, size_t* o) {
   o[9] = b; b += align_up((size_t)N * 2 * 2 * LH * Ch * 4);
   o[10] = b; b += 512;
   o[11] = b; b += align_up(drs_upfuse_edge_image_bytes(Cc, Ch));
+  // folded output projection (fuse_w given, shapes the direct kernel takes): the two fp32 contractions the images are packed from
+  o[12] = b; b += align_up((size_t)16 * Ch * 9 * 4);
+  o[13] = b; b += align_up((size_t)32 * (Cc + Ch) * 9 * 4);
+  o[14] = b; b += align_up((size_t)32 * 4);
   return b + 256;
 }
 extern "C" size_t drs_upconv_fused_workspace_bytes(int N, int Cc, int Ch, int LH, int LW) {
-  size_t o[12];
+  size_t o[15];
   return upfused_sizes(N, Cc, Ch, LH, LW, o);
 }
 extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const float* t_w, const float* t_b, const float* v_w,
@@ -258,7 +262,7 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
   DRS_REQUIRE(!fuse_w || (Ch == 32 && fuse_dim >= 1 && fuse_dim <= 4 && fuse_b && !post2 && !y2), DRS_ERR_SHAPE,
               "upconv_fused: the fused projection needs Ch == 32, fuse_dim <= 4 and no second output");
   DRS_REQUIRE((post2 == nullptr) == (y2 == nullptr), DRS_ERR_ARG, "upconv_fused: post2 and y2 come together");
-  size_t o[12];
+  size_t o[15];
   DRS_REQUIRE(workspace_bytes >= upfused_sizes(N, Cc, Ch, LH, LW, o), DRS_ERR_WORKSPACE, "upconv_fused: workspace too small");
   char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const int OH = 2 * LH, OW = 2 * LW;
@@ -266,8 +270,26 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
   DRS_CHECK_HIP(hipMemsetAsync(base + o[10], 0, 512, s));
   if ((rc = drs_launch_nchw_to_sp(h, (float*)(base + o[0]), N, Cc, LH, LW, s))) return rc;
   if ((rc = drs_launch_nchw_to_sp(att, (float*)(base + o[1]), N, Ch, OH, OW, s))) return rc;
-  if ((rc = drs_launch_upfuse_pack(v_w, v_b, t_w, t_b, Cc, Ch, base + o[4], (float*)(base + o[5]), base + o[11], s))) return rc;
-  if ((rc = drs_launch_pack_conv_mfma(v_w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + o[6], (float*)(base + o[7]), Ch,
+  // the projection folded into both launches' weights where the direct kernel takes the att-half (what the plan's stage 2
+  // does: DecStage::ah_proj / uf_proj), else as the matrix-pipe epilogue of the 32-channel layer
+  bool fold = false;
+  TapConv ah = conv_desc((const float*)(base + o[1]), N, OH, OW, Ch, Ch, 0, (const float*)(base + o[6]), nullptr, nullptr, 16, 16, 0, 3, 3, 1, 1);
+  if (fuse_w) {
+    ah.in_sp = 1; ah.zero_line = base + o[10]; ah.proj = 1; ah.fuse_out = y; ah.fuse_dim = fuse_dim;
+    fold = drs_conv3x3_direct_sp_proj_supported(ah, DRS_IMPL_MFMA_BF16X3);
+  }
+  const float *uv_w = v_w, *uv_b = v_b;
+  if (fold) {
+    if ((rc = drs_launch_upfuse_fold_proj(v_w, v_b, fuse_w, fuse_b, fuse_dim, Cc, Ch, (float*)(base + o[13]), (float*)(base + o[14]), s))) return rc;
+    uv_w = (const float*)(base + o[13]); uv_b = (const float*)(base + o[14]);
+    if ((rc = drs_launch_fold_proj(v_w, Cc + Ch, Cc, Ch, Ch, fuse_w, fuse_dim, (float*)(base + o[12]), s))) return rc;
+    if ((rc = drs_launch_pack_conv_mfma((const float*)(base + o[12]), nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + o[6],
+                                        (float*)(base + o[7]), 16, Ch, 9, 0, DRS_IMPL_MFMA_BF16X3, s, 0, 0, 0, 0, 0)))
+      return rc;
+  }
+  if ((rc = drs_launch_upfuse_pack(uv_w, uv_b, t_w, t_b, Cc, Ch, base + o[4], (float*)(base + o[5]), base + o[11], s))) return rc;
+  if (!fold &&
+      (rc = drs_launch_pack_conv_mfma(v_w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + o[6], (float*)(base + o[7]), Ch,
                                       Ch, 9, 0, DRS_IMPL_MFMA_BF16X3, s, 0, 0, 0, 0, fuse_w ? 0 : 1, Cc + Ch, Cc)))
     return rc;
   const float* aux = (const float*)(base + o[5]);
@@ -286,11 +308,15 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
     TapConv d = conv_desc((const float*)(base + o[1]), N, OH, OW, Ch, Ch, 0, (const float*)(base + o[6]), (const float*)(base + o[7]),
                           (float*)(base + o[2]), Ch, Ch, 0, 3, 3, 1, 1);
     d.in_sp = d.out_sp = 1; d.zero_line = base + o[10]; d.fault = fault;
+    if (fold) {
+      if ((rc = drs_launch_conv3x3_direct_sp(ah, s))) return rc;
+    } else {
     if (fuse_w) {  // projected att-half straight into y (the plan's stage 2)
       d.out = nullptr; d.out_sp = 0;
       d.fuse_w = fuse_w; d.fuse_b = (const float*)(base + o[7]); d.fuse_out = y; d.fuse_dim = fuse_dim;
     }
     if ((rc = drs_launch_tapconv_mfma(d, DRS_IMPL_MFMA_BF16X3, s))) return rc;
+    }
   }
   {
     UpFuseDesc u = {};
@@ -303,7 +329,9 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
     u.zero_line = base + o[10]; u.fault = fault;
     if (fuse_w) {
       u.res = nullptr; u.fuse_acc = 1;
-      u.fuse_w = fuse_w; u.fuse_b = fuse_b; u.fuse_out = y; u.fuse_dim = fuse_dim;
+      if (fold) u.proj = 1;
+      else { u.fuse_w = fuse_w; u.fuse_b = fuse_b; }
+      u.fuse_out = y; u.fuse_dim = fuse_dim;
     } else {
       u.out = (float*)(base + o[3]); u.out_cs = Ch; u.out_co = 0;
       if (y2) { u.out2 = (float*)(base + o[1]); u.out2_cs = Ch; u.out2_co = 0; u.post2 = post2; u.post2_cs = Ch; }  // (att is consumed by now)

@@ -108,6 +108,7 @@ UPFUSE_CASES = [
     (2, 256, 128, 32, 32),   # stage-0 shape: 2 x 2 tiles, 4 channel groups, 8 K-chunks
     (1, 64, 32, 48, 48),     # 3 x 3 tiles: an interior tile (fast window path)
     (3, 32, 32, 9, 17),      # smallest supported heights, odd sizes
+    (2, 64, 32, 32, 40),     # 64 output rows: with a projection, the folded form of both launches (as is (1, 64, 32, 48, 48)); ragged tiles in x
 ]
 TOL_UPFUSE = 1e-4  # measured ~1e-5 (16-bit operand mantissas, fp32 accumulation, fp32 edge vectors)
 
