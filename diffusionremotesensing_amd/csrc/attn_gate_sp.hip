@@ -19,7 +19,9 @@
 
 namespace {
 
-template <int NT>  // Ch = 16 * NT output channels everywhere: NT = 2 (Ch = 32), 4 (Ch = 64)
+// PSI_ONLY: stop at psi (written to psi_out): the consumer of `att` multiplies by psi itself (the top decoder stage, whose
+// att-half convolution has the `result` convolution and the output projection folded into its weights: conv3x3_proj_sp_kernel)
+template <int NT, bool PSI_ONLY = false>  // Ch = 16 * NT output channels everywhere: NT = 2 (Ch = 32), 4 (Ch = 64)
 __global__ __launch_bounds__(NT == 2 ? 1024 : 512, 1) void attn_gate_sp_kernel(AttnGateDesc d) {
   // (a 32-channel stage needs 92 registers: 16 waves per CU instead of 8 - the kernel is a chain of memory round trips per
   // item and wave, with nothing but the other waves of the CU to fill them.  The 64-channel stage fits 168 registers, i.e.
@@ -56,13 +58,13 @@ __global__ __launch_bounds__(NT == 2 ? 1024 : 512, 1) void attn_gate_sp_kernel(A
     copy(sGate, d.w_gate, 2 * gate_img);
     copy(sWg, d.w_wg, 2 * wg_img);
     copy(sWx, d.w_wx, 2 * wx_img);
-    copy(sRes, d.w_res, 2 * wg_img);
+    if constexpr (!PSI_ONLY) copy(sRes, d.w_res, 2 * wg_img);
     // bias vectors: a global load inside an item is a memory round trip on the wave's critical path (five of them per item)
     for (int i = tid; i < Ch; i += THREADS) {
       sB[i] = d.b_gate[i];
       sB[Ch + i] = d.b_wg[i] + d.b_wx[i];
       sB[2 * Ch + i] = d.w_psi[i];
-      sB[3 * Ch + i] = d.b_res[i];
+      sB[3 * Ch + i] = PSI_ONLY ? 0.f : d.b_res[i];
     }
     if (tid == 0) sB[4 * Ch] = d.b_psi[0];
   }
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(NT == 2 ? 1024 : 512, 1) void attn_gate_sp_kernel(A
     const float psi = 1.f / (1.f + expf(-(dot + sB[4 * Ch])));
     if (d.psi_out && valid && kg == 0) d.psi_out[((size_t)n * d.LH + y) * d.LW + px] = psi;
     // ---- att = psi * (W' x_res) + b' for the 4 pixels, stored as SP halves into the concat slice ----
+    if constexpr (!PSI_ONLY)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -444,9 +447,9 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide2_kernel(AttnGateDesc d)
   }
 }
 
-template <int NT>
+template <int NT, bool PSI_ONLY = false>
 int attn_launch(const AttnGateDesc& d, size_t lds, hipStream_t s) {
-  auto kern = attn_gate_sp_kernel<NT>;
+  auto kern = attn_gate_sp_kernel<NT, PSI_ONLY>;
   int num_cu = 0;
   {
     const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
@@ -504,7 +507,9 @@ bool drs_attn_gate_supported(int Cc, int Ch) {
 
 int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
   DRS_REQUIRE(drs_attn_gate_supported(d.Cc, d.Ch), DRS_ERR_SHAPE, "attn_gate: Cc=%d Ch=%d", d.Cc, d.Ch);
-  DRS_REQUIRE(d.x && d.xres && d.out && d.w_gate && d.w_wg && d.w_wx && d.w_res && d.w_psi, DRS_ERR_ARG, "attn_gate: null pointer");
+  const bool psi_only = !d.out;  // stop at psi (psi_out): the 32-channel stage only
+  DRS_REQUIRE(d.x && d.xres && (d.out || (d.psi_out && d.Ch == 32)) && d.w_gate && d.w_wg && d.w_wx && (psi_only || d.w_res) && d.w_psi,
+              DRS_ERR_ARG, "attn_gate: null pointer");
   DRS_REQUIRE(!(d.x_cs & 31) && !(d.x_co & 31) && !(d.r_cs & 31) && !(d.r_co & 31) && !(d.out_cs & 31) && !(d.out_co & 31),
               DRS_ERR_SHAPE, "attn_gate: channel strides / offsets must be multiples of 32");
   if ((long long)d.N * d.LH * d.LW == 0) return DRS_OK;
@@ -523,6 +528,7 @@ int drs_launch_attn_gate(const AttnGateDesc& d, hipStream_t s) {
     return DRS_OK;
   }
   const size_t lds = drs_attn_gate_lds_bytes(d.Cc, d.Ch);
+  if (psi_only) return attn_launch<2, true>(d, lds, s);
   return d.Ch == 32 ? attn_launch<2>(d, lds, s) : attn_launch<4>(d, lds, s);
 }
 

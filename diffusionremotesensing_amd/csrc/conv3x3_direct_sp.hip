@@ -40,7 +40,7 @@ __device__ __forceinline__ bf16x8 dpp_shift(const bf16x8& edge, const bf16x8& ow
   return __builtin_bit_cast(bf16x8, o);
 }
 
-template <int NT, bool HAS2, bool DUAL, bool FUSE, bool PROJ = false>
+template <int NT, bool HAS2, bool DUAL, bool FUSE>
 __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, int nck, unsigned w_gimage, unsigned w2_gimage) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
   char* sW = smem;
   char* sW2 = smem + 2 * img;
   float* sBias = reinterpret_cast<float*>(sW2 + 2 * img2);  // [CW] bias (+ bias2)   (fused projection: + fuse_w[4][32] + fuse_b[4])
-  float* sPost = sBias + (FUSE ? 32 + 128 + 4 : PROJ ? 32 : CW);  // [N][Cout] post_add rows, then [N][Cout] post2 rows
-  const int npost = PROJ ? 0 : min(d.N, NPOST);
+  float* sPost = sBias + (FUSE ? 32 + 128 + 4 : CW);        // [N][Cout] post_add rows, then [N][Cout] post2 rows
+  const int npost = min(d.N, NPOST);
   float* sPost2 = sPost + npost * d.Cout;
   {
     auto copy = [&](char* dst, const char* src, int bytes) __attribute__((always_inline)) {  // 8 loads in flight per thread
@@ -93,9 +93,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
       copy(sW2 + img2, w2 + w2_gimage, img2);
     }
     for (int i = tid; i < CW; i += 512) sBias[i] = (d.bias ? d.bias[i] : 0.f) + ((HAS2 && d.bias2) ? d.bias2[i] : 0.f);
-    if constexpr (PROJ) {
-      if (tid < 4) sBias[16 + tid] = d.fuse_b ? d.fuse_b[min(tid, d.fuse_dim - 1)] : 0.f;
-    } else if constexpr (FUSE) {
+    if constexpr (FUSE) {
       for (int i = tid; i < 128; i += 512) sBias[32 + i] = d.fuse_w[min(i >> 5, d.fuse_dim - 1) * d.Cout + (i & 31)];
       if (tid < 4) sBias[160 + tid] = d.fuse_b[min(tid, d.fuse_dim - 1)];
     } else {
@@ -296,16 +294,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
         TapConv de = d;
         de.relu_pre = 0;
         tile_epilogue_sp_pre<RB, false>(de, comb, kc, n, 0, yb, x0, 0, lr, kg);
-      } else if constexpr (PROJ) {
-        // folded projection: MFMA row 4 j = output j, i.e. register 0 of the lanes of k-group j; one store instruction per row
-        // writes all fuse_dim planes (16 consecutive pixels each)
-        const size_t plane = (size_t)d.OH * d.OW;
-        const float fbk = sBias[16 + kg];
-        if (kg < d.fuse_dim) {
-          float* o = d.fuse_out + ((size_t)n * d.fuse_dim + kg) * plane + (size_t)yb * d.OW + x0 + lr;
-#pragma unroll
-          for (int r = 0; r < RB; ++r) o[(size_t)r * d.OW] = acc[r][0][0] + fbk;
-        }
       } else if constexpr (FUSE) {
         FuseEpiConst kc;
         kc.b0 = *reinterpret_cast<const float4*>(sBias + kg * 4);
@@ -336,16 +324,129 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
   }
 }
 
+// ---- folded projection, taps in the M dimension -------------------------------------------------------------------------
+// output o up_convs.2[att half] is a 3x3 convolution Cin -> fuse_dim <= 4 (TapConv::proj).  With so few outputs the 16 rows of
+// an MFMA tile hold the THREE KERNEL ROWS at once: row 4 ky + o = W[ky][kx][o][:], one tile per kernel column kx.  An input row
+// is then multiplied ONCE (three column-shifted fragments x one tile = 9 MFMAs, against 27 when every output row multiplies
+// its three input rows): T_wr[4 ky + o][p] = what input row wr gives to output row wr - ky, and an output row is the sum of
+// three lane groups of three consecutive T's (k-group ky of T_{y + ky}): twelve lane reads per row.  A wave owns 16 x RB
+// output pixels; weights (6 KB per 32-channel chunk) stay in LDS; no prefetch pipeline - three waves per SIMD cover the loads.
+template <bool GATE>
+__global__ __launch_bounds__(256, GATE ? 2 : 3) void conv3x3_proj_sp_kernel(TapConv d, int nck, unsigned w_gimage) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using P = PolicyBF16X3;
+  using Frag = typename P::Frag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kg = lane >> 4;
+  const int img = nck * 3 * 4 * 16 * 16;  // one operand image: [chunk][kx][k-group][16 rows] slots
+  char* sW = smem;
+  float* sFb = reinterpret_cast<float*>(smem + 2 * img);
+  {
+    const char* w = reinterpret_cast<const char*>(d.w);
+    for (int o = tid * 16; o < img; o += 256 * 16) {
+      *reinterpret_cast<u32x4*>(sW + o) = *reinterpret_cast<const u32x4*>(w + o);
+      *reinterpret_cast<u32x4*>(sW + img + o) = *reinterpret_cast<const u32x4*>(w + w_gimage + o);
+    }
+    if (tid < 4) sFb[tid] = d.fuse_b ? d.fuse_b[min(tid, d.fuse_dim - 1)] : 0.f;
+    if (GATE && tid < 36) sFb[4 + tid] = d.bias ? d.bias[tid] : 0.f;
+  }
+  const float* sTab = sFb + 4;
+  (void)sTab;
+  __syncthreads();
+  const int gx = d.W >> 4, gy = d.H / RB;
+  const int total = d.N * gy * gx;
+  const int xcd = blockIdx.x & 7, member = blockIdx.x >> 3, members = gridDim.x >> 3;
+  const int t_lo = (int)((long long)total * xcd / 8), t_hi = (int)((long long)total * (xcd + 1) / 8);
+  const int stride = members * 4, first = member * 4 + wave;
+  const int half = drs_sp_group_bytes(d.in_cs), pixb = d.in_cs * 4;
+  const char* zero = reinterpret_cast<const char*>(d.zero_line) + kg * 16;
+  const char* wlane = sW + ((size_t)kg * 16 + lr) * 16;
+  const size_t plane = (size_t)d.OH * d.OW;
+  const float fbk = sFb[kg];
+  for (int q0 = t_lo + first; q0 < t_hi; q0 += stride) {
+    int q = q0;
+    const int x0 = (q % gx) * 16; q /= gx;
+    const int yb = (q % gy) * RB;
+    const int n = q / gy;
+    f32x4 T[RB + 2][GATE ? 3 : 1];
+#pragma unroll
+    for (int wr = 0; wr < RB + 2; ++wr)
+#pragma unroll
+      for (int j = 0; j < (GATE ? 3 : 1); ++j) T[wr][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nck; ++c) {
+      RowOp R[RB + 2];
+#pragma unroll
+      for (int wr = 0; wr < RB + 2; ++wr) {
+        const int iy = yb - 1 + wr;
+        const bool ok = iy >= 0 && iy < d.H;
+        const char* base = reinterpret_cast<const char*>(d.in) +
+                           ((((long long)n * d.H + iy) * d.W + x0 + lr) * d.in_cs + d.in_co) * 4 + c * 128 + kg * 16;
+        const char* p = ok ? base : zero;
+        R[wr].c = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + half : zero)};
+        if (lr == 0 || lr == 15) {
+          const int ex = lr == 0 ? x0 - 1 : x0 + 16;
+          const bool eok = ok && ex >= 0 && ex < d.W;
+          const char* pe = eok ? (lr == 0 ? base - pixb : base + pixb) : zero;
+          R[wr].e = Frag{*reinterpret_cast<const bf16x8*>(pe), *reinterpret_cast<const bf16x8*>(eok ? pe + half : zero)};
+        }
+      }
+      Frag wf[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) wf[kx] = P::load(wlane, (size_t)img, (size_t)((c * 3 + kx) * 4 * 16) * 16);
+#pragma unroll
+      for (int wr = 0; wr < RB + 2; ++wr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const Frag a = kx == 1 ? R[wr].c
+                                 : Frag{dpp_shift(R[wr].e.hi, R[wr].c.hi, kx == 0), dpp_shift(R[wr].e.lo, R[wr].c.lo, kx == 0)};
+          T[wr][GATE ? kx : 0] = P::mma(wf[kx], a, T[wr][GATE ? kx : 0]);
+        }
+    }
+    f32x4 t[RB + 2];
+    if constexpr (GATE) {
+      // the attention gate: input pixel (iy, ix) was multiplied by psi[n][iy / 2][ix / 2] (reference :105-106, nearest 2x); the map is
+      // linear, so the factor goes onto the 4 accumulators of the pixel's column instead of its 32 channels
+      const float* ps = d.gate + (size_t)n * (d.H >> 1) * (d.W >> 1);
+#pragma unroll
+      for (int wr = 0; wr < RB + 2; ++wr) {
+        const int iy = min(max(yb - 1 + wr, 0), d.H - 1);
+        const float* pr = ps + (size_t)(iy >> 1) * (d.W >> 1);
+        const float s0 = pr[max(x0 + lr - 1, 0) >> 1], s1 = pr[(x0 + lr) >> 1], s2 = pr[min(x0 + lr + 1, d.W - 1) >> 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[wr][j] = s0 * T[wr][0][j] + s1 * T[wr][1][j] + s2 * T[wr][GATE ? 2 : 0][j];
+      }
+    } else {
+#pragma unroll
+      for (int wr = 0; wr < RB + 2; ++wr) t[wr] = T[wr][0];
+    }
+    float* o = d.fuse_out + ((size_t)n * d.fuse_dim + min(kg, d.fuse_dim - 1)) * plane + (size_t)yb * d.OW + x0 + lr;
+#pragma unroll
+    for (int y = 0; y < RB; ++y) {
+      float sv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        sv[j] = __shfl(t[y][j], lr, 64) + __shfl(t[y + 1][j], lr + 16, 64) + __shfl(t[y + 2][j], lr + 32, 64);
+      float v = kg == 0 ? sv[0] : kg == 1 ? sv[1] : kg == 2 ? sv[2] : sv[3];
+      if constexpr (GATE) {  // the folded `result` bias: a constant per (row class, column class) of the output pixel
+        const int oy = yb + y, ox = x0 + lr;
+        const int rc = oy == 0 ? 0 : (oy == d.H - 1 ? 2 : 1), cc = ox == 0 ? 0 : (ox == d.W - 1 ? 2 : 1);
+        v += sTab[(rc * 3 + cc) * 4 + kg];
+      }
+      if (kg < d.fuse_dim) o[(size_t)y * d.OW] = v + fbk;
+    }
+  }
+}
+
 size_t direct_lds_bytes(const TapConv& d) {
   const int nck = (d.Cin + 31) / 32, CW = d.dual ? 2 * d.Cout : d.Cout;
   size_t b = (d.dual ? (size_t)2 * 5 * 4 * CW * 16 : (size_t)2 * nck * 36 * CW * 16) + (d.in2 ? (size_t)2 * 4 * CW * 16 : 0);
-  b += d.proj ? 32 * 4 : d.fuse_out ? (32 + 128 + 4) * 4 : (size_t)(CW + 2 * (d.N < NPOST ? d.N : NPOST) * d.Cout) * 4;
+  b += d.fuse_out ? (32 + 128 + 4) * 4 : (size_t)(CW + 2 * (d.N < NPOST ? d.N : NPOST) * d.Cout) * 4;
   return b;
 }
 
-template <int NT, bool HAS2, bool DUAL, bool FUSE, bool PROJ = false>
+template <int NT, bool HAS2, bool DUAL, bool FUSE>
 int direct_launch(const TapConv& d, hipStream_t s) {
-  auto kern = conv3x3_direct_sp_kernel<NT, HAS2, DUAL, FUSE, PROJ>;
+  auto kern = conv3x3_direct_sp_kernel<NT, HAS2, DUAL, FUSE>;
   int num_cu = 0;
   {
     const int rc = drs_kernel_prepare(reinterpret_cast<const void*>(kern), 160 * 1024, &num_cu);
@@ -367,40 +468,85 @@ bool std3x3(const TapConv& d) {
   return true;
 }
 
-// W''[4 j][ci][tap] = sum_co fw[j][co] * w[co][cin_off + ci][tap]: the 1x1 projection behind a bare 3x3 convolution folded into
-// its weights (fp32 contraction at pack time, the same class of re-association as the BatchNorm fold and the composite stage)
+// W'[4 ky + o][ci][kx] = sum_co fw[o][co] * w[co][cin_off + ci][ky * 3 + kx]: the 1x1 projection behind a bare 3x3 convolution
+// folded into its weights (fp32 contraction at pack time, the same class of re-association as the BatchNorm fold and the
+// composite stage), in the row order of conv3x3_proj_sp_kernel: a 16-row, 3-"tap" (kernel column) layer for the pack kernel
 __global__ __launch_bounds__(256) void fold_proj_kernel(const float* __restrict__ w, int cin_total, int cin_off, int Cmid, int Cin,
                                                         const float* __restrict__ fw, int fuse_dim, float* __restrict__ dst) {
-  const int total = 16 * Cin * 9;
+  const int total = 16 * Cin * 3;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int row = i / (Cin * 9), rem = i - row * Cin * 9, ci = rem / 9, tap = rem - ci * 9;
-    const int j = row >> 2;
+    const int row = i / (Cin * 3), rem = i - row * Cin * 3, ci = rem / 3, kx = rem - ci * 3;
+    const int ky = row >> 2, o = row & 3;
     float a = 0.f;
-    if ((row & 3) == 0 && j < fuse_dim)
-      for (int co = 0; co < Cmid; ++co) a += fw[(size_t)j * Cmid + co] * w[((size_t)co * cin_total + cin_off + ci) * 9 + tap];
+    if (ky < 3 && o < fuse_dim)
+      for (int co = 0; co < Cmid; ++co) a += fw[(size_t)o * Cmid + co] * w[((size_t)co * cin_total + cin_off + ci) * 9 + ky * 3 + kx];
     dst[i] = a;
+  }
+}
+
+// The gated form: the attention block's `result` convolution (1x1, BatchNorm folded: reference :84-87,107) sits between the gate
+// and the att-half and is linear too: att = psi * (Wr' x) + br', so output o up_convs.2[att] o result is ONE 3x3 convolution of
+// psi * x.  dst2[row][ci][kx] = sum_m dst1[row][m][kx] * Wr'[m][ci] (dst1: fold_proj_kernel's rows); the constant br' reaches an
+// output pixel through the taps that stay inside the image only: tab[row class 3][column class 3][4] (first / interior / last).
+__global__ __launch_bounds__(256) void fold_result_kernel(const float* __restrict__ dst1, int C, const float* __restrict__ wr,
+                                                          const float* __restrict__ br, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                          const float* __restrict__ rvar, float eps, float* __restrict__ dst2,
+                                                          float* __restrict__ tab) {
+  const int total = 16 * C * 3;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int row = i / (C * 3), rem = i - row * C * 3, ci = rem / 3, kx = rem - ci * 3;
+    float a = 0.f;
+    for (int m = 0; m < C; ++m) {
+      const float sc = gamma[m] / sqrtf(rvar[m] + eps);
+      a += dst1[((size_t)row * C + m) * 3 + kx] * (sc * wr[(size_t)m * C + ci]);
+    }
+    dst2[i] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 36) {
+    const int o = threadIdx.x & 3, cc = (threadIdx.x >> 2) % 3, rc = threadIdx.x / 12;
+    float a = 0.f;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        if ((rc == 0 && ky == 0) || (rc == 2 && ky == 2) || (cc == 0 && kx == 0) || (cc == 2 && kx == 2)) continue;
+        for (int m = 0; m < C; ++m) {
+          const float sc = gamma[m] / sqrtf(rvar[m] + eps);
+          const float bm = ((br ? br[m] : 0.f) - rmean[m]) * sc + beta[m];
+          a += dst1[((size_t)(4 * ky + o) * C + m) * 3 + kx] * bm;
+        }
+      }
+    tab[threadIdx.x] = a;
   }
 }
 
 }  // namespace
 
-int drs_launch_fold_proj(const float* w, int cin_total, int cin_off, int Cmid, int Cin, const float* fw, int fuse_dim, float* dst,
-                         hipStream_t s) {
-  DRS_REQUIRE(w && fw && dst && fuse_dim >= 1 && fuse_dim <= 4 && Cin > 0 && Cmid > 0, DRS_ERR_ARG, "fold_proj: bad arguments");
-  DRS_LAUNCH(fold_proj_kernel, dim3((16 * Cin * 9 + 255) / 256), dim3(256), 0, s, w, cin_total, cin_off, Cmid, Cin, fw, fuse_dim, dst);
+int drs_launch_fold_result(const float* dst1, int C, const float* wr, const float* br, const float* gamma, const float* beta,
+                           const float* rmean, const float* rvar, float eps, float* dst2, float* tab, hipStream_t s) {
+  DRS_REQUIRE(dst1 && wr && gamma && beta && rmean && rvar && dst2 && tab && C > 0, DRS_ERR_ARG, "fold_result: bad arguments");
+  DRS_LAUNCH(fold_result_kernel, dim3((16 * C * 3 + 255) / 256), dim3(256), 0, s, dst1, C, wr, br, gamma, beta, rmean, rvar, eps, dst2, tab);
   DRS_CHECK_HIP(hipGetLastError());
   return DRS_OK;
 }
 
-// The folded-projection flavour (TapConv::proj): 16-row weight image, one channel tile per wave, planar fp32 output.
+int drs_launch_fold_proj(const float* w, int cin_total, int cin_off, int Cmid, int Cin, const float* fw, int fuse_dim, float* dst,
+                         hipStream_t s) {
+  DRS_REQUIRE(w && fw && dst && fuse_dim >= 1 && fuse_dim <= 4 && Cin > 0 && Cmid > 0, DRS_ERR_ARG, "fold_proj: bad arguments");
+  DRS_LAUNCH(fold_proj_kernel, dim3((16 * Cin * 3 + 255) / 256), dim3(256), 0, s, w, cin_total, cin_off, Cmid, Cin, fw, fuse_dim, dst);
+  DRS_CHECK_HIP(hipGetLastError());
+  return DRS_OK;
+}
+
+// The folded-projection kernel (TapConv::proj; conv3x3_proj_sp_kernel): 16-row x 3-column weight image, planar fp32 output.
 bool drs_conv3x3_direct_sp_proj_supported(const TapConv& d, int impl) {
   static const bool env = !(getenv("DRS_FOLD_PROJ") && atoi(getenv("DRS_FOLD_PROJ")) == 0);
   if (!env || impl != DRS_IMPL_MFMA_BF16X3 || !d.proj) return false;
   if (!d.in || !d.in_sp || !d.zero_line || !std3x3(d) || !d.fuse_out || d.fuse_dim < 1 || d.fuse_dim > 4 || d.Cout != 16) return false;
-  if (d.out || d.out2 || d.in2 || d.dual || d.gate || d.in_add || d.res || d.post_add || d.relu_pre || d.relu_post || d.sigmoid) return false;
+  if (d.out || d.out2 || d.in2 || d.dual || d.in_add || d.res || d.post_add || d.relu_pre || d.relu_post || d.sigmoid) return false;
   if ((d.in_co & 31) || (d.in_cs & 31) || d.Cin % 32 != 0) return false;
   if ((d.W & 15) || (d.H % RB) || d.H < 64 || d.TH != d.H || d.TW != d.W || d.OH != d.H || d.OW != d.W) return false;
-  return direct_lds_bytes(d) <= 156 * 1024;
+  if (d.gate && ((d.H | d.W) & 1)) return false;
+  return (size_t)2 * (d.Cin / 32) * 3 * 4 * 16 * 16 + 256 <= 64 * 1024;
 }
 
 // Eligibility (shape only, never the batch size: a forward must not change its arithmetic with the batch): what
@@ -426,7 +572,24 @@ bool drs_conv3x3_direct_sp_supported(const TapConv& d, int impl) {
 int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s) {
   if (d.proj) {
     DRS_REQUIRE(drs_conv3x3_direct_sp_proj_supported(d, DRS_IMPL_MFMA_BF16X3), DRS_ERR_SHAPE, "conv3x3_direct_sp: unsupported folded-projection layer");
-    return direct_launch<1, false, false, false, true>(d, s);
+    int num_cu = 0;
+    const int nck = d.Cin / 32;
+    const unsigned w_gimage = (unsigned)((size_t)nck * 3 * 4 * 16 * 16);
+    const size_t lds = (size_t)2 * w_gimage + 256;
+    const void* kern = d.gate ? reinterpret_cast<const void*>(conv3x3_proj_sp_kernel<true>)
+                              : reinterpret_cast<const void*>(conv3x3_proj_sp_kernel<false>);
+    {
+      const int rc = drs_kernel_prepare(kern, 0, &num_cu);
+      if (rc) return rc;
+    }
+    const long long strips = (long long)d.N * (d.H / RB) * (d.W >> 4);
+    long long blocks = (long long)num_cu * (d.gate ? 2 : 3);
+    if (blocks * 4 > strips) blocks = (strips + 3) / 4;
+    blocks = (blocks + 7) / 8 * 8;
+    if (d.gate) DRS_LAUNCH(conv3x3_proj_sp_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, d, nck, w_gimage);
+    else DRS_LAUNCH(conv3x3_proj_sp_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, d, nck, w_gimage);
+    DRS_CHECK_HIP(hipGetLastError());
+    return DRS_OK;
   }
   if (d.dual) return direct_launch<4, false, true, false>(d, s);
   if (d.fuse_out) return direct_launch<2, false, false, true>(d, s);

@@ -61,8 +61,9 @@ struct TapConv {
   float* fuse_out;
   int fuse_dim;
   // proj = 1: the projection is FOLDED INTO THE WEIGHTS (both maps are linear and nothing sits between them): `w` is a
-  // 16-row operand image whose MFMA row 4 j carries output j < fuse_dim (drs_launch_fold_proj), Cout == 16, fuse_w unused:
-  //   fuse_out[n][j][oy][ox] = acc[row 4 j] (+ fuse_b[j] if set).  conv3x3_direct_sp.hip only.
+  // 16-row x 3-column operand image (drs_launch_fold_proj: row 4 ky + o), Cout == 16, fuse_w unused:
+  //   fuse_out[n][o][oy][ox] = the convolution (+ fuse_b[o] if set).  conv3x3_proj_sp_kernel (conv3x3_direct_sp.hip) only.
+  //   With `gate` set the input is taken as in * nearest2x(gate) (the attention gate's psi: reference :105-106).
   int proj;
   // launch hint: this op runs next to another one on a second stream: one block per CU (80 KB of LDS each, so a block of
   // either kernel fits on every CU at the same time) and no 512-thread variant; 2 = two blocks per CU for the small-LDS
@@ -282,10 +283,15 @@ bool drs_tapconv_sp_supported(const TapConv& d, int impl);
 // 3x3 stride 1 for the shallow layers (conv3x3_direct_sp.hip); with TapConv::proj the folded-projection flavour
 int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s);
 // weights of a 3x3 convolution (Cmid outputs; input channels [cin_off, cin_off + Cin) of cin_total) followed by a 1x1
-// projection fw[fuse_dim][Cmid], as ONE 3x3 convolution: dst[16][Cin][9] fp32, row 4 j = output j, other rows zero
+// projection fw[fuse_dim][Cmid], as ONE 3x3 convolution: dst[16][Cin][3] fp32, row 4 ky + o = kernel row ky of output o, the
+// three kernel columns as the "taps" of a 16-channel layer (conv3x3_proj_sp_kernel)
 int drs_launch_fold_proj(const float* w, int cin_total, int cin_off, int Cmid, int Cin, const float* fw, int fuse_dim, float* dst,
                          hipStream_t s);
 bool drs_conv3x3_direct_sp_proj_supported(const TapConv& d, int impl);
+// ... composed with the attention block's `result` convolution in front of it (1x1, C -> C, BatchNorm folded): dst2 in dst1's
+// layout, tab[3][3][4] = what the constant part of `result` gives an output pixel of each (row, column) border class
+int drs_launch_fold_result(const float* dst1, int C, const float* wr, const float* br, const float* gamma, const float* beta,
+                           const float* rmean, const float* rvar, float eps, float* dst2, float* tab, hipStream_t s);
   // wave-specialised SP-format 3x3 kernel (conv_mfma_sp.hip) takes this op
 
 // planar (NCHW) small-channel kernels

@@ -284,7 +284,7 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
     uv_w = (const float*)(base + o[13]); uv_b = (const float*)(base + o[14]);
     if ((rc = drs_launch_fold_proj(v_w, Cc + Ch, Cc, Ch, Ch, fuse_w, fuse_dim, (float*)(base + o[12]), s))) return rc;
     if ((rc = drs_launch_pack_conv_mfma((const float*)(base + o[12]), nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + o[6],
-                                        (float*)(base + o[7]), 16, Ch, 9, 0, DRS_IMPL_MFMA_BF16X3, s, 0, 0, 0, 0, 0)))
+                                        (float*)(base + o[7]), 16, Ch, 3, 0, DRS_IMPL_MFMA_BF16X3, s, 0, 0, 0, 0, 0)))
       return rc;
   }
   if ((rc = drs_launch_upfuse_pack(uv_w, uv_b, t_w, t_b, Cc, Ch, base + o[4], (float*)(base + o[5]), base + o[11], s))) return rc;
@@ -404,6 +404,10 @@ struct DecStage {
   // ... and into the composite's (UpFuseDesc::proj): the folded up_convs.2 x-half the composite is packed from
   bool uf_proj = false;
   size_t uf_tmpw_off = 0, uf_tmpb_off = 0;
+  // ... and the attention block's `result` convolution folded in as well: the gate stops at psi (attn_gate_sp.hip, PSI_ONLY), the
+  // att-half reads the skip tensor and multiplies by psi behind its MFMAs: `att` of the top stage never exists
+  bool gate_psi = false;
+  size_t ah_tmp2_off = 0, ah_tab_off = 0;
   int t_PA = -1;                  // att-half partial sums (SP), B x Ch x 2lh x 2lw
   size_t o_eh = 0, o_ev = 0;      // workspace: edge vectors of this forward
 };
@@ -692,6 +696,12 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
         if (d.ah_proj) { d.ah_tmp_off = cur; cur += align_up((size_t)16 * Ch * 9 * 4); }
         // the composite's folded form needs the att-half in the output tensor first (fuse_acc): both or neither
         d.uf_proj = d.ah_proj;
+        static const bool gp_env = !(getenv("DRS_GATE_PSI") && atoi(getenv("DRS_GATE_PSI")) == 0);
+        d.gate_psi = gp_env && d.ah_proj && d.fused_gate && Ch == 32 && !(cfg->flags & DRS_PLAN_KEEP_ALL) && !(cfg->height & 1) && !(cfg->width & 1);
+        if (d.gate_psi) {
+          d.ah_tmp2_off = cur; cur += align_up((size_t)16 * Ch * 3 * 4);
+          d.ah_tab_off = cur; cur += align_up((size_t)36 * 4);
+        }
         if (d.uf_proj) {
           d.uf_tmpw_off = cur; cur += align_up((size_t)32 * (Cc + Ch) * 9 * 4);
           d.uf_tmpb_off = cur; cur += align_up((size_t)32 * 4);
@@ -947,8 +957,16 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
     if (d.ah_proj) {
       float* tmp = (float*)(base + d.ah_tmp_off);
       if ((rc = drs_launch_fold_proj(F(d.upconv.w), Cc + Ch, Cc, Ch, Ch, F(plan->output.w), plan->cfg.out_dim, tmp, s))) return rc;
+      if (d.gate_psi) {  // ... o attention_blocks.2.result (1x1 + BatchNorm, linear): the convolution then reads psi * x_res
+        float* tmp2 = (float*)(base + d.ah_tmp2_off);
+        const ConvLayer& R = d.result;
+        if ((rc = drs_launch_fold_result(tmp, Ch, F(R.w), F(R.b), F(R.bn), F(R.bn + 1), F(R.bn + 2), F(R.bn + 3), plan->cfg.bn_eps, tmp2,
+                                         (float*)(base + d.ah_tab_off), s)))
+          return rc;
+        tmp = tmp2;
+      }
       if ((rc = drs_launch_pack_conv_mfma(tmp, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + d.ah_w_off,
-                                          (float*)(base + d.ah_b_off), 16, Ch, 9, 0, impl, s, 0, 0, 0, 0, 0)))
+                                          (float*)(base + d.ah_b_off), 16, Ch, 3, 0, impl, s, 0, 0, 0, 0, 0)))
         return rc;
       continue;
     }
@@ -1349,6 +1367,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
       a.xres = xres; a.r_cs = Ch; a.r_co = 0;
       a.out = cat; a.out_cs = Cc + Ch; a.out_co = Cc;
       a.psi_out = nullptr;
+      if (st.gate_psi) { a.out = nullptr; a.psi_out = TP(plan->t_PSI[i]); }  // (the att-half multiplies by psi itself: below)
       a.N = B; a.LH = lh; a.LW = lw; a.Cc = Cc; a.Ch = Ch;
       a.w_gate = PW(st.gate); a.b_gate = PB(st.gate);
       a.w_wg = pk + st.fz_wg_off; a.b_wg = PB(st.wg);
@@ -1472,6 +1491,11 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
           d.out = nullptr; d.out_sp = 0; d.bias = nullptr;
           d.Cout = 16; d.out_cs = 16;
           d.proj = 1;
+          if (st.gate_psi) {  // `result` folded in: the input is the skip tensor, gated by psi inside the kernel
+            d.in = xres; d.in_cs = Ch; d.in_co = 0;
+            d.gate = TP(plan->t_PSI[i]);
+            d.bias = (const float*)(pk + st.ah_tab_off);
+          }
           d.fuse_out = out; d.fuse_dim = c.out_dim; d.fuse_b = nullptr;
           prof_begin(plan, "up_convs.2.att", ah_flops, ah_bytes, s);
           rc = drs_launch_conv3x3_direct_sp(d, s);
