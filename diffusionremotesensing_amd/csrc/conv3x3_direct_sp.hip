@@ -329,16 +329,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
 // an MFMA tile hold the THREE KERNEL ROWS at once: row 4 ky + o = W[ky][kx][o][:], one tile per kernel column kx.  An input row
 // is then multiplied ONCE (three column-shifted fragments x one tile = 9 MFMAs, against 27 when every output row multiplies
 // its three input rows): T_wr[4 ky + o][p] = what input row wr gives to output row wr - ky, and an output row is the sum of
-// three lane groups of three consecutive T's (k-group ky of T_{y + ky}): twelve lane reads per row.  A wave owns 16 x RB
-// output pixels; weights (6 KB per 32-channel chunk) stay in LDS; no prefetch pipeline - three waves per SIMD cover the loads.
+// three lane groups of three consecutive T's (k-group ky of T_{y + ky}): twelve lane reads per row.  A wave owns 16 x RBP
+// output pixels and streams their RBP + 2 input rows through a short register ring; weights (6 KB, Cin == 32) stay in LDS /
+// registers; three waves per SIMD.
+constexpr int RBP = 8;  // output rows per strip of the projection kernel
 template <bool GATE>
-__global__ __launch_bounds__(256, GATE ? 2 : 3) void conv3x3_proj_sp_kernel(TapConv d, int nck, unsigned w_gimage) {
+__global__ __launch_bounds__(256, GATE ? 2 : 3) void conv3x3_proj_sp_kernel(TapConv d, unsigned w_gimage) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   using Frag = typename P::Frag;
+  constexpr int NR = RBP + 2, PF = 3;  // input rows of a strip; rows in flight ahead of the one being multiplied
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, kg = lane >> 4;
-  const int img = nck * 3 * 4 * 16 * 16;  // one operand image: [chunk][kx][k-group][16 rows] slots
+  const int img = 3 * 4 * 16 * 16;  // one operand image (Cin == 32: one K-chunk): [kx][k-group][16 rows] slots
   char* sW = smem;
   float* sFb = reinterpret_cast<float*>(smem + 2 * img);
   {
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256, GATE ? 2 : 3) void conv3x3_proj_sp_kernel(TapC
   const float* sTab = sFb + 4;
   (void)sTab;
   __syncthreads();
-  const int gx = d.W >> 4, gy = d.H / RB;
+  const int gx = d.W >> 4, gy = d.H / RBP;
   const int total = d.N * gy * gx;
   const int xcd = blockIdx.x & 7, member = blockIdx.x >> 3, members = gridDim.x >> 3;
   const int t_lo = (int)((long long)total * xcd / 8), t_hi = (int)((long long)total * (xcd + 1) / 8);
@@ -363,65 +366,68 @@ __global__ __launch_bounds__(256, GATE ? 2 : 3) void conv3x3_proj_sp_kernel(TapC
   const char* wlane = sW + ((size_t)kg * 16 + lr) * 16;
   const size_t plane = (size_t)d.OH * d.OW;
   const float fbk = sFb[kg];
+  Frag wf[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) wf[kx] = P::load(wlane, (size_t)img, (size_t)(kx * 4 * 16) * 16);
   for (int q0 = t_lo + first; q0 < t_hi; q0 += stride) {
     int q = q0;
     const int x0 = (q % gx) * 16; q /= gx;
-    const int yb = (q % gy) * RB;
+    const int yb = (q % gy) * RBP;
     const int n = q / gy;
-    f32x4 T[RB + 2][GATE ? 3 : 1];
-#pragma unroll
-    for (int wr = 0; wr < RB + 2; ++wr)
-#pragma unroll
-      for (int j = 0; j < (GATE ? 3 : 1); ++j) T[wr][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nck; ++c) {
-      RowOp R[RB + 2];
-#pragma unroll
-      for (int wr = 0; wr < RB + 2; ++wr) {
-        const int iy = yb - 1 + wr;
-        const bool ok = iy >= 0 && iy < d.H;
-        const char* base = reinterpret_cast<const char*>(d.in) +
-                           ((((long long)n * d.H + iy) * d.W + x0 + lr) * d.in_cs + d.in_co) * 4 + c * 128 + kg * 16;
-        const char* p = ok ? base : zero;
-        R[wr].c = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + half : zero)};
-        if (lr == 0 || lr == 15) {
-          const int ex = lr == 0 ? x0 - 1 : x0 + 16;
-          const bool eok = ok && ex >= 0 && ex < d.W;
-          const char* pe = eok ? (lr == 0 ? base - pixb : base + pixb) : zero;
-          R[wr].e = Frag{*reinterpret_cast<const bf16x8*>(pe), *reinterpret_cast<const bf16x8*>(eok ? pe + half : zero)};
-        }
+    // An input row is multiplied ONCE and is dead afterwards: the rows stream through a ring of PF + 1 register sets, PF rows
+    // ahead of the MFMAs (the scheduling barriers keep the compiler from hoisting every load of the strip to its top)
+    RowOp R[PF + 1];
+    float psv[PF + 1][3];
+    auto load_row = [&](int slot, int wr) __attribute__((always_inline)) {
+      const int iy = yb - 1 + wr;
+      const bool ok = iy >= 0 && iy < d.H;
+      const char* base = reinterpret_cast<const char*>(d.in) +
+                         ((((long long)n * d.H + iy) * d.W + x0 + lr) * d.in_cs + d.in_co) * 4 + kg * 16;
+      const char* p = ok ? base : zero;
+      R[slot].c = Frag{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(ok ? p + half : zero)};
+      if (lr == 0 || lr == 15) {
+        const int ex = lr == 0 ? x0 - 1 : x0 + 16;
+        const bool eok = ok && ex >= 0 && ex < d.W;
+        const char* pe = eok ? (lr == 0 ? base - pixb : base + pixb) : zero;
+        R[slot].e = Frag{*reinterpret_cast<const bf16x8*>(pe), *reinterpret_cast<const bf16x8*>(eok ? pe + half : zero)};
       }
-      Frag wf[3];
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) wf[kx] = P::load(wlane, (size_t)img, (size_t)((c * 3 + kx) * 4 * 16) * 16);
-#pragma unroll
-      for (int wr = 0; wr < RB + 2; ++wr)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const Frag a = kx == 1 ? R[wr].c
-                                 : Frag{dpp_shift(R[wr].e.hi, R[wr].c.hi, kx == 0), dpp_shift(R[wr].e.lo, R[wr].c.lo, kx == 0)};
-          T[wr][GATE ? kx : 0] = P::mma(wf[kx], a, T[wr][GATE ? kx : 0]);
-        }
-    }
-    f32x4 t[RB + 2];
-    if constexpr (GATE) {
-      // the attention gate: input pixel (iy, ix) was multiplied by psi[n][iy / 2][ix / 2] (reference :105-106, nearest 2x); the map is
-      // linear, so the factor goes onto the 4 accumulators of the pixel's column instead of its 32 channels
-      const float* ps = d.gate + (size_t)n * (d.H >> 1) * (d.W >> 1);
-#pragma unroll
-      for (int wr = 0; wr < RB + 2; ++wr) {
-        const int iy = min(max(yb - 1 + wr, 0), d.H - 1);
-        const float* pr = ps + (size_t)(iy >> 1) * (d.W >> 1);
-        const float s0 = pr[max(x0 + lr - 1, 0) >> 1], s1 = pr[(x0 + lr) >> 1], s2 = pr[min(x0 + lr + 1, d.W - 1) >> 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t[wr][j] = s0 * T[wr][0][j] + s1 * T[wr][1][j] + s2 * T[wr][GATE ? 2 : 0][j];
+      if constexpr (GATE) {
+        // the attention gate: input pixel (iy, ix) was multiplied by psi[n][iy / 2][ix / 2] (reference :105-106, nearest 2x); the map
+        // is linear, so the factor goes onto the 4 accumulators of the pixel's kernel column instead of its 32 channels
+        const float* pr = d.gate + ((size_t)n * (d.H >> 1) + (min(max(iy, 0), d.H - 1) >> 1)) * (d.W >> 1);
+        psv[slot][0] = pr[max(x0 + lr - 1, 0) >> 1];
+        psv[slot][1] = pr[(x0 + lr) >> 1];
+        psv[slot][2] = pr[min(x0 + lr + 1, d.W - 1) >> 1];
       }
-    } else {
+    };
+    f32x4 t[NR];
 #pragma unroll
-      for (int wr = 0; wr < RB + 2; ++wr) t[wr] = T[wr][0];
+    for (int i = 0; i < PF; ++i) load_row(i, i);
+#pragma unroll
+    for (int wr = 0; wr < NR; ++wr) {
+      if (wr + PF < NR) load_row((wr + PF) % (PF + 1), wr + PF);
+      __builtin_amdgcn_sched_barrier(0);
+      const RowOp& r = R[wr % (PF + 1)];
+      f32x4 tk[GATE ? 3 : 1];
+#pragma unroll
+      for (int j = 0; j < (GATE ? 3 : 1); ++j) tk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const Frag a = kx == 1 ? r.c : Frag{dpp_shift(r.e.hi, r.c.hi, kx == 0), dpp_shift(r.e.lo, r.c.lo, kx == 0)};
+        tk[GATE ? kx : 0] = P::mma(wf[kx], a, tk[GATE ? kx : 0]);
+      }
+      if constexpr (GATE) {
+        const float* sc = psv[wr % (PF + 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[wr][j] = sc[0] * tk[0][j] + sc[1] * tk[1][j] + sc[2] * tk[GATE ? 2 : 0][j];
+      } else {
+        t[wr] = tk[0];
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     float* o = d.fuse_out + ((size_t)n * d.fuse_dim + min(kg, d.fuse_dim - 1)) * plane + (size_t)yb * d.OW + x0 + lr;
 #pragma unroll
-    for (int y = 0; y < RB; ++y) {
+    for (int y = 0; y < RBP; ++y) {
       float sv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -543,10 +549,10 @@ bool drs_conv3x3_direct_sp_proj_supported(const TapConv& d, int impl) {
   if (!env || impl != DRS_IMPL_MFMA_BF16X3 || !d.proj) return false;
   if (!d.in || !d.in_sp || !d.zero_line || !std3x3(d) || !d.fuse_out || d.fuse_dim < 1 || d.fuse_dim > 4 || d.Cout != 16) return false;
   if (d.out || d.out2 || d.in2 || d.dual || d.in_add || d.res || d.post_add || d.relu_pre || d.relu_post || d.sigmoid) return false;
-  if ((d.in_co & 31) || (d.in_cs & 31) || d.Cin % 32 != 0) return false;
-  if ((d.W & 15) || (d.H % RB) || d.H < 64 || d.TH != d.H || d.TW != d.W || d.OH != d.H || d.OW != d.W) return false;
+  if ((d.in_co & 31) || (d.in_cs & 31) || d.Cin != 32) return false;
+  if ((d.W & 15) || (d.H % RBP) || d.H < 64 || d.TH != d.H || d.TW != d.W || d.OH != d.H || d.OW != d.W) return false;
   if (d.gate && ((d.H | d.W) & 1)) return false;
-  return (size_t)2 * (d.Cin / 32) * 3 * 4 * 16 * 16 + 256 <= 64 * 1024;
+  return true;
 }
 
 // Eligibility (shape only, never the batch size: a forward must not change its arithmetic with the batch): what
@@ -573,8 +579,7 @@ int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s) {
   if (d.proj) {
     DRS_REQUIRE(drs_conv3x3_direct_sp_proj_supported(d, DRS_IMPL_MFMA_BF16X3), DRS_ERR_SHAPE, "conv3x3_direct_sp: unsupported folded-projection layer");
     int num_cu = 0;
-    const int nck = d.Cin / 32;
-    const unsigned w_gimage = (unsigned)((size_t)nck * 3 * 4 * 16 * 16);
+    const unsigned w_gimage = (unsigned)(3 * 4 * 16 * 16);
     const size_t lds = (size_t)2 * w_gimage + 256;
     const void* kern = d.gate ? reinterpret_cast<const void*>(conv3x3_proj_sp_kernel<true>)
                               : reinterpret_cast<const void*>(conv3x3_proj_sp_kernel<false>);
@@ -582,12 +587,12 @@ int drs_launch_conv3x3_direct_sp(const TapConv& d, hipStream_t s) {
       const int rc = drs_kernel_prepare(kern, 0, &num_cu);
       if (rc) return rc;
     }
-    const long long strips = (long long)d.N * (d.H / RB) * (d.W >> 4);
+    const long long strips = (long long)d.N * (d.H / RBP) * (d.W >> 4);
     long long blocks = (long long)num_cu * (d.gate ? 2 : 3);
     if (blocks * 4 > strips) blocks = (strips + 3) / 4;
     blocks = (blocks + 7) / 8 * 8;
-    if (d.gate) DRS_LAUNCH(conv3x3_proj_sp_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, d, nck, w_gimage);
-    else DRS_LAUNCH(conv3x3_proj_sp_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, d, nck, w_gimage);
+    if (d.gate) DRS_LAUNCH(conv3x3_proj_sp_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, d, w_gimage);
+    else DRS_LAUNCH(conv3x3_proj_sp_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, d, w_gimage);
     DRS_CHECK_HIP(hipGetLastError());
     return DRS_OK;
   }
