@@ -238,6 +238,11 @@ struct UpFuseDesc {
 };
 // (v_w', v_b') of that layer: v_w'[8 j][c][kv] = sum_co fw[j][co] v_w[co][c][kv] for c < Cc (the x-half of up_convs.i),
 // v_b'[8 j] = fb[j] + sum_co fw[j][co] v_b[co]; dst_w: 32 x (Cc + Ch) x 9 floats, dst_b: 32 floats
+// the folded top stage as a streaming direct-operand kernel, kernel rows in the MFMA's M dimension (upfuse_proj_sp.hip)
+bool drs_upfuse_proj_supported(int Cc, int Ch, int fuse_dim);
+size_t drs_upfuse_proj_weight_bytes(int Cc);
+int drs_launch_upfuse_proj_pack(const float* vp, const float* t_w, int Cc, int Ch, int fuse_dim, void* dst, hipStream_t s);
+int drs_launch_upfuse_proj(const UpFuseDesc& d, hipStream_t s);
 int drs_launch_upfuse_fold_proj(const float* v_w, const float* v_b, const float* fw, const float* fb, int fuse_dim, int Cc, int Ch,
                                 float* dst_w, float* dst_b, hipStream_t s);
 

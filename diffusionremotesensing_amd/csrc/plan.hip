@@ -408,6 +408,9 @@ struct DecStage {
   // att-half reads the skip tensor and multiplies by psi behind its MFMAs: `att` of the top stage never exists
   bool gate_psi = false;
   size_t ah_tmp2_off = 0, ah_tab_off = 0;
+  // the folded composite on the streaming kernel (upfuse_proj_sp.hip): its own operand image
+  bool uf_stream = false;
+  size_t ufp_w_off = 0;
   int t_PA = -1;                  // att-half partial sums (SP), B x Ch x 2lh x 2lw
   size_t o_eh = 0, o_ev = 0;      // workspace: edge vectors of this forward
 };
@@ -705,6 +708,8 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
         if (d.uf_proj) {
           d.uf_tmpw_off = cur; cur += align_up((size_t)32 * (Cc + Ch) * 9 * 4);
           d.uf_tmpb_off = cur; cur += align_up((size_t)32 * 4);
+          d.uf_stream = drs_upfuse_proj_supported(Cc, Ch, cfg->out_dim);
+          if (d.uf_stream) { d.ufp_w_off = cur; cur += align_up(drs_upfuse_proj_weight_bytes(Cc)); }
         }
       }
     }
@@ -946,6 +951,7 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
       float* tb = (float*)(base + d.uf_tmpb_off);
       if ((rc = drs_launch_upfuse_fold_proj(uv_w, uv_b, F(plan->output.w), F(plan->output.b), plan->cfg.out_dim, Cc, Ch, tw, tb, s))) return rc;
       uv_w = tw; uv_b = tb;
+      if (d.uf_stream && (rc = drs_launch_upfuse_proj_pack(tw, F(d.transform.w), Cc, Ch, plan->cfg.out_dim, base + d.ufp_w_off, s))) return rc;
     }
     if ((rc = drs_launch_upfuse_pack(uv_w, uv_b, F(d.transform.w), F(d.transform.b), Cc, Ch, base + d.uf_w_off,
                                      (float*)(base + d.uf_aux_off), base + d.uf_edge_off, s)))
@@ -1548,7 +1554,12 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         // executed work: 6.25 composite taps per output pixel; bytes: h + att-half partial sums + result (+ weights)
         prof_begin(plan, "up_convs." + std::to_string(i) + ".fused", 2.0 * opix * 6.25 * Cc * Ch,
                    4.0 * (opix / 4.0 * Cc + 2.0 * opix * Ch + 25.0 * Cc * Ch), s);
-        rc = drs_launch_upfuse(u, s);
+        if (i == 2 && st.uf_stream) {
+          u.w = pk + st.ufp_w_off;
+          rc = drs_launch_upfuse_proj(u, s);
+        } else {
+          rc = drs_launch_upfuse(u, s);
+        }
         prof_end(plan, s);
         if (rc) return rc;
       }
