@@ -90,6 +90,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp8_kernel(TapConv d, int nchu
       src = base + soff + lane_w;
       dst = sW + im * W_IMAGE + (((second ? 0 : col) * 3 + ky) * 4 + kq) * BNB * 16 + lane * 16;
     };
+    bool prev_fill = false;  // the previous step stored weight columns 1 / 2
     for (int k = 0; k < S; ++k) {
       if (++c == nck) c = 0;
       if (c == 0) item_of(++ord, quad, n0);
@@ -156,10 +157,14 @@ __global__ __launch_bounds__(768, 1) void tapconv_sp8_kernel(TapConv d, int nchu
         sp_wait_lds();
         if (lane == 0) sp_bump(sWL + (k & 1));
       }
-      if (k >= 1 && np[1]) sp_poll(sCR + 1, 8u * (unsigned)k, d.fault);
+      // (right behind a step that stored columns 1 / 2 a one-tap step polls too: the landed counters count bumps, not movers -
+      //  conv_sp_movers.inc has the story)
+      const bool after_fill = prev_fill;
+      prev_fill = np[1] != 0 || np[2] != 0;
+      if (k >= 1 && (np[1] || after_fill)) sp_poll(sCR + 1, 8u * (unsigned)k, d.fault);
       sp_wait_vm(np[2]);
       store_col(1);
-      if (k >= 1 && np[2]) sp_poll(sCR + 2, 8u * (unsigned)k, d.fault);
+      if (k >= 1 && (np[2] || after_fill)) sp_poll(sCR + 2, 8u * (unsigned)k, d.fault);
       sp_wait_vm(0);
       store_col(2);
     }

@@ -228,10 +228,10 @@ struct UpFuseDesc {
   // fuse_w comp + fuse_w att_half + ...), written by the att-half convolution's own fused-projection epilogue: this kernel
   // adds its part.  12.6 MB instead of the 134 MB of 32-channel partial sums per forward at 256 x 256; `res` is null then.
   int fuse_acc;
-  // proj = 1: the projection is folded into the composite weights (drs_launch_upfuse_fold_proj feeds the pack: a 32-channel
-  // layer whose logical channel 8 j is output j, everything else zero - MFMA row 4 j of the first channel tile): the kernel
-  // multiplies ONE channel tile, streams half of every weight group and stores acc + bias + edge + fuse_out; fuse_w / fuse_b
-  // are unused (the output bias is part of `bias`).
+  // proj = 1 (drs_launch_upfuse_proj, upfuse_proj_sp.hip): the projection is folded into the composite weights.  bias / eh / ev
+  // are those of a 32-channel layer whose logical channel 8 o is output o, everything else zero (drs_launch_upfuse_fold_proj
+  // feeds the unchanged pack / edge kernels), `w` is drs_launch_upfuse_proj_pack's image; fuse_w / fuse_b are unused (the output
+  // bias is part of `bias`).
   int proj;
   const void* zero_line;
   unsigned* fault;

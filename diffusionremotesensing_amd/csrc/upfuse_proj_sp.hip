@@ -35,7 +35,7 @@ __host__ __device__ constexpr int up_tap_t(int j) { return j >= 3 ? j - 2 : j; }
 __host__ __device__ constexpr bool up_pair(int p, int t, int kv, int kw) { return p + kv - kw == 2 * (t - 1); }
 
 template <int NCK>
-__global__ __launch_bounds__(256, 2) void upfuse_proj_sp_kernel(UpFuseDesc d) {
+__global__ __launch_bounds__(256, 3) void upfuse_proj_sp_kernel(UpFuseDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   using Frag = typename P::Frag;
@@ -206,8 +206,7 @@ __global__ __launch_bounds__(128) void upfuse_proj_pack_kernel(const float* __re
 size_t drs_upfuse_proj_weight_bytes(int Cc) { return (size_t)2 * (Cc / 32) * 5 * 4 * 16 * 16; }
 
 bool drs_upfuse_proj_supported(int Cc, int Ch, int fuse_dim) {
-  static const bool env = !(getenv("DRS_UPFUSE_STREAM") && atoi(getenv("DRS_UPFUSE_STREAM")) == 0);
-  return env && Ch == 32 && (Cc == 32 || Cc == 64) && fuse_dim >= 1 && fuse_dim <= 3;
+  return Ch == 32 && (Cc == 32 || Cc == 64) && fuse_dim >= 1 && fuse_dim <= 3;
 }
 
 int drs_launch_upfuse_proj_pack(const float* vp, const float* t_w, int Cc, int Ch, int fuse_dim, void* dst, hipStream_t s) {
@@ -232,7 +231,7 @@ int drs_launch_upfuse_proj(const UpFuseDesc& d, hipStream_t s) {
   }
   const size_t lds = drs_upfuse_proj_weight_bytes(d.Cc) + 64;
   const long long strips = (long long)d.N * ((d.LH + RBC - 1) / RBC) * ((d.LW + 15) >> 4);
-  long long blocks = (long long)num_cu * 2;
+  long long blocks = (long long)num_cu * 3;
   if (blocks * 4 > strips) blocks = (strips + 3) / 4;
   blocks = (blocks + 7) / 8 * 8;
   if (d.Cc == 64) DRS_LAUNCH(upfuse_proj_sp_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, d);

@@ -68,9 +68,9 @@ __host__ __device__ constexpr bool uf_pair(int p, int t, int kv, int kw) { retur
 // SP output-row permutation (drs_sp_cout_perm of the pack kernels): MFMA row nn of a 32-channel group carries logical channel
 __host__ __device__ constexpr int uf_perm(int nn) { return ((nn & 15) >> 2) * 8 + (nn >> 4) * 4 + (nn & 3); }
 
-template <bool FUSE, bool PROJ = false>
+template <bool FUSE>
 __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int tiles_y, int tiles_x, int nck, int debug) {
-  constexpr int NT = PROJ ? 1 : 2;  // channel tiles a consumer multiplies (PROJ: rows 16..31 of every weight group are zero)
+  constexpr int NT = 2;  // channel tiles a consumer multiplies
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using P = PolicyBF16X3;
   using G = UfGeom;
@@ -156,13 +156,6 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
     const bool tail_ok = (NBLK - 1) * 8 + l_px < G::NPIX;  // the last block is half empty
     constexpr int WPC = 5;                                 // weight pieces (1 KB) per mover wave and group
     u32x4 wr[2][WPC], ww[NPW];
-    if constexpr (PROJ) {
-#pragma unroll
-      for (int i = 0; i < WPC; ++i) wr[0][i] = wr[1][i] = u32x4{0u, 0u, 0u, 0u};
-    }
-    // PROJ: a 1 KB weight piece = two (tap, k-group) rows of 32 channel slots; channels 16..31 (lanes with bit 4 set) are the
-    // second channel tile, all zero and never read: those lanes do not load (half the weight traffic of a step)
-    const bool wlane_on = !PROJ || !(lane & 16);
     const int nwin = pw == 0 ? NPW : NPW - 1;
     const char* wg = reinterpret_cast<const char*>(d.w);
     const unsigned my_piece = (unsigned)(pw * WPC) * 1024u + (unsigned)lane * 16u;
@@ -221,8 +214,7 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
       const char* gsrc = wg + ((size_t)(n0 >> 5) * nck + c) * (size_t)(G::NGRP * SLOT) + my_piece;
       auto load_grp = [&](int g, int set) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < WPC; ++i)
-          if (wlane_on) wr[set][i] = *reinterpret_cast<const u32x4*>(gsrc + (unsigned)(g * SLOT + i * 1024));
+        for (int i = 0; i < WPC; ++i) wr[set][i] = *reinterpret_cast<const u32x4*>(gsrc + (unsigned)(g * SLOT + i * 1024));
       };
       // store group g (registers `set`) once its ring slot is free; `after` = vector-memory operations issued after its loads
       auto store_grp = [&](int g, int set, int after) __attribute__((always_inline)) {
@@ -363,65 +355,6 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
       UF_STAMP(5);
       sp_release(sWR + (k & 1), lane);  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
       UF_STAMP(6);
-      if constexpr (PROJ) {
-      if (c == nck - 1) {
-        // ---------------- item epilogue, folded projection ----------------
-        // MFMA row 4 kg of the (only) channel tile = logical channel 8 kg (uf_perm) = output kg: register 0 of the lanes of
-        // k-group kg.  value = acc + bias + edge vectors (32-channel vectors whose channel 8 j is output j) + what fuse_out
-        // already holds (the att-half, projected by its own folded weights); all loads before the first store.
-        int lr_e = lr, kg_e = kg;
-        asm volatile("" : "+v"(lr_e), "+v"(kg_e));
-        const int OH = 2 * d.LH, OW = 2 * d.LW;
-        const int ch = kg_e * 8;
-        const int mx = tx0 + lr_e;
-        const bool own_ok = mx < d.LW && kg_e < d.fuse_dim;
-        const int ox_own = 2 * min(mx, d.LW - 1) + px;
-        const int myb = ty0 + rw * RPW;
-        const size_t plane = (size_t)OH * OW;
-        float* obase = d.fuse_out + ((size_t)n * d.fuse_dim + min(kg_e, d.fuse_dim - 1)) * plane + ox_own;
-        const float b = sConst[ch];
-        float add[RPW][2];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-          for (int py = 0; py < 2; ++py) {
-            const int oy = 2 * min(myb + r, d.LH - 1) + py;
-            add[r][py] = d.fuse_acc ? obase[(size_t)oy * OW] : 0.f;
-          }
-        if (d.eh) {
-#pragma unroll
-          for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int py = 0; py < 2; ++py) {
-              const int oy = 2 * (myb + r) + py;
-              if (myb + r < d.LH && (oy == 0 || oy == OH - 1))
-                add[r][py] += d.eh[(((size_t)n * 2 + (oy ? 1 : 0)) * OW + ox_own) * d.Ch + ch];
-            }
-          if (mx < d.LW && (ox_own == 0 || ox_own == OW - 1)) {
-            const float* evp = d.ev + ((size_t)n * 2 + (ox_own ? 1 : 0)) * OH * d.Ch + ch;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-#pragma unroll
-              for (int py = 0; py < 2; ++py) {
-                const int oy = 2 * (myb + r) + py;
-                if (myb + r < d.LH && oy > 0 && oy < OH - 1) add[r][py] += evp[(size_t)oy * d.Ch];  // (rows 0 / OH-1 took the row vectors)
-              }
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-          for (int py = 0; py < 2; ++py) asm volatile("" :: "v"(add[r][py]));
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-          const int my = myb + r;
-          if (my < d.LH && own_ok) {
-#pragma unroll
-            for (int py = 0; py < 2; ++py) obase[(size_t)(2 * my + py) * OW] = acc[r][py][0][0] + b + add[r][py];
-          }
-        }
-      }
-      } else
       if (c == nck - 1) {
         // ---------------- item epilogue ----------------
         // lane (lr, kg) holds, per (cell row r, y-phase py), the 8 consecutive logical channels n0 + kg*8 .. +7 (tile 0:
@@ -977,18 +910,17 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
   DRS_REQUIRE(!d.out || ((d.out_cs & 31) == 0 && (d.out_co & 31) == 0), DRS_ERR_SHAPE, "upfuse: out slice");
   DRS_REQUIRE(!d.out2 || (d.post2 && (d.out2_cs & 31) == 0 && (d.out2_co & 31) == 0 && (d.post2_cs & 3) == 0),
               DRS_ERR_SHAPE, "upfuse: out2");
-  DRS_REQUIRE(!d.fuse_out || (d.Ch == 32 && d.fuse_dim >= 1 && d.fuse_dim <= 4 && (d.proj || (d.fuse_w && d.fuse_b)) && !d.out && !d.out2),
+  DRS_REQUIRE(!d.proj, DRS_ERR_ARG, "upfuse: the folded projection runs on drs_launch_upfuse_proj (upfuse_proj_sp.hip)");
+  DRS_REQUIRE(!d.fuse_out || (d.Ch == 32 && d.fuse_dim >= 1 && d.fuse_dim <= 4 && d.fuse_w && d.fuse_b && !d.out && !d.out2),
               DRS_ERR_SHAPE, "upfuse: fused projection needs Ch == 32, fuse_dim <= 4 and no wide output");
-  DRS_REQUIRE(!d.proj || (d.fuse_out && !d.res), DRS_ERR_ARG, "upfuse: the folded projection writes fuse_out and takes no residual");
   DRS_REQUIRE(!d.fuse_acc || (d.fuse_out && !d.res), DRS_ERR_ARG, "upfuse: fuse_acc takes the att-half from fuse_out, not from res");
   DRS_REQUIRE((d.eh == nullptr) == (d.ev == nullptr), DRS_ERR_ARG, "upfuse: edge vectors");
   if ((size_t)d.N * d.LH * d.LW == 0) return DRS_OK;
   const int tiles_y = drs_cdiv(d.LH, 16), tiles_x = drs_cdiv(d.LW, 16), nck = d.Cc / 32;
   const long long nitems = (long long)d.N * tiles_y * tiles_x * (d.Ch / 32);
   int num_cu = 0;
-  const void* kern = d.proj ? reinterpret_cast<const void*>(upfuse_sp_kernel<false, true>)
-                            : d.fuse_out ? reinterpret_cast<const void*>(upfuse_sp_kernel<true>)
-                                         : reinterpret_cast<const void*>(upfuse_sp_kernel<false>);
+  const void* kern = d.fuse_out ? reinterpret_cast<const void*>(upfuse_sp_kernel<true>)
+                                : reinterpret_cast<const void*>(upfuse_sp_kernel<false>);
   static_assert(UfGeom::LDS <= 160 * 1024, "LDS budget");
   {
     const int rc = drs_kernel_prepare(kern, 160 * 1024, &num_cu);
@@ -998,9 +930,7 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
   if (blocks > nitems) blocks = nitems;
   blocks = (blocks + 7) / 8 * 8;
   static const int dbg = getenv("DRS_DEBUG_FLAGS") ? atoi(getenv("DRS_DEBUG_FLAGS")) : 0;  // timeline builds: 1 no stores, 2 no residual loads
-  if (d.proj)
-    DRS_LAUNCH((upfuse_sp_kernel<false, true>), dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
-  else if (d.fuse_out)
+  if (d.fuse_out)
     DRS_LAUNCH(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
   else
     DRS_LAUNCH(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
@@ -1012,9 +942,7 @@ int drs_launch_upfuse(const UpFuseDesc& d, hipStream_t s) {
     float ms = 0.f;
     DRS_CHECK_HIP(hipEventCreate(&e0)); DRS_CHECK_HIP(hipEventCreate(&e1));
     DRS_CHECK_HIP(hipEventRecord(e0, s));
-    if (d.proj)  // timed repeat (fuse_acc: adds its part once more - timing runs only)
-      DRS_LAUNCH((upfuse_sp_kernel<false, true>), dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
-    else if (d.fuse_out)
+    if (d.fuse_out)  // timed repeat (same result)
       DRS_LAUNCH(upfuse_sp_kernel<true>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
     else
       DRS_LAUNCH(upfuse_sp_kernel<false>, dim3((unsigned)blocks), dim3(768), UfGeom::LDS, s, d, tiles_y, tiles_x, nck, dbg);
