@@ -724,10 +724,11 @@ def test_full_length_chain_is_deterministic(dev, model):
 @pytest.mark.parametrize("env", [{"DRS_SP": "0"}, {"DRS_SP": "0", "DRS_WS": "0"}, {"DRS_FUSE_GATE": "0"},
                                  {"DRS_CONCURRENT": "1"}, {"DRS_D3K": "0", "DRS_S2K": "0"}, {"DRS_UPFUSE": "0"},
                                  {"DRS_XT_ONLY": "0"}, {"DRS_RB0": "0"}, {"DRS_DOWNK": "0"}, {"DRS_SP8": "0"},
-                                 {"DRS_FOLD_PROJ": "0"}],
+                                 {"DRS_FOLD_PROJ": "0"}, {"DRS_GATE_PSI": "0"}],
                          ids=["fp32-activations+ws", "fp32-activations+lockstep", "sp-unfused-gate", "sp-two-streams",
                               "sp-without-direct-kernels", "sp-unfused-up", "sp-plain-stage-inputs", "sp-two-launch-block0",
-                              "sp-direct-operand-downs0", "sp-lockstep-8x8-level", "sp-projection-in-the-epilogue"])
+                              "sp-direct-operand-downs0", "sp-lockstep-8x8-level", "sp-projection-in-the-epilogue",
+                              "sp-top-stage-with-att"])
 def test_conv_kernel_variants_in_subprocess(env):
     """The kernel families of the eval split-bf16 plan are chosen once per process.  Default = SP-format activations with
     the wave-specialised SP kernel and the fused attention gate, serial stages; the switches select the older paths that
@@ -740,8 +741,8 @@ def test_conv_kernel_variants_in_subprocess(env):
     the four-images-per-item instance of the wave-specialised one, DRS_DOWNK=0 downs.0 on the direct-operand stride-2 kernel
     instead of the LDS-staged one, DRS_D3K=0 / DRS_S2K=0 the plan without the direct-operand kernels (3x3 on the
     32-channel layers, stride-2 and transposed convolutions), DRS_FOLD_PROJ=0 the `output` projection as an epilogue of
-    up_convs.2's two launches (what images under 64 rows always run) instead of folded into their weights.  All must reproduce
-    the same goldens.  Own process, because the switches are read once."""
+    up_convs.2's two launches (what images under 64 rows always run) instead of folded into their weights, DRS_GATE_PSI=0 the
+    top stage's gate writing `att` (and the att-half reading it) instead of stopping at psi.  All must reproduce the same goldens.  Own process, because the switches are read once."""
     import os
     import subprocess
     import sys
