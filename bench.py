@@ -412,28 +412,32 @@ def main():
                            "frac": round(fb / 1e9 / (all_ms * 1e-3) / HBM_PEAK_GBS, 4)}
             break
         mfma_per_product = 3 if args.impl == "mfma_bf16x3" else 1
-        # the family's two kernels on the default plan: the 32-channel layers at full resolution run the direct-operand
-        # kernel (conv3x3_direct_sp.hip), everything else the wave-specialised one; per-kernel averages for the cross-check
-        # against the rocprofv3 kernel trace (profiles/r02_bench_kernel_stats.csv)
+        # the family's kernels, named by the plan's own launch log of the profiled forward (op -> kernel: what tools/collect_pmc.py
+        # joins the counter passes with); per-kernel averages for the cross-check against the rocprofv3 kernel trace
         by_kernel = None
         if args.impl == "mfma_bf16x3":
-            direct_ops = ("conv_blocks.0.conv1.0+skip", "conv_blocks.0.conv2.0", "up_convs.2", "up_convs.2.att")
+            import re
+            kern_of = {}
+            for op_name, kname in getattr(engine, "last_launch_log", None) or []:
+                if op_name:
+                    kern_of.setdefault(op_name, re.sub(r"^void\s+", "", kname).split("<")[0].split("(")[0].strip())
+            groups = {}
+            for o in dom:
+                groups.setdefault(kern_of.get(o[0], "?"), []).append(o)
             by_kernel = {}
-            for kname, sel in (("conv3x3_direct_sp_kernel", [o for o in dom if o[0] in direct_ops]),
-                               ("resblock0_kernel", [o for o in dom if o[0] == "conv_blocks.0.fused"]),
-                               ("upfuse_sp_kernel", [o for o in dom if o[0].startswith("up_convs.") and o[0].endswith(".fused")]),
-                               ("tapconv_sp_kernel", [o for o in dom if o[0] not in direct_ops and not o[0].endswith(".fused")])):
-                if sel:
-                    ms = sum(o[1] for o in sel)
-                    by_kernel[kname] = {"launches": len(sel), "avg_launch_us": round(1e3 * ms / len(sel), 2),
-                                        "achieved": round(sum(o[2] for o in sel) / (ms * 1e-3) / 1e12, 2)}
+            for kname, sel in groups.items():
+                ms = sum(o[1] for o in sel)
+                by_kernel[kname] = {"launches": len(sel), "avg_launch_us": round(1e3 * ms / len(sel), 2),
+                                    "achieved": round(sum(o[2] for o in sel) / (ms * 1e-3) / 1e12, 2)}
         roofline = {"bound": "mfma",
                     "kernel": ("3x3 stride-1 convolutions: tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL> (conv_mfma_sp.hip; 8 MFMA + 4 "
                                "mover waves per CU) on the deep layers + upfuse_sp_kernel (same structure: ups.i.transform composed "
                                "with the x-half of up_convs.i, executed FLOPs counted) + resblock0_kernel (the first encoder block as "
                                "one launch: conv1 + skip into an LDS window, conv2 + shortcut from it; algorithmic FLOPs, the halo "
-                               "recomputation not counted) + conv3x3_direct_sp_kernel (weights resident in LDS, operands global -> "
-                               "registers) on up_convs.2's att-half; SP-format operands"
+                               "recomputation not counted) + the top stage with result / up_convs.2 / output folded into its weights: "
+                               "conv3x3_proj_sp_kernel (att-half) and upfuse_proj_sp_kernel (composite), streaming direct-operand kernels "
+                               "with the kernel rows in the MFMA's M dimension (algorithmic FLOPs of the reference ops, a fraction of "
+                               "them executed); SP-format operands"
                                if args.impl == "mfma_bf16x3" else
                                "3x3 stride-1 family: tapconv_ws_kernel / tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *>" % args.impl)
                     if args.impl != "direct" else "tapconv_direct_kernel",
