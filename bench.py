@@ -420,7 +420,7 @@ def main():
             kern_of = {}
             for op_name, kname in getattr(engine, "last_launch_log", None) or []:
                 if op_name:
-                    kern_of.setdefault(op_name, re.sub(r"^void\s+", "", kname).split("<")[0].split("(")[0].strip())
+                    kern_of.setdefault(op_name, re.sub(r"^void\s+", "", kname.replace("(anonymous namespace)::", "")).split("<")[0].split("(")[0].strip())
             groups = {}
             for o in dom:
                 groups.setdefault(kern_of.get(o[0], "?"), []).append(o)
@@ -448,6 +448,9 @@ def main():
                     "traffic": traffic, "traffic_source": (tsource + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per "
                                                            "op of one forward through the plan's launch log; op names AND the "
                                                            "kernel behind every op match this run)") if tsource else None,
+                    "note": ("achieved counts the ALGORITHMIC FLOPs of the reference ops (SURVEY 8(d)); the composite stages execute "
+                             "25/54 of theirs and the top stage's two folded launches about a tenth (output o up_convs.2 o result is "
+                             "one 3-output convolution), so mfma_pipe_frac overstates the matrix pipe's load on those four launches"),
                     "mfma_instructions_per_product": mfma_per_product,
                     "mfma_pipe_frac": round(mfma_per_product * achieved / peak, 5),
                     "forward_ms_sum_of_ops": round(all_ms, 4), "conv_ms": round(conv_ms, 4),

@@ -244,10 +244,11 @@ static size_t upfused_sizes(int N, int Cc, int Ch, int LH, int LW, size_t* o) {
   o[12] = b; b += align_up((size_t)16 * Ch * 9 * 4);
   o[13] = b; b += align_up((size_t)32 * (Cc + Ch) * 9 * 4);
   o[14] = b; b += align_up((size_t)32 * 4);
+  o[15] = b; b += align_up(drs_upfuse_proj_weight_bytes(Cc > 64 ? 64 : Cc));
   return b + 256;
 }
 extern "C" size_t drs_upconv_fused_workspace_bytes(int N, int Cc, int Ch, int LH, int LW) {
-  size_t o[15];
+  size_t o[16];
   return upfused_sizes(N, Cc, Ch, LH, LW, o);
 }
 extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const float* t_w, const float* t_b, const float* v_w,
@@ -262,7 +263,7 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
   DRS_REQUIRE(!fuse_w || (Ch == 32 && fuse_dim >= 1 && fuse_dim <= 4 && fuse_b && !post2 && !y2), DRS_ERR_SHAPE,
               "upconv_fused: the fused projection needs Ch == 32, fuse_dim <= 4 and no second output");
   DRS_REQUIRE((post2 == nullptr) == (y2 == nullptr), DRS_ERR_ARG, "upconv_fused: post2 and y2 come together");
-  size_t o[15];
+  size_t o[16];
   DRS_REQUIRE(workspace_bytes >= upfused_sizes(N, Cc, Ch, LH, LW, o), DRS_ERR_WORKSPACE, "upconv_fused: workspace too small");
   char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const int OH = 2 * LH, OW = 2 * LW;
@@ -276,12 +277,13 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
   TapConv ah = conv_desc((const float*)(base + o[1]), N, OH, OW, Ch, Ch, 0, (const float*)(base + o[6]), nullptr, nullptr, 16, 16, 0, 3, 3, 1, 1);
   if (fuse_w) {
     ah.in_sp = 1; ah.zero_line = base + o[10]; ah.proj = 1; ah.fuse_out = y; ah.fuse_dim = fuse_dim;
-    fold = drs_conv3x3_direct_sp_proj_supported(ah, DRS_IMPL_MFMA_BF16X3);
+    fold = drs_conv3x3_direct_sp_proj_supported(ah, DRS_IMPL_MFMA_BF16X3) && drs_upfuse_proj_supported(Cc, Ch, fuse_dim);
   }
   const float *uv_w = v_w, *uv_b = v_b;
   if (fold) {
     if ((rc = drs_launch_upfuse_fold_proj(v_w, v_b, fuse_w, fuse_b, fuse_dim, Cc, Ch, (float*)(base + o[13]), (float*)(base + o[14]), s))) return rc;
     uv_w = (const float*)(base + o[13]); uv_b = (const float*)(base + o[14]);
+    if ((rc = drs_launch_upfuse_proj_pack(uv_w, t_w, Cc, Ch, fuse_dim, base + o[15], s))) return rc;
     if ((rc = drs_launch_fold_proj(v_w, Cc + Ch, Cc, Ch, Ch, fuse_w, fuse_dim, (float*)(base + o[12]), s))) return rc;
     if ((rc = drs_launch_pack_conv_mfma((const float*)(base + o[12]), nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, base + o[6],
                                         (float*)(base + o[7]), 16, Ch, 3, 0, DRS_IMPL_MFMA_BF16X3, s, 0, 0, 0, 0, 0)))
@@ -336,7 +338,9 @@ extern "C" int drs_upconv_fused_nchw(const float* h, const float* att, const flo
       u.out = (float*)(base + o[3]); u.out_cs = Ch; u.out_co = 0;
       if (y2) { u.out2 = (float*)(base + o[1]); u.out2_cs = Ch; u.out2_co = 0; u.post2 = post2; u.post2_cs = Ch; }  // (att is consumed by now)
     }
-    if ((rc = drs_launch_upfuse(u, s))) return rc;
+    if (fold) { u.w = base + o[15]; rc = drs_launch_upfuse_proj(u, s); }
+    else rc = drs_launch_upfuse(u, s);
+    if (rc) return rc;
   }
   if (!fuse_w) {
     if ((rc = drs_launch_sp_to_nchw((const float*)(base + o[3]), y, N, Ch, OH, OW, Ch, 0, s))) return rc;
@@ -698,7 +702,7 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
         d.ah_proj = drs_conv3x3_direct_sp_proj_supported(probe, cfg->impl);
         if (d.ah_proj) { d.ah_tmp_off = cur; cur += align_up((size_t)16 * Ch * 9 * 4); }
         // the composite's folded form needs the att-half in the output tensor first (fuse_acc): both or neither
-        d.uf_proj = d.ah_proj;
+        d.uf_proj = d.ah_proj && drs_upfuse_proj_supported(Cc, Ch, cfg->out_dim);
         static const bool gp_env = !(getenv("DRS_GATE_PSI") && atoi(getenv("DRS_GATE_PSI")) == 0);
         d.gate_psi = gp_env && d.ah_proj && d.fused_gate && Ch == 32 && !(cfg->flags & DRS_PLAN_KEEP_ALL) && !(cfg->height & 1) && !(cfg->width & 1);
         if (d.gate_psi) {
@@ -708,8 +712,8 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
         if (d.uf_proj) {
           d.uf_tmpw_off = cur; cur += align_up((size_t)32 * (Cc + Ch) * 9 * 4);
           d.uf_tmpb_off = cur; cur += align_up((size_t)32 * 4);
-          d.uf_stream = drs_upfuse_proj_supported(Cc, Ch, cfg->out_dim);
-          if (d.uf_stream) { d.ufp_w_off = cur; cur += align_up(drs_upfuse_proj_weight_bytes(Cc)); }
+          d.uf_stream = true;
+          d.ufp_w_off = cur; cur += align_up(drs_upfuse_proj_weight_bytes(Cc));
         }
       }
     }
