@@ -86,6 +86,47 @@ __global__ void sp_to_fl(const unsigned char* __restrict__ sp, unsigned char* __
   if (s == 0) { o[112] = (unsigned char)(127 + em); o[113] = (unsigned char)(127 + er); }
 }
 
+// ---- SP -> FL, one lane per (pixel, chunk) - a whole 32-channel block in a lane, so that the conversions are the hardware's:
+// v_cvt_scalef32_pk32_fp6_f16 takes 32 fp16 and one f32 scale (code of x / scale, RNE, saturating; element t at bits 6 t:
+// tools/micro/cvt_fp6_probe.hip).  The remainder is exact in fp16 whenever it is not below fp16's subnormal step (2^-24).
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+__global__ __launch_bounds__(256) void sp_to_fl_lane(const unsigned char* __restrict__ sp, unsigned char* __restrict__ fl, int nlines) {
+  const int line = blockIdx.x * blockDim.x + threadIdx.x;
+  if (line >= nlines) return;
+  const u32x4* in = reinterpret_cast<const u32x4*>(sp + (size_t)line * 128);
+  u32x4 hi[4], lo[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { hi[s] = in[s]; lo[s] = in[4 + s]; }
+  f16x32 m, r;
+  float am = 0.f, ar = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned h = hi[s][j >> 1], l = lo[s][j >> 1];
+      const float x = __uint_as_float((j & 1) ? (h & 0xffff0000u) : (h << 16)) + __uint_as_float((j & 1) ? (l & 0xffff0000u) : (l << 16));
+      const _Float16 mh = (_Float16)x;
+      const float rem = x - (float)mh;
+      m[s * 8 + j] = mh;
+      r[s * 8 + j] = (_Float16)rem;
+      am = fmaxf(am, fabsf((float)mh));
+      ar = fmaxf(ar, fabsf(rem));
+    }
+  const int em = block_exp(am), er = block_exp(ar);
+  const u32x6 qm = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(m, ldexpf(1.f, em));
+  const u32x6 qr = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(r, ldexpf(1.f, er));
+  unsigned* o = reinterpret_cast<unsigned*>(fl + (size_t)line * 128);
+  const unsigned* mw = reinterpret_cast<const unsigned*>(&m);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) reinterpret_cast<u32x4*>(o)[s] = u32x4{mw[4 * s], mw[4 * s + 1], mw[4 * s + 2], mw[4 * s + 3]};
+  reinterpret_cast<u32x4*>(o)[4] = u32x4{qm[0], qm[1], qm[2], qm[3]};
+  reinterpret_cast<u32x4*>(o)[5] = u32x4{qm[4], qm[5], qr[0], qr[1]};
+  reinterpret_cast<u32x4*>(o)[6] = u32x4{qr[2], qr[3], qr[4], qr[5]};
+  reinterpret_cast<u32x4*>(o)[7] = u32x4{(unsigned)(127 + em) | ((unsigned)(127 + er) << 8), 0u, 0u, 0u};
+}
+
 // ---- the layer: one wave per (row y, 16-pixel segment); A = weights (rows = output channels), B = activations (columns = pixels)
 template <int SCHEME>  // 0: split bf16 x 3 from SP lines, 1: fp16 + paired fp6 from FL lines
 __global__ __launch_bounds__(64) void conv(const unsigned char* __restrict__ act, const unsigned char* __restrict__ wmain,
@@ -214,6 +255,18 @@ int main() {
   hipMemcpy(dwf, wf.data(), wf.size(), hipMemcpyHostToDevice); hipMemcpy(dwc, wc.data(), wc.size(), hipMemcpyHostToDevice);
   const int nlines = H * W * NCH;
   hipLaunchKernelGGL(sp_to_fl, dim3((nlines * 4 + 255) / 256), dim3(256), 0, 0, dsp, dfl, nlines);
+  {  // the lane-per-block form with the hardware converters must write the same lines (bytes 0 - 113)
+    unsigned char* dfl2;
+    hipMalloc(&dfl2, sp.size());
+    hipMemset(dfl2, 0, sp.size());
+    hipLaunchKernelGGL(sp_to_fl_lane, dim3((nlines + 255) / 256), dim3(256), 0, 0, dsp, dfl2, nlines);
+    std::vector<unsigned char> a(sp.size()), b(sp.size());
+    hipMemcpy(a.data(), dfl, a.size(), hipMemcpyDeviceToHost); hipMemcpy(b.data(), dfl2, b.size(), hipMemcpyDeviceToHost);
+    long long diff = 0;
+    for (int ln = 0; ln < nlines; ++ln)
+      for (int i = 0; i < 114; ++i) diff += a[(size_t)ln * 128 + i] != b[(size_t)ln * 128 + i];
+    printf("SP -> FL by a lane quad (manual e2m3 pack) vs by one lane per block (v_cvt_scalef32_pk32_fp6_f16): %lld differing bytes of %d lines\n", diff, nlines);
+  }
   hipLaunchKernelGGL(conv<0>, dim3(H * (W / 16)), dim3(64), 0, 0, dsp, dwb, (const unsigned char*)nullptr, o0);
   hipLaunchKernelGGL(conv<1>, dim3(H * (W / 16)), dim3(64), 0, 0, dfl, dwf, dwc, o1);
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
