@@ -5,19 +5,28 @@
 //   V1: 4 waves (1 per SIMD), 8 rows x 32 channels each, window fragments prefetched PF rows ahead through a 5-slot
 //       register ring, weight fragments of the next column under the tail of the current one, order pinned by
 //       sched_barrier
+//   V2: the arithmetic of DESIGN.md section 9 on V0's structure: fp16 main product (window / weight fragments = one 16-byte slot)
+//       + the cross terms of tap PAIRS as one block-scaled fp6 instruction (fragments = the 24-byte block of slots 4-5 or 6-7
+//       of the lane's pixel: k-groups 0 / 1 of the pair's first tap, 2 / 3 of its second; pairs (c0k0,c0k1) (c0k2,c1k0)
+//       (c1k1,c1k2) (c2k0,c2k1) (c2k2,-)); 9 + 5 instructions per product row instead of 27.  Static LDS contents, the
+//       same rotated lines: what the LDS array and the matrix pipe do with that mix.
 // Prints ticks per step (6912 = the 432 MFMAs of a SIMD back to back).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct Frag { bf16x8 hi, lo; };
 constexpr int IW = 18, WBUF = 41 * 1024, W_IMAGE = 9 * 4 * 64 * 16, BNB = 64;
 
 __device__ __forceinline__ f32x4 mm(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 template <int VARIANT, int PF>
-__global__ __launch_bounds__(VARIANT == 0 ? 512 : 256, 1) void cons(float* out, int steps, unsigned long long* ticks, int data) {
+__global__ __launch_bounds__(VARIANT == 1 ? 256 : 512, 1) void cons(float* out, int steps, unsigned long long* ticks, int data) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sWin = smem;
   char* sW = smem + 2 * WBUF;
@@ -30,12 +39,15 @@ __global__ __launch_bounds__(VARIANT == 0 ? 512 : 256, 1) void cons(float* out, 
     unsigned h = (unsigned)i * 2654435761u;
     h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
     const unsigned rnd = (h & 0x807f807fu) | ((0x7bu + ((h >> 8) & 7u)) << 7) | ((0x7bu + ((h >> 24) & 7u)) << 23);
-    reinterpret_cast<unsigned*>(smem)[i] = data ? rnd : 0x3c003c00u + ((i * 2654435761u) >> 20 & 0x00ff00ffu);
+    // (V2 reads the same words as fp16 - (h & 0x83ff83ff) | 0x3c003c00-ish keeps them finite: exponent field 0x0f +- 1 - and as fp6 bits)
+    const unsigned rnd16 = (h & 0x83ff83ffu) | ((0x0eu + ((h >> 10) & 1u)) << 10) | ((0x0eu + ((h >> 26) & 1u)) << 26);
+    reinterpret_cast<unsigned*>(smem)[i] = VARIANT == 2 ? (data ? rnd16 : 0x3c003c00u + ((i * 2654435761u) >> 20 & 0x00ff00ffu))
+                                                        : (data ? rnd : 0x3c003c00u + ((i * 2654435761u) >> 20 & 0x00ff00ffu));
   }
   __syncthreads();
-  constexpr int RPW = VARIANT == 0 ? 4 : 8;
-  const int rw = VARIANT == 0 ? (wid & 3) : (wid & 1);
-  const int ng = VARIANT == 0 ? (wid >> 2) : (wid >> 1);
+  constexpr int RPW = VARIANT == 1 ? 8 : 4;
+  const int rw = VARIANT == 1 ? (wid & 1) : (wid & 3);
+  const int ng = VARIANT == 1 ? (wid >> 1) : (wid >> 2);
   const int B = rw * RPW * IW;
   int tab_hi[8], tab_lo[8];
 #pragma unroll
@@ -92,6 +104,84 @@ __global__ __launch_bounds__(VARIANT == 0 ? 512 : 256, 1) void cons(float* out, 
 #pragma unroll
                 for (int t = 0; t < 2; ++t) wf[ky][t] = w_frag(col + 1, ky, t);
               }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (stands for the release of the ring slot)
+      }
+    }
+  } else if constexpr (VARIANT == 2) {
+    auto mm16 = [](u32x4 a, u32x4 b, f32x4 c) __attribute__((always_inline)) {
+      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    };
+    // cross-term window fragment of product row r for the tap pair (row kA, column cA | row kB, column cB): the lane's pixel is
+    // tap A's for k-groups 0 / 1, tap B's for 2 / 3; its block = slots 4-5 (q(main), even k-group) or 6-7 (q(remainder)), rotated
+    // per-lane address tables (as tab_hi / tab_lo of the main fragments): k-groups 2 / 3 sit `delta` pixels behind tap A's pixel
+    // (kind 0: the next window row, + IW; kind 1: (row 2, column c) -> (row 0, column c + 1), - 2 IW + 1); entry j serves the
+    // compile-time pixel offsets that are j mod 8; part 0: the block's first slot (16 bytes), part 1: its second (8 bytes used)
+    int tq[2][2][8];
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = kg < 2 ? 0 : (kind == 0 ? IW : -2 * IW + 1), sb = 4 + 2 * (kg & 1), q = B + lr + d;
+        tq[kind][0][j] = q * 128 + (((sb + q + j) & 7) << 4);
+        tq[kind][1][j] = q * 128 + (((sb + 1 + q + j) & 7) << 4);
+      }
+    auto xq_frag = [&](const char* buf, int r, int kA, int cA, int kB, int cB) __attribute__((always_inline)) {
+      const int kind = (kB == kA + 1 || kB == kA) ? 0 : 1, off = (r + kA) * IW + cA;  // (compile-time after unrolling)
+      const u32x4 a = *reinterpret_cast<const u32x4*>(buf + tq[kind][0][off & 7] + off * 128);
+      const u32x2 b = *reinterpret_cast<const u32x2*>(buf + tq[kind][1][off & 7] + off * 128);
+      (void)cB;
+      return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], 0, 0};
+    };
+    auto wq_frag = [&](int pair, int t) __attribute__((always_inline)) {  // 32-byte records (static contents: they overlap the unused second image)
+      const char* rec = sW + 32768 + ((size_t)(pair * 4 + kg) * BNB + ng * 32 + t * 16 + lr) * 32;  // (20 rows of 2 KB: ends with the LDS allocation)
+      const u32x4 a = *reinterpret_cast<const u32x4*>(rec);
+      const u32x2 b = *reinterpret_cast<const u32x2*>(rec + 16);
+      return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], 0, 0};
+    };
+    constexpr int PA[5][4] = {{0, 0, 1, 0}, {2, 0, 0, 1}, {1, 1, 2, 1}, {0, 2, 1, 2}, {2, 2, 2, 2}};  // kA, cA, kB, cB (the fifth pair: its second half meets zero weights)
+    const int sc = 127;
+    u32x4 wm[3][2];
+    for (int k = 0; k < steps; ++k) {
+      const char* buf = sWin + (k & 1) * WBUF;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wm[ky][t] = __builtin_bit_cast(u32x4, w_frag(0, ky, t).hi);
+#pragma unroll
+      for (int col = 0; col < 3; ++col) {
+#pragma unroll
+        for (int wr = 0; wr < RPW + 2; ++wr) {
+          const u32x4 am = __builtin_bit_cast(u32x4, win_frag(buf, wr * IW + col).hi);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int r = wr - ky;
+            if (r >= 0 && r < RPW) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t) acc[r][t] = mm16(wm[ky][t], am, acc[r][t]);
+            }
+          }
+          if (col < 2) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+              if (wr == ky + RPW - 1) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wm[ky][t] = __builtin_bit_cast(u32x4, w_frag(col + 1, ky, t).hi);
+              }
+          }
+        }
+        // the pairs whose taps are complete with this column: 0 | 1, 2 | 3, 4
+#pragma unroll
+        for (int pr = (col == 0 ? 0 : col == 1 ? 1 : 3); pr < (col == 0 ? 1 : col == 1 ? 3 : 5); ++pr) {
+          const i32x8 w0 = wq_frag(pr, 0), w1 = wq_frag(pr, 1);
+          i32x8 xq[RPW];  // (all rows' fragments requested before the first instruction that needs one)
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) xq[r] = xq_frag(buf, r, PA[pr][0], PA[pr][1], PA[pr][2], PA[pr][3]);
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) {
+            acc[r][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w0, xq[r], acc[r][0], 2, 2, 0, sc, 0, sc);
+            acc[r][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w1, xq[r], acc[r][1], 2, 2, 0, sc, 0, sc);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (stands for the release of the ring slot)
@@ -171,7 +261,7 @@ void run(const char* name, int blocks, int steps, float* out, unsigned long long
   // MI355X_MICROARCH.md, DVFS give-back item 6: the clock under load is read after seconds of back-to-back launches
   for (int rep = 0; rep < g_reps; ++rep) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(V == 0 ? 512 : 256), lds, 0, out, steps, ticks, data);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(V == 1 ? 256 : 512), lds, 0, out, steps, ticks, data);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     hipEventElapsedTime(&ms, e0, e1);
@@ -195,6 +285,7 @@ int main(int argc, char** argv) {
       printf("data %d\n", data);
       run<0, 0>("V0 2 waves/SIMD 4 rows", blocks, steps, out, ticks, data);
       run<1, 3>("V1 1 wave/SIMD 8 rows PF=3", blocks, steps, out, ticks, data);
+      run<2, 0>("V2 fp16 + paired fp6 (as V0)", blocks, steps, out, ticks, data);
     }
   return 0;
 }
