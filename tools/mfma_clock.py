@@ -34,6 +34,8 @@ for line in out.splitlines():
         rows.append({"variant": m.group(1).strip(), "operands": "random mantissas" if data else "near-constant", "cus": int(m.group(2)),
                      "us_per_step": round(us_step, 4), "clock_ghz_in_kernel": clk,
                      "ticks_per_step_wall": round(us_step * clk * 1e3), "mfma_rate": round(6912 / (us_step * clk * 1e3), 3)})
+# (V2 is the fp16 + fp6 study of DESIGN.md section 9: its step has fewer MFMAs, the 6912-tick reference does not apply)
+rows = [r for r in rows if not r["variant"].startswith("V2")]
 full = [r for r in rows if r["cus"] == 256 and r["operands"].startswith("random")]
 res = {"source": "tools/micro/cons_loop.hip via tools/mfma_clock.py", "steps_per_launch": 4096, "launches": 120,
        "rows": rows,
