@@ -536,6 +536,10 @@ int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s) {
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_conv3x3_direct_sp_supported(d, impl))
     return drs_launch_conv3x3_direct_sp(d, s);
   if ((mode == MODE_CONV3X3 || mode == MODE_CONV3X3_FUSE) && drs_tapconv_sp_supported(d, impl)) {
+    if (drs_tapconv_fl_supported(d, impl)) {
+      const int rc = drs_launch_tapconv_fl(d, g, s);
+      if (rc != DRS_FL_DECLINED) return rc;
+    }
     return drs_launch_tapconv_sp(d, g, s);
   }
   if (mode == MODE_CONV3X3 && drs_tapconv_sp_f32out_supported(d, impl)) return drs_launch_tapconv_sp(d, g, s);

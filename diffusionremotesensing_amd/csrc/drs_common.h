@@ -92,6 +92,11 @@ struct TapConv {
   // device word set to 1 by a wave of the wave-specialised SP kernels whose bounded poll of an LDS counter ran out (a
   // protocol bug: sp_sync.h); null = no report.  Read back by drs_unet_check_faults.
   unsigned* fault;
+  // "FL" operand images of this layer's weights (conv_mfma_fl.hip: fp16 main image + block-scaled fp6 cross-term image,
+  // derived from the packed split-bf16 images by drs_launch_fl_repack), or null: the layer then runs on the split-bf16
+  // kernel.  w2_fl: the same for the second input's 1x1 weights.
+  const void* w_fl;
+  const void* w2_fl;
 };
 
 struct DrsErr {
@@ -169,6 +174,11 @@ int drs_launch_pack_conv_mfma(const float* w, const float* b, const float* gamma
                               const float* rvar, float eps, void* dst_w, float* dst_b, int Cout, int Cin, int taps,
                               int transposed, int impl, hipStream_t s, int cout_src = 0, int flip_taps = 0, int co_off = 0,
                               int partial = 0, int perm = 0, int cin_total = 0, int cin_off = 0);
+
+// FL operand images (conv_mfma_fl.hip) of a layer from its packed split-bf16 images (hi image, then lo image); `flag`: device
+// word, bit 0 is set when a folded weight lies outside what fp16 holds (|w| > 60000, or a layer whose largest weight is under 2^-10)
+size_t drs_fl_image_bytes(int Cout, int Cin, int taps);
+int drs_launch_fl_repack(const void* sp_images, void* dst, int Cout, int Cin, int taps, unsigned* flag, hipStream_t s);
 
 int drs_launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int dst_cs, int dst_co,
                             hipStream_t s);

@@ -87,6 +87,11 @@ int drs_launch_tapconv_ws(const TapConv& d, const MfmaGeom& g, int impl, hipStre
 // wave-specialised 3x3 kernel over SP-format activations (conv_mfma_sp.hip); eligibility: drs_tapconv_sp_supported (drs_common.h)
 int drs_launch_tapconv_sp(const TapConv& d, const MfmaGeom& g, hipStream_t s);
 bool drs_tapconv_sp_f32out_supported(const TapConv& d, int impl);  // the same kernel with the fp32 channels-last epilogue
+// the same item / step protocol in the FL arithmetic (conv_mfma_fl.hip: fp16 main product + block-scaled fp6 cross terms of
+// tap pairs); DRS_FL_DECLINED: the launch prefers the split-bf16 kernel's 32-channel groups (fewer 64-channel items than half the CUs)
+#define DRS_FL_DECLINED (-1000)
+bool drs_tapconv_fl_supported(const TapConv& d, int impl);
+int drs_launch_tapconv_fl(const TapConv& d, const MfmaGeom& g, hipStream_t s);
 // the same structure for 8 x 8 images, four images per item (conv_mfma_sp8.hip): the bottleneck level of 64 x 64 models
 bool drs_tapconv_sp8_supported(const TapConv& d, int impl);
 int drs_launch_tapconv_sp8(const TapConv& d, hipStream_t s);

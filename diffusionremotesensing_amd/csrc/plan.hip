@@ -366,6 +366,11 @@ struct ConvLayer {
   bool transposed = false, mfma = false;
   bool out_sp = false;  // this layer stores its output in SP format: weights packed with the output-channel permutation
   size_t w_off = 0, b_off = 0;
+  // eval split-bf16 plans: "FL" operand images of a wide 3x3 / 1x1 layer (conv_mfma_fl.hip: fp16 main + block-scaled fp6 cross
+  // terms, derived from the packed split-bf16 images); fl_ok: the folded weights passed the pack-time fp16 range check
+  size_t fl_off = 0;
+  int fl_slot = -1;
+  bool fl_ok = false;
   int t_Z = -1;         // train plans: pre-BatchNorm tensor
   int t_Zsp = -1;       // train plans, 3x3 stride-1 layers: SP-format copy of dZ for the wave-specialised data-gradient convolution
   size_t stats_off = 0;  // train plans: saved batch mean / rstd (2 x Cout floats) in the workspace
@@ -401,6 +406,9 @@ struct DecStage {
   // and the att-half of up_convs.i packed as its own Ch -> Ch 3x3 convolution (no bias: it is in the composite's)
   bool upfuse = false;
   size_t uf_w_off = 0, uf_aux_off = 0, uf_edge_off = 0, ah_w_off = 0, ah_b_off = 0;
+  size_t ah_fl_off = 0;  // FL images of the att-half (stages 0 / 1)
+  int ah_fl_slot = -1;
+  bool ah_fl_ok = false;
   // stage 2: the `output` projection folded into the att-half's weights (conv3x3_direct_sp.hip, TapConv::proj): a 16-row image,
   // ah_tmp = the fp32 contraction it is packed from
   bool ah_proj = false;
@@ -451,6 +459,11 @@ struct drs_plan {
   // a small finishing kernel replaced per-block atomics onto the same 2 x Cout addresses: 512 blocks x 90 ns per serialised
   // atomic = a 46 us floor under every one of those launches, whatever the tensor size (round 3: 63 of them per step).
   size_t o_bn_sums = 0, bn_sums_bytes = 0, o_red = 0;
+  // FL arithmetic (conv_mfma_fl.hip) for the layers the wave-specialised SP kernel takes at 64 channels per item; per-layer range
+  // flags (device words, one per FL image: bit 0 = a folded weight outside what fp16 holds) are read back at pack time
+  bool fl = false;
+  int fl_slots = 0;
+  size_t o_fl_flags = 0;
   bool packed_ok = false;
   const void* packed_ptr = nullptr;
   unsigned* fault_ptr = nullptr;  // device word of the current forward's packed buffer (TapConv::fault)
@@ -716,6 +729,25 @@ extern "C" int drs_unet_plan_create(drs_plan** out, const drs_unet_config* cfg) 
           d.ufp_w_off = cur; cur += align_up(drs_upfuse_proj_weight_bytes(Cc));
         }
       }
+    }
+  }
+  {
+    static const bool fl_env = !(getenv("DRS_FL") && atoi(getenv("DRS_FL")) == 0);
+    p->fl = fl_env && p->sp;
+    if (p->fl) {
+      for (ConvLayer* L : p->convs)
+        if ((L->taps == 9 || L->taps == 1) && !L->transposed && L->Cout % 64 == 0 && L->Cin % 32 == 0) {
+          L->fl_off = cur; cur += align_up(drs_fl_image_bytes(L->Cout, L->Cin, L->taps));
+          L->fl_slot = p->fl_slots++;
+        }
+      for (int i = 0; i < 2; ++i) {
+        DecStage& d = p->dec[i];
+        if (d.upfuse && kUp[i + 1] % 64 == 0) {
+          d.ah_fl_off = cur; cur += align_up(drs_fl_image_bytes(kUp[i + 1], kUp[i + 1], 9));
+          d.ah_fl_slot = p->fl_slots++;
+        }
+      }
+      p->o_fl_flags = cur; cur += align_up((size_t)p->fl_slots * 8);  // [range flag, largest |weight|] per image
     }
   }
   for (PlanarConv* L : p->planars) {
@@ -1013,6 +1045,25 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
   }
   if ((rc = drs_launch_gather_copy(copies.data(), (int)copies.size(), s))) return rc;
   if ((rc = pack_queue.flush(s))) return rc;
+  if (plan->fl) {
+    // FL images from the split-bf16 images just packed + the range check of the folded weights: a layer whose weights fp16 cannot
+    // hold keeps the split-bf16 kernel (the flags cross to the host here: one stream synchronisation per pack of an eval plan)
+    unsigned* flags = (unsigned*)(base + plan->o_fl_flags);
+    DRS_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)plan->fl_slots * 8, s));
+    for (ConvLayer* L : plan->convs)
+      if (L->fl_off && L->mfma && (rc = drs_launch_fl_repack(base + L->w_off, base + L->fl_off, L->Cout, L->Cin, L->taps, flags + 2 * L->fl_slot, s)))
+        return rc;
+    for (int i = 0; i < 2; ++i) {
+      const DecStage& d = plan->dec[i];
+      if (d.ah_fl_off && (rc = drs_launch_fl_repack(base + d.ah_w_off, base + d.ah_fl_off, kUp[i + 1], kUp[i + 1], 9, flags + 2 * d.ah_fl_slot, s)))
+        return rc;
+    }
+    std::vector<unsigned> host((size_t)plan->fl_slots * 2 + 2, 0u);
+    DRS_CHECK_HIP(hipMemcpyAsync(host.data(), flags, (size_t)plan->fl_slots * 8, hipMemcpyDeviceToHost, s));
+    DRS_CHECK_HIP(hipStreamSynchronize(s));
+    for (ConvLayer* L : plan->convs) L->fl_ok = L->fl_off && L->mfma && host[2 * L->fl_slot] == 0u;
+    for (int i = 0; i < 2; ++i) plan->dec[i].ah_fl_ok = plan->dec[i].ah_fl_off && host[2 * plan->dec[i].ah_fl_slot] == 0u;
+  }
   DRS_CHECK_HIP(hipMemsetAsync(base + plan->o_zero, 0, 512, s));  // zero line + fault word
   plan->param_ptrs.assign(params, params + plan->params.size());
   plan->packed_ok = true;
@@ -1058,6 +1109,7 @@ static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d_in, hi
   // take get it from a separate pass over the first output
   TapConv d = d_in;
   d.fault = plan->fault_ptr;
+  if (L.fl_ok && !d.w_fl) d.w_fl = aligned_base(plan->packed_ptr) + L.fl_off;
   const bool split_out2 = d.out2 && !drs_tapconv_sp_supported(d, plan->cfg.impl) && !drs_tapconv_sp8_supported(d, plan->cfg.impl);
   if (split_out2) d.out2 = nullptr;
   std::string name = plan->params[L.w].name;
@@ -1310,6 +1362,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         d.in2 = xin; d.in2_cs = ci; d.in2_co = 0; d.Cin2 = ci; d.H2 = hh; d.W2 = ww;
         d.w2 = PW(rb.shortcut); d.bias2 = PB(rb.shortcut);
         d.in2_sp = sp;
+        if (rb.shortcut.fl_ok) d.w2_fl = pk + rb.shortcut.fl_off;
       } else {
         d.res = TP(plan->t_S[i]); d.res_cs = co; d.res_co = 0; d.res_sp = rb.shortcut.out_sp ? 1 : 0;
       }
@@ -1495,6 +1548,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         TapConv d = conv_desc(cat, B, 2 * lh, 2 * lw, Ch, Cc + Ch, Cc, (const float*)(pk + st.ah_w_off),
                               (const float*)(pk + st.ah_b_off), i < 2 ? TP(st.t_PA) : nullptr, Ch, Ch, 0, 3, 3, 1, 1);
         d.in_sp = 1; d.out_sp = 1; d.zero_line = zero_line; d.fault = plan->fault_ptr;
+        if (i < 2 && st.ah_fl_ok) d.w_fl = pk + st.ah_fl_off;
         const double ah_flops = conv_flops(d), ah_bytes = conv_bytes(d);  // (the reference's op, whatever form runs)
         if (i == 2 && st.ah_proj) {
           // projection folded into the weights (pack time): a Ch -> out_dim 3x3 convolution straight into the caller's tensor
