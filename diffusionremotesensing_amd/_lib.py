@@ -74,12 +74,17 @@ SIGNATURES = {
 _lib = None
 
 
+def lib_path():
+    """The shared object load() binds (DRS_LIB overrides the in-tree build: A/B experiments with builds of the same ABI)."""
+    return os.environ.get("DRS_LIB", LIB_PATH)
+
+
 def load():
     """Return the loaded library (cached).  Raises RuntimeError if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("DRS_LIB", LIB_PATH)  # A/B experiments with alternative builds of the same ABI
+    path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: the HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
@@ -93,7 +98,15 @@ def load():
     return lib
 
 
+class RangeFault(RuntimeError):
+    """DRS_ERR_RANGE from drs_unet_check_faults: an activation left fp16's range in the FL arithmetic; the plan has switched
+    itself to the split-bf16 kernels, the forwards since the last check must be run again."""
+
+
 def check(status, what):
     if status != 0:
         msg = load().drs_last_error()
-        raise RuntimeError(f"{what} failed with status {status}: {msg.decode() if msg else '?'}")
+        text = f"{what} failed with status {status}: {msg.decode() if msg else '?'}"
+        if status == 6:
+            raise RangeFault(text)
+        raise RuntimeError(text)

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdrs_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _newer(dst, srcs):
@@ -42,7 +42,12 @@ def build(force=False, verbose=True):
         list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
     if force or jobs or not _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # the C-ABI is the dynamic symbol table: drs_* (include/drs_hip.h, DRS_API) and nothing else - libstdc++'s inline
+        # templates carry default visibility whatever -fvisibility says, so the linker gets the list as well
+        vers = os.path.join(OBJ, "exports.map")
+        with open(vers, "w") as f:
+            f.write("{ global: drs_*; local: *; };\n")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vers, "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

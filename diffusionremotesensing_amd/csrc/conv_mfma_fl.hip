@@ -58,6 +58,14 @@ __device__ unsigned long long drs_fl_tl[64];
 #define FL_STAMP(i) do { } while (0)
 #endif
 
+// The movers' polls: LDS counters guarding LDS slots - the relaxed form (sp_sync.h).  The acquire form also drains the wave's
+// vector-memory counter: a mover would wait at every poll for the global loads it has just issued for LATER use.
+#ifdef DRS_FL_ACQPOLL
+#define FL_MPOLL sp_poll
+#else
+#define FL_MPOLL sp_poll_lds
+#endif
+
 struct FlGeom {
   static constexpr int IW = 18;
   static constexpr int WBUF = 41 * 1024;                     // one window buffer (328 lines of 128 bytes)
@@ -70,9 +78,13 @@ struct FlGeom {
 __device__ __forceinline__ void fl_bump_prio(sp_flag_ptr f, unsigned step_base, int lane) {  // (sp_bump_prio of conv_mfma_sp.hip)
   unsigned old = 0;
   if (lane == 0) old = __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef DRS_FL_NO_PRIO
   const unsigned rank = (unsigned)__builtin_amdgcn_readfirstlane((int)old) - step_base;
   if (rank >= 4) __builtin_amdgcn_s_setprio(2);
   else __builtin_amdgcn_s_setprio(0);
+#else
+  (void)old; (void)step_base;
+#endif
 }
 
 // ---- SP -> FL for HALF a pixel (16 channels of one 32-channel block) -------------------------------------------------------
@@ -81,9 +93,9 @@ __device__ __forceinline__ void fl_bump_prio(sp_flag_ptr f, unsigned step_base, 
 // Packed fp16 arithmetic: hi and lo are exact in fp16 (8 significant bits each; below fp16's subnormal step lo is truncated,
 // above its range cvt_pkrtz saturates at 65504), m = hi + lo is x' rounded ONCE to fp16, t = m - hi and r = lo - t are exact
 // (Fast2Sum, |hi| >= |lo|).  Block scale: the power of two that puts the block maximum into [3.75, 7.5] (e2m3's top binade).
-struct FlHalf { u32x4 m0, m1; unsigned qm[3], qr[3]; unsigned sm, sr; };
+struct FlHalf { u32x4 m0, m1; unsigned qm[3], qr[3]; unsigned sm, sr; bool over; };  // over: the block's maximum is not finite / at fp16's edge
 
-__device__ __forceinline__ unsigned fl_block_exp(const f16x2 (&v)[8]) {  // biased (E8M0) exponent of the lane pair's block scale
+__device__ __forceinline__ unsigned fl_block_exp(const f16x2 (&v)[8], bool& over) {  // biased (E8M0) exponent of the lane pair's block scale
   f16x2 mx = v[0], mn = v[0];
 #pragma unroll
   for (int d = 1; d < 8; ++d) { mx = __builtin_elementwise_max(mx, v[d]); mn = __builtin_elementwise_min(mn, v[d]); }
@@ -91,6 +103,7 @@ __device__ __forceinline__ unsigned fl_block_exp(const f16x2 (&v)[8]) {  // bias
   const unsigned ab = __builtin_bit_cast(unsigned, am);
   unsigned a16 = max(ab & 0xffffu, ab >> 16);
   a16 = max(a16, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a16, 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]: the pair's other lane
+  over = a16 >= 0x7bffu;  // 65504 (where cvt_pkrtz saturates), inf, NaN: fp16 does not hold this block
   const unsigned f = a16 >> 10, mant = a16 & 0x3ffu;
   // amax = (1 + mant / 1024) 2^(f - 15); scale 2^(f - 17) puts it into [4, 8); above 7.5 (mant > 0.875 * 1024) one more
   return max(f, 1u) + (127u - 17u) + (mant > 0x380u ? 1u : 0u);
@@ -115,10 +128,17 @@ __device__ __forceinline__ void fl_convert_half(const u32x4& h0, const u32x4& h1
     const f16x2 t = m[d] - hp;
     r[d] = lp - t;
   }
-  o.sm = fl_block_exp(m);
-  // |r| <= ulp(m) / 2 = 2^-11 |m| element by element, so 2^-11 of the main scale holds every remainder of the block (at most
-  // one bit coarser than a scale from the remainders' own maximum, for ~25 instructions less per half pixel)
+  o.sm = fl_block_exp(m, o.over);
+  // The remainders' scale from their own maximum.  (|r| <= 2^-11 |m| element by element, so 2^-11 of the main scale would hold
+  // them too, ~25 instructions cheaper per half pixel: measured on the trained-like fixture of tests/test_gpu_fl.py it costs
+  // accuracy - forward max-rel 7.8e-5 -> 1.05e-4, the largest remainder is on average well under its bound - and buys
+  // nothing measurable: DRS_FL_RSCALE_BOUND.)
+#ifdef DRS_FL_RSCALE_BOUND
   o.sr = o.sm > 12u ? o.sm - 11u : 1u;
+#else
+  bool over_r;
+  o.sr = fl_block_exp(r, over_r);
+#endif
   const u32x6 cm = fl_codes16(m, o.sm), cr = fl_codes16(r, o.sr);
 #pragma unroll
   for (int j = 0; j < 3; ++j) { o.qm[j] = cm[j]; o.qr[j] = cr[j]; }
@@ -313,6 +333,9 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
         fl_convert_half(ww[i][0], ww[i][1], ww[i][2], ww[i][3], f);
 #endif
         if ((keep >> i) & 1u) fl_store_half(buf + (pw + 4 * i) * 4096, f, hh != 0, a_m0, a_m1, a_w4, a_p46, a_w5, a_p57);
+#ifndef DRS_FL_COPYMOVER
+        if (f.over && d.fault) atomicOr(d.fault, 2u);  // (never in a healthy network: reported by drs_unet_check_faults as DRS_ERR_RANGE)
+#endif
         __builtin_amdgcn_sched_barrier(0);  // one round's temporaries at a time
       }
     };
@@ -368,7 +391,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
       }
       load_window(cur, 2, 3);
       FL_STAMP(0);
-      if (k >= 1) sp_poll(sCR, 8u * (unsigned)k, d.fault);  // every consumer holds column 0 of step k - 1 in registers
+      if (k >= 1) FL_MPOLL(sCR, 8u * (unsigned)k, d.fault);  // every consumer holds column 0 of step k - 1 in registers
       FL_STAMP(1);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // column 0 (and everything older: the constants, window rounds 0 / 1) has landed
       FL_STAMP(2);
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
         for (int j = 0; j < 3; ++j) wrA[3 + j] = *reinterpret_cast<const u32x4*>(cb2 + vo_c[j]);
       }
       FL_STAMP(3);
-      if (k >= 2) sp_poll(sWR + (k & 1), 8u * (unsigned)(k >> 1), d.fault);  // the consumers left the buffer in step k - 2
+      if (k >= 2) FL_MPOLL(sWR + (k & 1), 8u * (unsigned)(k >> 1), d.fault);  // the consumers left the buffer in step k - 2
       FL_STAMP(4);
       store_window(second, w3 ? 13 : 0, sWin + (k & 1) * WBUF);
       sp_wait_lds();
@@ -415,7 +438,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
       // (the rule behind a filling step: conv_sp_movers.inc)
       const bool after_fill = prev_fill;
       prev_fill = w3;
-      if (k >= 1 && (w3 || after_fill)) sp_poll(sCR + 1, 8u * (unsigned)k, d.fault);
+      if (k >= 1 && (w3 || after_fill)) FL_MPOLL(sCR + 1, 8u * (unsigned)k, d.fault);
       if (w3) {
         asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // column 1 has landed (behind it: 6 pieces of column 2, 8 window loads)
 #pragma unroll
@@ -424,7 +447,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
       sp_wait_lds();
       if (lane == 0) sp_bump(sCL + 1);
       FL_STAMP(7);
-      if (k >= 1 && (w3 || after_fill)) sp_poll(sCR + 2, 8u * (unsigned)k, d.fault);
+      if (k >= 1 && (w3 || after_fill)) FL_MPOLL(sCR + 2, 8u * (unsigned)k, d.fault);
       if (w3) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #pragma unroll
@@ -497,9 +520,17 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
     // cross-term products of one pair over the wave's four rows: the fragment of row r + 1 is requested before the
     // instructions of row r (the compiler barrier keeps the request order; left alone the scheduler hoists every read of a
     // column to its top and spills)
-#define FL_CROSS(XQ, W)                                                        \
+    // (FL_CROSS_P: row 0's fragment was requested by the caller, in front of a ring-slot release that only waits for the reads
+    //  issued BEFORE it - a release that drains the whole LDS queue costs a fragment latency with an idle pipe, five per step)
+#ifdef DRS_FL_FULLDRAIN  // experiment: every release drains the queue
+#define FL_WAIT_BUT(n) sp_wait_lds()
+#else
+#define FL_WAIT_BUT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#endif
+#define FL_CROSS(XQ, W) { const i32x8 x0_ = XQ(0); FL_CROSS_P(XQ, W, x0_) }
+#define FL_CROSS_P(XQ, W, X0)                                                  \
     {                                                                          \
-      i32x8 xq_ = XQ(0);                                                       \
+      i32x8 xq_ = X0;                                                          \
       _Pragma("unroll") for (int r = 0; r < RPW; ++r) {                        \
         i32x8 xn_ = xq_;                                                       \
         if (r + 1 < RPW) xn_ = XQ(r + 1);                                      \
@@ -510,8 +541,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
     }
     // fp16 products of kernel column `col` (weights wm[ky]); PRE: the main weight fragments of the next column (ring offset
     // `next`) replace wm[ky] as soon as the last window row that needs the old ones has been issued
-    auto main_col = [&](const char* buf, int col, bool pre, int next, unsigned ltarget) __attribute__((always_inline)) {
-      u32x4 af = mfrag(buf, col);
+    auto main_col = [&](const char* buf, int col, bool pre, int next, unsigned ltarget, u32x4 af) __attribute__((always_inline)) {  // af: the fragment of window row 0
 #pragma unroll
       for (int wr = 0; wr < RPW + 2; ++wr) {
         u32x4 afn = af;
@@ -587,10 +617,12 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
             for (int t = 0; t < NT; ++t) wm[ky][t] = wmain(G::RING0, ky, t);
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_full(G::RING0 + G::CROSS, t);
-          sp_wait_lds();
+          asm volatile("" ::: "memory");
+          const u32x4 af0 = mfrag(buf, 0);
+          FL_WAIT_BUT(1);  // everything but the window fragment just requested
           fl_bump_prio(sCR, 8u * (unsigned)k, lane);  // slot 0 is in registers
           FL_STAMP(2);
-          main_col(buf, 0, true, G::RING1, ltarget);
+          main_col(buf, 0, true, G::RING1, ltarget, af0);
           FL_STAMP(3);
 #define XQ0(r_) xq_row(buf, (r_) * IW)
           FL_CROSS(XQ0, wq)
@@ -603,16 +635,18 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
           i32x8 wq[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_full(G::RING1 + G::CROSS, t);
-          main_col(buf, 1, true, G::RING2, ltarget);
+          main_col(buf, 1, true, G::RING2, ltarget, mfrag(buf, 1));
           FL_STAMP(5);
 #define XQ1(r_) xq_row(buf, (r_) * IW + 1)
 #define XQ2(r_) xq_col(buf, ((r_) + 2) * IW)
           FL_CROSS(XQ1, wq)
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_full(G::RING1 + G::CROSS + 8192, t);
-          sp_wait_lds();
+          asm volatile("" ::: "memory");
+          const i32x8 x20 = XQ2(0);
+          FL_WAIT_BUT(2);
           fl_bump_prio(sCR + 1, 8u * (unsigned)k, lane);
-          FL_CROSS(XQ2, wq)
+          FL_CROSS_P(XQ2, wq, x20)
           FL_STAMP(6);
         }
         // ---- column 2: pair 3 = (c2k0 | c2k1), pair 4 = (c2k2 | -) ----
@@ -620,16 +654,18 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
           i32x8 wq[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_full(G::RING2 + G::CROSS, t);
-          main_col(buf, 2, false, 0, 0u);
+          main_col(buf, 2, false, 0, 0u, mfrag(buf, 2));
           FL_STAMP(7);
 #define XQ3(r_) xq_row(buf, (r_) * IW + 2)
 #define XQ4(r_) xq_half(buf, ((r_) + 2) * IW + 2)
           FL_CROSS(XQ3, wq)
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_half(G::RING2 + G::CROSS + 8192, t);
-          sp_wait_lds();
+          asm volatile("" ::: "memory");
+          const i32x8 x40 = XQ4(0);
+          FL_WAIT_BUT(2);
           fl_bump_prio(sCR + 2, 8u * (unsigned)k, lane);
-          FL_CROSS(XQ4, wq)
+          FL_CROSS_P(XQ4, wq, x40)
         }
         sp_wait_lds();  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
         if (lane == 0) sp_bump(sWR + (k & 1));

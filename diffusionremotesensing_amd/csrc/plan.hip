@@ -25,7 +25,7 @@ void DrsErr::set(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* drs_last_error(void) { return g_err; }
-extern "C" int drs_abi_version(void) { return 6; }
+extern "C" int drs_abi_version(void) { return 7; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -462,6 +462,7 @@ struct drs_plan {
   // FL arithmetic (conv_mfma_fl.hip) for the layers the wave-specialised SP kernel takes at 64 channels per item; per-layer range
   // flags (device words, one per FL image: bit 0 = a folded weight outside what fp16 holds) are read back at pack time
   bool fl = false;
+  bool fl_off = false;  // an activation left fp16's range (drs_unet_check_faults): the plan stays on the split-bf16 kernels
   int fl_slots = 0;
   size_t o_fl_flags = 0;
   bool packed_ok = false;
@@ -1109,7 +1110,7 @@ static int plan_conv(drs_plan* plan, const ConvLayer& L, const TapConv& d_in, hi
   // take get it from a separate pass over the first output
   TapConv d = d_in;
   d.fault = plan->fault_ptr;
-  if (L.fl_ok && !d.w_fl) d.w_fl = aligned_base(plan->packed_ptr) + L.fl_off;
+  if (L.fl_ok && !plan->fl_off && !d.w_fl) d.w_fl = aligned_base(plan->packed_ptr) + L.fl_off;
   const bool split_out2 = d.out2 && !drs_tapconv_sp_supported(d, plan->cfg.impl) && !drs_tapconv_sp8_supported(d, plan->cfg.impl);
   if (split_out2) d.out2 = nullptr;
   std::string name = plan->params[L.w].name;
@@ -1362,7 +1363,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         d.in2 = xin; d.in2_cs = ci; d.in2_co = 0; d.Cin2 = ci; d.H2 = hh; d.W2 = ww;
         d.w2 = PW(rb.shortcut); d.bias2 = PB(rb.shortcut);
         d.in2_sp = sp;
-        if (rb.shortcut.fl_ok) d.w2_fl = pk + rb.shortcut.fl_off;
+        if (rb.shortcut.fl_ok && !plan->fl_off) d.w2_fl = pk + rb.shortcut.fl_off;
       } else {
         d.res = TP(plan->t_S[i]); d.res_cs = co; d.res_co = 0; d.res_sp = rb.shortcut.out_sp ? 1 : 0;
       }
@@ -1548,7 +1549,7 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
         TapConv d = conv_desc(cat, B, 2 * lh, 2 * lw, Ch, Cc + Ch, Cc, (const float*)(pk + st.ah_w_off),
                               (const float*)(pk + st.ah_b_off), i < 2 ? TP(st.t_PA) : nullptr, Ch, Ch, 0, 3, 3, 1, 1);
         d.in_sp = 1; d.out_sp = 1; d.zero_line = zero_line; d.fault = plan->fault_ptr;
-        if (i < 2 && st.ah_fl_ok) d.w_fl = pk + st.ah_fl_off;
+        if (i < 2 && st.ah_fl_ok && !plan->fl_off) d.w_fl = pk + st.ah_fl_off;
         const double ah_flops = conv_flops(d), ah_bytes = conv_bytes(d);  // (the reference's op, whatever form runs)
         if (i == 2 && st.ah_proj) {
           // projection folded into the weights (pack time): a Ch -> out_dim 3x3 convolution straight into the caller's tensor
@@ -1676,7 +1677,15 @@ extern "C" int drs_unet_check_faults(drs_plan* plan, const void* packed, drs_str
   unsigned word = 0;
   DRS_CHECK_HIP(hipMemcpyAsync(&word, aligned_base(packed) + plan->o_fault, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
   DRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  DRS_REQUIRE(word == 0, DRS_ERR_HIP, "a wave-specialised kernel timed out on an LDS counter (protocol fault); results are incomplete");
+  DRS_REQUIRE((word & 1u) == 0, DRS_ERR_HIP, "a wave-specialised kernel timed out on an LDS counter (protocol fault); results are incomplete");
+  if (word & 2u) {  // the FL kernel's movers met an activation block whose maximum fp16 cannot hold
+    plan->fl_off = true;
+    DRS_CHECK_HIP(hipMemsetAsync(aligned_base(packed) + plan->o_fault, 0, 4, (hipStream_t)stream));
+    DRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    DrsErr::set("an activation left fp16's range in the FL arithmetic: the forward(s) since the last check are invalid; this plan "
+                "now runs the split-bf16 kernels - run the forward / chain again");
+    return DRS_ERR_RANGE;
+  }
   return DRS_OK;
 }
 

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .. import dist as drs_dist
 from .. import hip_ops
-from ..train_diffusion_superres import Diffusion as _SuperresDiffusion
+from ..train_diffusion_superres import Diffusion as _SuperresDiffusion, retry_on_range_fault
 from .UNet_model_generation import Residual_Attention_UNet_generation
 
 
@@ -38,6 +38,7 @@ class Diffusion(_SuperresDiffusion):
     def _predict(self, net, x_t, t, cond):
         return net(x_t, t, cond)
 
+    @retry_on_range_fault
     def sample(self, n, model, target_class=None, cfg_scale=3, input_channels=3, generate_video=False,
                noise_source=None):
         """Reference :206-259."""

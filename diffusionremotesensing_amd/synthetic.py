@@ -120,3 +120,69 @@ def canonical_key(key):
 def _is_bn_key(key):
     k = canonical_key(key)
     return ("batch_norm" in k) or (".result.1." in k)
+
+
+# BatchNorm registration (canonical prefix) -> the convolution in front of it
+_BN_CONV = (
+    (".batch_norm1", ".conv1.0"), (".batch_norm2", ".conv2.0"), (".shortcut_batch_norm", ".shortcut_conv.0"),
+    (".result.1", ".result.0"),
+)
+
+
+def _conv_of_bn(bn_prefix):
+    for bn, conv in _BN_CONV:
+        if bn_prefix.endswith(bn):
+            return bn_prefix[: -len(bn)] + conv
+    if bn_prefix.endswith(".batch_norm"):  # gating_signals.i / ups.i
+        return bn_prefix[: -len(".batch_norm")] + ".conv"
+    raise KeyError(bn_prefix)
+
+
+def trained_like_state_dict(template, calibrate, seed=0, bare_gain=1.0, tweak=None):
+    """Seeded weights with the dynamic range a TRAINED snapshot folds into the kernels' operands, which freshly seeded ones
+    (running_var 0.5 .. 1.5, gamma 0.6 .. 1.4) never show:
+      * every convolution in front of a BatchNorm has its output channels scaled by 10^-1.5 .. 1 (log-uniform), so the
+        statistics the BatchNorm holds span three decades (running_var down to ~1e-3 and below) and the folded weights
+        gamma / sqrt(var) * w carry the inverse of it;
+      * gamma 0.1 .. 10 (log-uniform), beta ~ N(0, 0.3);
+      * the bare convolutions (`downs.*`, `up_convs.*`: no BatchNorm behind them) scaled by `bare_gain`: their outputs - inputs
+        of the next wide 3x3 layers - grow by that factor;
+      * `tweak(sd)`, if given, edits the weights further (in place) before the calibration;
+      * running_mean / running_var are then CALIBRATED: `calibrate(sd)` runs a train-mode forward of the oracle on a batch and
+        returns {bn_prefix: (batch_mean, batch_var)}, as the running averages of a converged training would be.
+    All BatchNorm aliases of a registration receive the same values."""
+    sd = seeded_state_dict(template, seed)
+    groups = {}
+    for key in sd:
+        if _is_bn_key(key):
+            groups.setdefault(canonical_key(key).rsplit(".", 1)[0], []).append(key)
+    for bn, keys in groups.items():
+        C = sd[bn + ".weight"].shape[0]
+        s = 10.0 ** tensor_uniform(bn + ".tl.s", (C,), seed, -1.5, 0.0)
+        gamma = 10.0 ** tensor_uniform(bn + ".tl.g", (C,), seed, -1.0, 1.0)
+        beta = tensor_normal(bn + ".tl.b", (C,), seed, std=0.3)
+        conv = _conv_of_bn(bn)
+        sd[conv + ".weight"] = sd[conv + ".weight"] * s.view(-1, 1, 1, 1)
+        sd[conv + ".bias"] = sd[conv + ".bias"] * s
+        for key in keys:
+            leaf = key.rsplit(".", 1)[-1]
+            if leaf == "weight":
+                sd[key] = gamma.clone()
+            elif leaf == "bias":
+                sd[key] = beta.clone()
+    if bare_gain != 1.0:
+        for key in sd:
+            if key.startswith(("downs.", "up_convs.")):
+                sd[key] = sd[key] * bare_gain
+    if tweak is not None:
+        tweak(sd)
+    stats = calibrate(sd)
+    for bn, keys in groups.items():
+        mean, var = stats[bn]
+        for key in keys:
+            leaf = key.rsplit(".", 1)[-1]
+            if leaf == "running_mean":
+                sd[key] = mean.clone()
+            elif leaf == "running_var":
+                sd[key] = var.clone()
+    return sd

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import dist as drs_dist
 from . import hip_ops
-from .train_diffusion_superres import Diffusion as _SuperresDiffusion
+from .train_diffusion_superres import Diffusion as _SuperresDiffusion, retry_on_range_fault
 from .UNet_model_SAR_TO_NDVI import Residual_Attention_UNet_SAR_TO_NDVI
 
 
@@ -29,6 +29,7 @@ class Diffusion(_SuperresDiffusion):
     def _predict(self, net, x_t, t, cond):
         return net(x_t, t, cond)
 
+    @retry_on_range_fault
     def sample(self, n, model, SAR_img, NDVI_channels=1, generate_video=False, noise_source=None):
         """Reference :204-249.  One (SAR_channels, S, S) image conditions all n chains; its encoder branch is computed
         once per chain instead of once per step.  `noise_source(i, shape)` as in the super-resolution sampler."""

@@ -19,11 +19,27 @@ import torch
 import torch.nn as nn
 
 from . import dist as drs_dist
-from . import hip_ops
+from . import _lib, hip_ops
 from .optim import FusedAdam
 from .UNet_model_superres import EMA, Residual_Attention_UNet_superres
 
 _DEGRADATIONS = ("downblur", "bsrgan", "downblurnoise")
+
+
+
+def retry_on_range_fault(fn):
+    """`sample` chains end with engine.check_faults(); DRS_ERR_RANGE (an activation left fp16's range in the FL arithmetic,
+    csrc/conv_mfma_fl.hip) invalidates the chain and switches the plan to the split-bf16 kernels: run it once more."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except _lib.RangeFault as e:
+            print(f"[drs] {e}\n[drs] re-running the chain on the split-bf16 kernels")
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 class Diffusion:
@@ -83,6 +99,7 @@ class Diffusion:
         return torch.randint(low=1, high=self.noise_steps, size=(n,))
 
     # -- reverse process (reference :207-255) ---------------------------------------------------
+    @retry_on_range_fault
     def sample(self, n, model, lr_img, input_channels=3, generate_video=False, noise_source=None):
         """`noise_source(i, shape)`, when given, supplies x_T (i == noise_steps) and the per-step noise z_i
         instead of torch.randn — used to drive this sampler and the oracle with identical noise."""

@@ -24,6 +24,10 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table
+ * (tests/test_abi_symbols.py checks exported == declared). */
+#define DRS_API __attribute__((visibility("default")))
+
 typedef void* drs_stream_t; /* hipStream_t; NULL = default stream */
 typedef struct drs_plan drs_plan;
 
@@ -33,7 +37,10 @@ enum {
   DRS_ERR_SHAPE = 2,     /* shape the kernels do not support (e.g. H,W not divisible by 8) */
   DRS_ERR_HIP = 3,       /* a HIP runtime call failed; see drs_last_error() */
   DRS_ERR_WORKSPACE = 4, /* workspace / packed buffer too small */
-  DRS_ERR_STATE = 5      /* plan used before its weights were packed */
+  DRS_ERR_STATE = 5,     /* plan used before its weights were packed */
+  DRS_ERR_RANGE = 6      /* drs_unet_check_faults: an activation left the range of the fp16 main operand of the FL arithmetic
+                          * (csrc/conv_mfma_fl.hip) during a forward since the last check: that forward's result is invalid; the
+                          * plan has switched itself to the split-bf16 kernels - run the forward / the chain again */
 };
 
 /* Convolution implementations (same arithmetic, different kernels). */
@@ -51,9 +58,9 @@ enum {
  * process from the environment (A/B experiments and the variant tests; unset = the shipped defaults): DRS_SP,
  * DRS_WS, DRS_D3K, DRS_S2K, DRS_NWG, DRS_BLOCKS_PER_CU, DRS_FUSE_GATE, DRS_UPFUSE, DRS_XT_ONLY, DRS_RB0, DRS_DOWNK, DRS_SP8, DRS_CONCURRENT, DRS_DEBUG_FLAGS, DRS_TRAIN_BWD_IMPL, DRS_TRAIN_WGRAD_IMPL.
  * Human-readable message for the last non-zero status returned on this thread. */
-const char* drs_last_error(void);
+DRS_API const char* drs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
-int drs_abi_version(void);  /* 6 */
+DRS_API int drs_abi_version(void);  /* 7 */
 
 /* ------------------------------------------------------------------------------------------
  * Diffusion arithmetic
@@ -62,21 +69,21 @@ int drs_abi_version(void);  /* 6 */
 /* Forward process q(x_t | x_0): x_t[i] = sqrt(alpha_hat[t[i]]) * x0[i] + sqrt(1 - alpha_hat[t[i]]) * eps[i]
  * for n images of `chw` elements each.  `eps` is supplied by the caller (torch.randn_like).
  * Replaces Diffusion.noise_images, train_diffusion_superres.py:171-190. */
-int drs_noise_images(const float* x0, const float* eps, const int64_t* t, const float* alpha_hat,
+DRS_API int drs_noise_images(const float* x0, const float* eps, const int64_t* t, const float* alpha_hat,
                      int noise_steps, float* x_t, int n, int64_t chw, drs_stream_t stream);
 
 /* One ancestral sampling update, in place on x:
  *   x = 1/sqrt(alpha[t]) * (x - (1 - alpha[t]) / sqrt(1 - alpha_hat[t]) * eps_pred) + sqrt(beta[t]) * noise
  * `noise` may be NULL (last step: reference uses zeros).  `t` is one scalar timestep shared by the
  * batch (the reference builds ones(n)*i).  Replaces the loop body at train_diffusion_superres.py:240-249. */
-int drs_sampler_step(float* x, const float* eps_pred, const float* noise, int t, const float* alpha,
+DRS_API int drs_sampler_step(float* x, const float* eps_pred, const float* noise, int t, const float* alpha,
                      const float* alpha_hat, const float* beta, int noise_steps, int64_t numel,
                      drs_stream_t stream);
 
 /* Same update with classifier-free guidance folded in: eps = lerp(eps_uncond, eps_cond, cfg_scale) with torch.lerp's
  * formula (weight >= 0.5: end - (end - start) * (1 - weight)), then the ancestral update above.
  * Replaces generate_new_imgs/train_diffusion_generation.py:236-249. */
-int drs_sampler_step_cfg(float* x, const float* eps_cond, const float* eps_uncond, float cfg_scale, const float* noise,
+DRS_API int drs_sampler_step_cfg(float* x, const float* eps_cond, const float* eps_uncond, float cfg_scale, const float* noise,
                          int t, const float* alpha, const float* alpha_hat, const float* beta, int noise_steps,
                          int64_t numel, drs_stream_t stream);
 
@@ -94,7 +101,7 @@ typedef struct drs_adam_tensor {
   int64_t n;
   int64_t step;
 } drs_adam_tensor;
-int drs_adam_multi(const drs_adam_tensor* table, int ntensors, int64_t max_numel, double lr, double beta1, double beta2,
+DRS_API int drs_adam_multi(const drs_adam_tensor* table, int ntensors, int64_t max_numel, double lr, double beta1, double beta2,
                    double eps, drs_stream_t stream);
 
 /* Multi-tensor exponential moving average of the parameters, ONE launch for all tensors:
@@ -110,7 +117,7 @@ typedef struct drs_ema_tensor {
   const void* cur;
   int64_t n;
 } drs_ema_tensor;
-int drs_ema_multi(const drs_ema_tensor* table, int ntensors, int64_t max_numel, double beta, int mode, drs_stream_t stream);
+DRS_API int drs_ema_multi(const drs_ema_tensor* table, int ntensors, int64_t max_numel, double beta, int mode, drs_stream_t stream);
 
 /* Gaussian-weighted blend of n overlapping super-resolved tiles into one image, normalised and clamped to [0,1]:
  *   out[c][y][x] = clamp( sum_i w[y-y0_i][x-x0_i] * tiles[i][c][y-y0_i][x-x0_i] / sum_i w[y-y0_i][x-x0_i], 0, 1 )
@@ -119,7 +126,7 @@ int drs_ema_multi(const drs_ema_tensor* table, int ntensors, int64_t max_numel, 
  * Returns DRS_ERR_SHAPE through `uncovered` (device int, may be NULL) != 0 semantics: the count of output pixels no
  * tile covers is written there (the reference asserts pixel_count != 0).
  * Replaces the loop + normalisation of split_aggregation_sampling.aggregation_sampling, Aggregation_Sampling.py:90-116. */
-int drs_aggregate_tiles(const float* tiles, const int32_t* origins, const float* weight, float* out, int32_t* uncovered,
+DRS_API int drs_aggregate_tiles(const float* tiles, const int32_t* origins, const float* weight, float* out, int32_t* uncovered,
                         int n, int C, int S, int H, int W, drs_stream_t stream);
 
 /* "DownBlur" degradation of the super-resolution data feed on the device, bit-exact with the Pillow calls of the
@@ -127,15 +134,15 @@ int drs_aggregate_tiles(const float* tiles, const int32_t* origins, const float*
  *   hr: (N,C,H,W) uint8;  x_lr: (N,C,out_h,out_w) float32 in [0,1];  y_hr: (N,C,H,W) float32 or NULL;
  *   blur_radius: Pillow's GaussianBlur radius (0 = no blur);  scratch: drs_downblur_scratch_bytes(...) bytes.
  * Replaces get_data_superres.__getitem__, utils.py:140-158 (Gauss_noise=False). */
-size_t drs_downblur_scratch_bytes(int N, int C, int H, int W, int out_h, int out_w);
-int drs_downblur_u8(const uint8_t* hr, int N, int C, int H, int W, int out_h, int out_w, float blur_radius, float* x_lr,
+DRS_API size_t drs_downblur_scratch_bytes(int N, int C, int H, int W, int out_h, int out_w);
+DRS_API int drs_downblur_u8(const uint8_t* hr, int N, int C, int H, int W, int out_h, int out_w, float blur_radius, float* x_lr,
                     float* y_hr, void* scratch, size_t scratch_bytes, drs_stream_t stream);
 
 /* The device half of the dataset item's `Gauss_noise=True` step: x (N,C,H,W) float32 += noise (N,H,W,C) float32, clipped to
  * [0, 1], in place.  The noise is drawn on the host from the generators the reference uses (Python `random`, numpy's global
  * generator), in its order, by diffusionremotesensing_amd.degradation.reference_noise.
  * Replaces the add and the clip of add_Gaussian_noise, utils.py:27-36 (called at utils.py:163-164). */
-int drs_add_noise_clip_f32(float* x, const float* noise_nhwc, int N, int C, int H, int W, drs_stream_t stream);
+DRS_API int drs_add_noise_clip_f32(float* x, const float* noise_nhwc, int N, int C, int H, int W, drs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (used by the parity tests for every convolution flavour
@@ -149,9 +156,9 @@ int drs_add_noise_clip_f32(float* x, const float* noise_nhwc, int N, int C, int 
  * transposed 3x3 s2 p1 out_pad 1.  `relu` != 0 applies max(.,0).
  * workspace: device scratch of at least drs_conv2d_workspace_bytes() bytes.
  * Replaces nn.Conv2d / nn.ConvTranspose2d calls at UNet_model_superres.py:70-85,123-141,184-185,217,298,321,325. */
-size_t drs_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
+DRS_API size_t drs_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
                                   int pad, int transposed, int out_pad);
-int drs_conv2d_nchw(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
+DRS_API int drs_conv2d_nchw(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
                     int Cout, int KH, int KW, int stride, int pad, int transposed, int out_pad, int relu,
                     void* workspace, size_t workspace_bytes, int impl, drs_stream_t stream);
 
@@ -165,21 +172,21 @@ int drs_conv2d_nchw(const float* x, const float* w, const float* b, float* y, in
  *   fuse_w (fuse_dim,Ch) / fuse_b (fuse_dim): with Ch == 32, y is (N,fuse_dim,2LH,2LW) = conv1x1(y32) (the UNet's `output`)
  * Cc, Ch multiples of 32.  Replaces UpConvBlock.transform + torch.cat + up_convs[i] (+ output),
  * UNet_model_superres.py:206-207,376-377,379. */
-size_t drs_upconv_fused_workspace_bytes(int N, int Cc, int Ch, int LH, int LW);
-int drs_upconv_fused_nchw(const float* h, const float* att, const float* t_w, const float* t_b, const float* v_w,
+DRS_API size_t drs_upconv_fused_workspace_bytes(int N, int Cc, int Ch, int LH, int LW);
+DRS_API int drs_upconv_fused_nchw(const float* h, const float* att, const float* t_w, const float* t_b, const float* v_w,
                           const float* v_b, const float* post2, const float* fuse_w, const float* fuse_b, int fuse_dim,
                           float* y, float* y2, int N, int Cc, int Ch, int LH, int LW, void* workspace, size_t workspace_bytes,
                           drs_stream_t stream);
 
 /* y = F.interpolate(x, scale_factor=scale, mode='bicubic') (align_corners=False, A=-0.75, border clamp),
  * integer scale.  x: (N,C,H,W) -> y: (N,C,H*scale,W*scale).  Replaces UNet_model_superres.py:349. */
-int drs_bicubic_upsample_nchw(const float* x, float* y, int N, int C, int H, int W, int scale,
+DRS_API int drs_bicubic_upsample_nchw(const float* x, float* y, int N, int C, int H, int W, int scale,
                               drs_stream_t stream);
 
 /* out[b, :] = relu(W2 @ silu(W1 @ posenc(t[b]) + b1) + b2), posenc = [sin(t*f_j) | cos(t*f_j)], j < dim_in/2,
  * inv_freq[j] = f_j supplied by the caller (dim_in/2 floats).  W1: (dim_out, dim_in), W2: (dim_out, dim_out).
  * Replaces pos_encoding + time_mlp + ReLU, UNet_model_superres.py:328-335,143-151,161 (and :187-199). */
-int drs_time_mlp(const int64_t* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
+DRS_API int drs_time_mlp(const int64_t* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
                  const float* b2, float* out, int B, int dim_in, int dim_out, drs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -218,21 +225,21 @@ typedef struct drs_unet_config {
  * pre-normalisation tensor is kept.  Reference: model.train() + nn.BatchNorm2d defaults (eps 1e-5, momentum 0.1). */
 #define DRS_PLAN_TRAIN 2
 
-int drs_unet_plan_create(drs_plan** plan, const drs_unet_config* cfg);
-void drs_unet_plan_destroy(drs_plan* plan);
+DRS_API int drs_unet_plan_create(drs_plan** plan, const drs_unet_config* cfg);
+DRS_API void drs_unet_plan_destroy(drs_plan* plan);
 
 /* The state_dict entries the plan consumes, in the order drs_unet_pack_weights expects. */
-int drs_unet_num_params(const drs_plan* plan);
-const char* drs_unet_param_name(const drs_plan* plan, int i);
-int64_t drs_unet_param_numel(const drs_plan* plan, int i);
+DRS_API int drs_unet_num_params(const drs_plan* plan);
+DRS_API const char* drs_unet_param_name(const drs_plan* plan, int i);
+DRS_API int64_t drs_unet_param_numel(const drs_plan* plan, int i);
 
-size_t drs_unet_packed_bytes(const drs_plan* plan);
-size_t drs_unet_workspace_bytes(const drs_plan* plan);
+DRS_API size_t drs_unet_packed_bytes(const drs_plan* plan);
+DRS_API size_t drs_unet_workspace_bytes(const drs_plan* plan);
 
 /* Fold BatchNorm (eval) into conv weights/biases and re-lay every weight for the kernels.
  * params[i] = device pointer of state_dict[drs_unet_param_name(i)] (fp32).  inv_freq = 50 floats (host
  * pointer) computed like reference :329-331.  Must be re-run whenever the parameters change. */
-int drs_unet_pack_weights(drs_plan* plan, const void* const* params, const float* inv_freq_host, void* packed,
+DRS_API int drs_unet_pack_weights(drs_plan* plan, const void* const* params, const float* inv_freq_host, void* packed,
                           size_t packed_bytes, drs_stream_t stream);
 
 /* eps_pred = model(x, t, lr_img, magnification).  x: (batch,C,H,W)  t: (batch) int64
@@ -241,21 +248,21 @@ int drs_unet_pack_weights(drs_plan* plan, const void* const* params, const float
  * :345-353) and reuse the one left in the workspace by the previous call — valid while lr_img and the weights
  * are unchanged, i.e. inside one Diffusion.sample chain (the reference recomputes it every step). */
 #define DRS_FWD_REUSE_COND 1
-int drs_unet_forward(drs_plan* plan, const void* packed, const float* x, const int64_t* t, const float* lr_img,
+DRS_API int drs_unet_forward(drs_plan* plan, const void* packed, const float* x, const int64_t* t, const float* lr_img,
                      float* out, void* workspace, size_t workspace_bytes, int flags, drs_stream_t stream);
 /* Same, with class labels for the GENERATION variant: labels = int64[label_batch] (label_batch == batch or 1,
  * broadcast) or NULL for the unconditional forward (reference forward(x, timestep, y=None)). */
-int drs_unet_forward_labels(drs_plan* plan, const void* packed, const float* x, const int64_t* t, const float* cond,
+DRS_API int drs_unet_forward_labels(drs_plan* plan, const void* packed, const float* x, const int64_t* t, const float* cond,
                             const int64_t* labels, int label_batch, float* out, void* workspace,
                             size_t workspace_bytes, int flags, drs_stream_t stream);
 
 /* Introspection for block-level parity tests: intermediate activations left in the workspace by the last
  * forward, converted to NCHW into `dst`.  Names follow the reference module tree
  * ("conv_blocks.0", "downs.1", "attention_blocks.2", ...). */
-int drs_unet_num_tensors(const drs_plan* plan);
-const char* drs_unet_tensor_name(const drs_plan* plan, int i);
-int drs_unet_tensor_shape(const drs_plan* plan, int i, int* n, int* c, int* h, int* w);
-int drs_unet_read_tensor(const drs_plan* plan, int i, const void* workspace, float* dst_nchw, drs_stream_t stream);
+DRS_API int drs_unet_num_tensors(const drs_plan* plan);
+DRS_API const char* drs_unet_tensor_name(const drs_plan* plan, int i);
+DRS_API int drs_unet_tensor_shape(const drs_plan* plan, int i, int* n, int* c, int* h, int* w);
+DRS_API int drs_unet_read_tensor(const drs_plan* plan, int i, const void* workspace, float* dst_nchw, drs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training step, backward half (reference loop body train_diffusion_superres.py:388-393: loss.backward()).
@@ -265,12 +272,12 @@ int drs_unet_read_tensor(const drs_plan* plan, int i, const void* workspace, flo
  * Requires a DRS_PLAN_TRAIN plan with lr_batch == batch and the workspace exactly as the last drs_unet_forward
  * (train mode) on this plan left it; `packed_bwd` is scratch for the re-packed (transposed) weights.
  * ------------------------------------------------------------------------------------------ */
-size_t drs_unet_packed_bwd_bytes(const drs_plan* plan);
-int drs_unet_backward(drs_plan* plan, const void* packed, void* packed_bwd, size_t packed_bwd_bytes, const float* x,
+DRS_API size_t drs_unet_packed_bwd_bytes(const drs_plan* plan);
+DRS_API int drs_unet_backward(drs_plan* plan, const void* packed, void* packed_bwd, size_t packed_bwd_bytes, const float* x,
                       const int64_t* t, const float* dout, float* const* grads, void* workspace, size_t workspace_bytes,
                       drs_stream_t stream);
 /* Same for a forward that was given class labels (GENERATION variant): also produces d(label_emb.weight). */
-int drs_unet_backward_labels(drs_plan* plan, const void* packed, void* packed_bwd, size_t packed_bwd_bytes,
+DRS_API int drs_unet_backward_labels(drs_plan* plan, const void* packed, void* packed_bwd, size_t packed_bwd_bytes,
                              const float* x, const int64_t* t, const int64_t* labels, int label_batch,
                              const float* dout, float* const* grads, void* workspace, size_t workspace_bytes,
                              drs_stream_t stream);
@@ -281,18 +288,18 @@ int drs_unet_backward_labels(drs_plan* plan, const void* packed, void* packed_bw
 /* Synchronises `stream` and returns DRS_ERR_HIP if a wave of the wave-specialised kernels gave up waiting on an LDS
  * counter since the weights were last packed into `packed` (a protocol bug; such a wave records it and ends instead of
  * hanging or faulting the device: csrc/sp_sync.h).  Debug / test aid; a healthy run never sets it. */
-int drs_unet_check_faults(drs_plan* plan, const void* packed, drs_stream_t stream);
+DRS_API int drs_unet_check_faults(drs_plan* plan, const void* packed, drs_stream_t stream);
 
-int drs_unet_profile_enable(drs_plan* plan, int on);
-int drs_unet_profile_num_ops(const drs_plan* plan);
-int drs_unet_profile_read(drs_plan* plan, int i, char* name, int name_len, float* ms, double* flops, double* bytes);
+DRS_API int drs_unet_profile_enable(drs_plan* plan, int on);
+DRS_API int drs_unet_profile_num_ops(const drs_plan* plan);
+DRS_API int drs_unet_profile_read(drs_plan* plan, int i, char* name, int name_len, float* ms, double* flops, double* bytes);
 /* Launch log of the last PROFILED forward (ABI 6): one entry per kernel the forward launched, in host launch order, with
  * the kernel's name as the runtime reports it (demangled) and the op of the schedule that issued it ("" for launches
  * outside any op bracket, e.g. the per-image gate-bias tables).  A rocprofv3 counter pass over the same process sees
  * exactly these dispatches, in this order, as the process's last launches: tools/collect_pmc.py joins the two and
  * refuses to attribute bytes if a kernel name differs. */
-int drs_unet_profile_num_launches(const drs_plan* plan);
-int drs_unet_profile_launch(const drs_plan* plan, int i, char* op, int op_len, char* kernel, int kernel_len);
+DRS_API int drs_unet_profile_num_launches(const drs_plan* plan);
+DRS_API int drs_unet_profile_launch(const drs_plan* plan, int i, char* op, int op_len, char* kernel, int kernel_len);
 
 #ifdef __cplusplus
 }
