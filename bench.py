@@ -125,7 +125,8 @@ def _build_workload(wl, impl, dev, rank, multi):
         timpl = os.environ.get("DRS_TRAIN_IMPL", "mfma_f32")
         return (step, "train_steps/s (16 images per rank)", 16, 3 * 454.39,
                 f"BASELINE configs[2] per-rank shape: superres 256x256 train step, batch 16 per GPU, MSE, Adam, train_impl={timpl}",
-                "f32 (v_mfma_f32_16x16x4_f32)" if timpl == "mfma_f32" else DTYPE.get(timpl, timpl), m)
+                ("forward f32 (v_mfma_f32_16x16x4_f32); backward: data gradients split bf16 x3 (SP-format dZ), weight gradients "
+                 "bf16 MFMA on split operands, fp32 accumulate") if timpl == "mfma_f32" else DTYPE.get(timpl, timpl), m)
     if wl == "sar":
         from diffusionremotesensing_amd.train_diffusion_SAR_TO_NDVI import Diffusion
         from diffusionremotesensing_amd.UNet_model_SAR_TO_NDVI import Residual_Attention_UNet_SAR_TO_NDVI

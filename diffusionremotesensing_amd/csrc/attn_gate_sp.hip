@@ -120,8 +120,8 @@ __global__ __launch_bounds__(NT == 2 ? 1024 : 512, 1) void attn_gate_sp_kernel(A
       float v[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = fmaxf(acc[2 * cc][j] + bb[j], 0.f);
-        v[4 + j] = fmaxf(acc[2 * cc + 1][j] + bb[4 + j], 0.f);
+        v[j] = drs_maxf(acc[2 * cc][j] + bb[j], 0.f);
+        v[4 + j] = drs_maxf(acc[2 * cc + 1][j] + bb[4 + j], 0.f);
       }
       u32x4 h, l;
       drs_sp_split8(v, h, l);
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(NT == 2 ? 1024 : 512, 1) void attn_gate_sp_kernel(A
       const int ch = (tt >> 1) * 32 + kg * 8 + (tt & 1) * 4;
       const float4 bs = *reinterpret_cast<const float4*>(sB + Ch + ch);
       const float4 wp = *reinterpret_cast<const float4*>(sB + 2 * Ch + ch);
-      dot += fmaxf(acc[tt][0] + bs.x, 0.f) * wp.x + fmaxf(acc[tt][1] + bs.y, 0.f) * wp.y +
-             fmaxf(acc[tt][2] + bs.z, 0.f) * wp.z + fmaxf(acc[tt][3] + bs.w, 0.f) * wp.w;
+      dot += drs_maxf(acc[tt][0] + bs.x, 0.f) * wp.x + drs_maxf(acc[tt][1] + bs.y, 0.f) * wp.y +
+             drs_maxf(acc[tt][2] + bs.z, 0.f) * wp.z + drs_maxf(acc[tt][3] + bs.w, 0.f) * wp.w;
     }
     dot += __shfl_xor(dot, 16);
     dot += __shfl_xor(dot, 32);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide2_kernel(AttnGateDesc d)
       for (int b = 0; b < 4; ++b) {
         const float* bsrc = (d.b_gate_img ? d.b_gate_img + (size_t)nn[b] * Ch : d.b_gate) + ch0;  // (both global: no flat load)
         const float4 bb = *reinterpret_cast<const float4*>(bsrc);
-        const float v[4] = {fmaxf(acc[b][0] + bb.x, 0.f), fmaxf(acc[b][1] + bb.y, 0.f), fmaxf(acc[b][2] + bb.z, 0.f), fmaxf(acc[b][3] + bb.w, 0.f)};
+        const float v[4] = {drs_maxf(acc[b][0] + bb.x, 0.f), drs_maxf(acc[b][1] + bb.y, 0.f), drs_maxf(acc[b][2] + bb.z, 0.f), drs_maxf(acc[b][3] + bb.w, 0.f)};
         unsigned h2[2], l2[2];
         drs_sp_split4(v, h2, l2);
         char* line = sG + ((b * NG + G) * 16 + lr) * 128;
@@ -405,8 +405,8 @@ __global__ __launch_bounds__(512, 1) void attn_gate_wide2_kernel(AttnGateDesc d)
       const float4 bsum = *reinterpret_cast<const float4*>(sB + ch0), wp = *reinterpret_cast<const float4*>(sB + Ch + ch0);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        float dot = fmaxf(acc[b][0] + bsum.x, 0.f) * wp.x + fmaxf(acc[b][1] + bsum.y, 0.f) * wp.y +
-                    fmaxf(acc[b][2] + bsum.z, 0.f) * wp.z + fmaxf(acc[b][3] + bsum.w, 0.f) * wp.w;
+        float dot = drs_maxf(acc[b][0] + bsum.x, 0.f) * wp.x + drs_maxf(acc[b][1] + bsum.y, 0.f) * wp.y +
+                    drs_maxf(acc[b][2] + bsum.z, 0.f) * wp.z + drs_maxf(acc[b][3] + bsum.w, 0.f) * wp.w;
         dot += __shfl_xor(dot, 16);
         dot += __shfl_xor(dot, 32);
         if (kg == 0) sPsi[wave * 64 + b * 16 + lr] = dot;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     float y[4] = {(v.x - m.x) * r.x * g.x + b.x, (v.y - m.y) * r.y * g.y + b.y, (v.z - m.z) * r.z * g.z + b.z,
                   (v.w - m.w) * r.w * g.w + b.w};
     if (relu_pre)
-      for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
+      for (int j = 0; j < 4; ++j) y[j] = drs_maxf(y[j], 0.f);
     if (post_add) {
       const float4 a = *reinterpret_cast<const float4*>(post_add + (p / pix_per_image) * post_cs + c);
       y[0] += a.x; y[1] += a.y; y[2] += a.z; y[3] += a.w;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       y[0] += a.x; y[1] += a.y; y[2] += a.z; y[3] += a.w;
     }
     if (relu_post)
-      for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
+      for (int j = 0; j < 4; ++j) y[j] = drs_maxf(y[j], 0.f);
     *reinterpret_cast<float4*>(out + p * out_cs + out_co + c) = make_float4(y[0], y[1], y[2], y[3]);
   }
 }

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_sp_kernel(TapConv d, in
 #pragma unroll
           for (int r = 0; r < RB; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) comb[r][t][j] = fmaxf(acc[r][t][j] + bm[t * 4 + j], 0.f) + (acc[r][t + 2][j] + bs[t * 4 + j]);
+            for (int j = 0; j < 4; ++j) comb[r][t][j] = drs_maxf(acc[r][t][j] + bm[t * 4 + j], 0.f) + (acc[r][t + 2][j] + bs[t * 4 + j]);
         SpEpiConst kc;
         if (n < npost) lds8(sPost + n * d.Cout + kg * 8, kc.post);
         else if (d.post_add) lds8(d.post_add + (size_t)n * d.post_cs + kg * 8, kc.post);

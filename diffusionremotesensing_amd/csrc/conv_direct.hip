@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256) void tapconv_direct_kernel(TapConv d) {
     float v = acc[j];
     if (d.gate) v *= g;
     if (d.bias) v += d.bias[co];
-    if (d.relu_pre) v = fmaxf(v, 0.f);
+    if (d.relu_pre) v = drs_maxf(v, 0.f);
     if (d.post_add) v += d.post_add[(int64_t)n * d.post_cs + co];
     if (d.res) v += d.res[rpix * d.res_cs + d.res_co + co];
-    if (d.relu_post) v = fmaxf(v, 0.f);
+    if (d.relu_post) v = drs_maxf(v, 0.f);
     if (d.sigmoid) v = 1.f / (1.f + expf(-v));
     vals[j] = v;
     if (vec_store) continue;

@@ -118,7 +118,7 @@ __device__ __forceinline__ void tile_epilogue(const TapConv& d, f32x4 (&acc)[RPW
           v[0] += bias4[pr].x; v[1] += bias4[pr].y; v[2] += bias4[pr].z; v[3] += bias4[pr].w;
           if (d.relu_pre) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            for (int j = 0; j < 4; ++j) v[j] = drs_maxf(v[j], 0.f);
           }
           v[0] += post4[pr].x; v[1] += post4[pr].y; v[2] += post4[pr].z; v[3] += post4[pr].w;
           if (d.res) {
@@ -126,7 +126,7 @@ __device__ __forceinline__ void tile_epilogue(const TapConv& d, f32x4 (&acc)[RPW
           }
           if (d.relu_post) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            for (int j = 0; j < 4; ++j) v[j] = drs_maxf(v[j], 0.f);
           }
           if (d.out && valid[rr][h])
             *reinterpret_cast<float4*>(d.out + (size_t)opix[rr][h] * d.out_cs + d.out_co + n0 + pr * 32 + csel) =
@@ -272,7 +272,7 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         v[j] += bias8[j];
-        if (d.relu_pre) v[j] = fmaxf(v[j], 0.f);
+        if (d.relu_pre) v[j] = drs_maxf(v[j], 0.f);
         v[j] += post8[j];
       }
       }
@@ -290,7 +290,7 @@ __device__ __forceinline__ void tile_epilogue_sp(const TapConv& d, f32x4 (&acc)[
       }
       if (!LEAN && d.relu_post) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int j = 0; j < 8; ++j) v[j] = drs_maxf(v[j], 0.f);
       }
       if (d.out) store_sp(d.out, d.out_cs, d.out_co + cg, v, ty, oy);
       if constexpr (OUT2) {
@@ -314,9 +314,8 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
                                                      int ty0, int tx0, int wave, int lr, int kg) {
   const bool lo = lr < 8;
   const int pl = lr & 7;
-  // (the two optional ReLUs as max(v, bound) with a launch-uniform bound, 0 or -inf: one instruction per value instead of a
-  // max and a select on the flag.  fmaxf drops a NaN operand, so with the ReLU off a NaN accumulator leaves as -inf rather
-  // than NaN: divergence still shows - the callers' checks are isfinite(), which rejects both)
+  // (the two optional ReLUs as maximum(v, bound) with a launch-uniform bound, 0 or -inf: one instruction per value instead of
+  // a max and a select on the flag; drs_maxf propagates a NaN accumulator whether the ReLU is on or off)
   const float lo_pre = d.relu_pre ? 0.f : -__builtin_inff(), lo_post = d.relu_post ? 0.f : -__builtin_inff();
   const int tyb = ty0 + wave * RPW;
   const size_t pix0 = ((size_t)n * d.OH + tyb) * d.OW + tx0 + pl;  // (out_scale 1, no phase offset: 3x3 stride 1)
@@ -333,7 +332,7 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] = acc[r][0][j] + k.bias[j]; v[4 + j] = acc[r][1][j] + k.bias[4 + j]; }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaxf(v[j], lo_pre) + k.post[j], lo_post);
+      for (int j = 0; j < 8; ++j) v[j] = drs_maxf(drs_maxf(v[j], lo_pre) + k.post[j], lo_post);
 #ifdef DRS_X_NOAFFINE
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] = acc[r][0][j]; v[4 + j] = acc[r][1][j]; }

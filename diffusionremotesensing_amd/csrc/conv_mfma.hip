@@ -623,7 +623,7 @@ __global__ void pack_conv_mfma_kernel(PackBatch batch) {
     }
     P::cvt_store(dst_w, image_bytes, s * 16, x);
   }
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0 && dst_b) {  // (dst_b null: a second operand image of a layer whose bias slot another job of the batch writes)
     for (int cot = threadIdx.x; cot < Cout; cot += blockDim.x) {
       const int co = cot - co_off;
       const bool mine = co >= 0 && co < cout_src;

@@ -528,6 +528,11 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
 #define FL_WAIT_BUT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #endif
 #define FL_CROSS(XQ, W) { const i32x8 x0_ = XQ(0); FL_CROSS_P(XQ, W, x0_) }
+#ifdef DRS_FL_X_NOCROSS  // speed experiment (wrong numbers): no cross-term fragments / instructions
+#undef FL_CROSS
+#define FL_CROSS(XQ, W) { }
+#define FL_CROSS_P(XQ, W, X0) { (void)X0; }
+#else
 #define FL_CROSS_P(XQ, W, X0)                                                  \
     {                                                                          \
       i32x8 xq_ = X0;                                                          \
@@ -539,6 +544,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
         xq_ = xn_;                                                             \
       }                                                                        \
     }
+#endif
     // fp16 products of kernel column `col` (weights wm[ky]); PRE: the main weight fragments of the next column (ring offset
     // `next`) replace wm[ky] as soon as the last window row that needs the old ones has been issued
     auto main_col = [&](const char* buf, int col, bool pre, int next, unsigned ltarget, u32x4 af) __attribute__((always_inline)) {  // af: the fragment of window row 0
@@ -552,7 +558,11 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
           const int r = wr - ky;
           if (r >= 0 && r < RPW) {
 #pragma unroll
+#ifndef DRS_FL_X_NOMAIN  // speed experiment (wrong numbers): no fp16 instructions (their fragments are still read)
             for (int t = 0; t < NT; ++t) acc[r][t] = mm16(wm[ky][t], af, acc[r][t]);
+#else
+            for (int t = 0; t < NT; ++t) acc[r][t][0] += __uint_as_float(wm[ky][t][0] ^ af[t]);
+#endif
           }
         }
         if (pre) {

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
 #pragma unroll
             for (int r = 0; r < RPW; ++r)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) comb[r][t][j] = fmaxf(acc[r][t][j] + bm[j], 0.f) + (acc[r][t + 2][j] + bs[j]);
+              for (int j = 0; j < 4; ++j) comb[r][t][j] = drs_maxf(acc[r][t][j] + bm[j], 0.f) + (acc[r][t + 2][j] + bs[j]);
           }
           TapConv de = d;
           de.bias = nullptr; de.bias2 = nullptr; de.relu_pre = 0;

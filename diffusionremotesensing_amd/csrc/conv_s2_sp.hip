@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_sp_kernel(TapConv d, int nck, 
       for (int j = 0; j < 4; ++j) { v[j] = acc[0][2 * pr][j] + bias8[pr][j]; v[4 + j] = acc[0][2 * pr + 1][j] + bias8[pr][4 + j]; }
       if (d.relu_pre || d.relu_post) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int j = 0; j < 8; ++j) v[j] = drs_maxf(v[j], 0.f);
       }
       u32x4 H, L;
       drs_sp_split8(v, H, L);

@@ -121,6 +121,10 @@ struct DrsErr {
   } while (0)
 
 static inline int drs_cdiv(int a, int b) { return (a + b - 1) / b; }
+// ReLU and the other activation maxima: IEEE 754-2019 `maximum` (v_maximum3_f32), which PROPAGATES a NaN like torch.relu does.
+// fmaxf (v_max_f32) returns the other operand: a NaN accumulator would leave a ReLU as 0 and the divergence it signals
+// would be gone from the output (tests/test_gpu_parity.py: test_nan_reaches_the_output).
+__device__ __forceinline__ float drs_maxf(float a, float b) { return __builtin_elementwise_maximum(a, b); }
 #define DRS_RED_BLOCKS 512  // most blocks a partial-sum reduction of the training kernels uses (size of the partials buffer)
 
 // Every kernel of the library is launched through DRS_LAUNCH (same arguments as hipLaunchKernelGGL).  While a plan runs a

@@ -965,12 +965,13 @@ extern "C" int drs_unet_pack_weights(drs_plan* plan, const void* const* params, 
   for (int i = 0; i < 3; ++i) {
     const DecStage& d = plan->dec[i];
     if (!d.fused_gate) continue;
-    // (the pack kernel also writes the bias vector: the layers' own bias slots receive the same values again)
+    // (no bias destination: the layers' own jobs - same batched launch - write d.wg.b_off / d.wx.b_off; two jobs of one launch
+    //  storing to one slot was benign only while both computed bit-identical values)
     if ((rc = drs_launch_pack_conv_mfma(F(d.wg.w), F(d.wg.b), nullptr, nullptr, nullptr, nullptr, 0.f, base + d.fz_wg_off,
-                                        (float*)(base + d.wg.b_off), d.wg.Cout, d.wg.Cin, 1, 0, impl, s, 0, 0, 0, 0, 1)))
+                                        nullptr, d.wg.Cout, d.wg.Cin, 1, 0, impl, s, 0, 0, 0, 0, 1)))
       return rc;
     if ((rc = drs_launch_pack_conv_mfma(F(d.wx.w), F(d.wx.b), nullptr, nullptr, nullptr, nullptr, 0.f, base + d.fz_wx_off,
-                                        (float*)(base + d.wx.b_off), d.wx.Cout, d.wx.Cin, 4, 0, impl, s, 0, 0, 0, 0, 1)))
+                                        nullptr, d.wx.Cout, d.wx.Cin, 4, 0, impl, s, 0, 0, 0, 0, 1)))
       return rc;
     // fp32 [Cc][Ch] gating weights, BatchNorm folded (per-image bias of a stage input stored as x + temb)
     if ((rc = drs_launch_pack_conv(F(d.gate.w), F(d.gate.b), F(d.gate.bn), F(d.gate.bn + 1), F(d.gate.bn + 2), F(d.gate.bn + 3),

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          v[t * 4 + i] = (fmaxf(acc[b][t][i] + bm[t * 4 + i], 0.f) + (acc[b][t + 2][i] + bs[t * 4 + i])) + te[t * 4 + i];  // (the two-launch path's order)
+          v[t * 4 + i] = (drs_maxf(acc[b][t][i] + bm[t * 4 + i], 0.f) + (acc[b][t + 2][i] + bs[t * 4 + i])) + te[t * 4 + i];  // (the two-launch path's order)
       u32x4 hh, hl;
       drs_sp_split8(v, hh, hl);
       int p = wp[b];
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void resblock0_kernel(ResBlock0Desc d, unsi
       for (int r = 0; r < 2; ++r) {
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = fmaxf(o[r][0][i] + bb[i], 0.f); v[4 + i] = fmaxf(o[r][1][i] + bb[4 + i], 0.f); }
+        for (int i = 0; i < 4; ++i) { v[i] = drs_maxf(o[r][0][i] + bb[i], 0.f); v[4 + i] = drs_maxf(o[r][1][i] + bb[4 + i], 0.f); }
         u32x4 H, L;
         drs_sp_split8(v, H, L);
         const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo

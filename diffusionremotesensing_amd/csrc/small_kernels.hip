@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void conv3x3_planar_kernel(const float* __rest
     for (int co = 0; co < 4; ++co) {
       if (co >= Cout) break;
       float v = acc[co];
-      if (relu) v = fmaxf(v, 0.f);
+      if (relu) v = drs_maxf(v, 0.f);
       const int64_t o = ((int64_t)n * Cout + co) * hw + (int64_t)y * W + x;
       if (res) v += res[o];
       out[o] = v;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const int64_t* __restrict
     float acc = 0.f;
     for (int k = 0; k < dim_out; ++k) acc = fmaf(wr[k], h[k], acc);
     acc += b2[c];
-    out[(int64_t)b * out_stride + c] = fmaxf(acc, 0.f);
+    out[(int64_t)b * out_stride + c] = drs_maxf(acc, 0.f);
   }
 }
 int drs_launch_time_mlp(const int64_t* t, const float* inv_freq, const float* W1, const float* b1, const float* W2,
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void time_mlp_multi_kernel(const int64_t* __re
     float acc = 0.f;
     for (int k = 0; k < dim_out; ++k) acc = fmaf(wr[k], h[k], acc);
     acc += b2[c];
-    o[c] = fmaxf(acc, 0.f);
+    o[c] = drs_maxf(acc, 0.f);
   }
 }
 int drs_launch_time_mlp_multi(const int64_t* t, const float* inv_freq, const char* packed, const long long* table,

@@ -89,7 +89,7 @@ def add_reference_noise(x, noise_level1=2, noise_level2=10):
     return x
 
 
-def load_image_folder_u8(root_dir, image_size=None, rank=0, world_size=1):
+def load_image_folder_u8(root_dir, image_size=None, rank=0, world_size=1, limit=None):
     """Decode side of the reference's `get_data_superres` (utils.py:93-138) + the `transforms.Resize((image_size,
     image_size))` its `launch` hands it as `transform` (train_diffusion_superres.py:594-605): the images of `root_dir` in
     `sorted(os.listdir(...))` order, opened with Pillow (`data_format='PIL'`), resized to image_size x image_size when they
@@ -98,20 +98,33 @@ def load_image_folder_u8(root_dir, image_size=None, rank=0, world_size=1):
     `DeviceSuperresFeed` then keeps on the device.  Everything after the decode (bicubic down-sampling, blur, noise,
     ToTensor) happens per batch on the device.  Done once per dataset, not per item per epoch.
 
-    `rank` / `world_size`: decode only this rank's shard (every world-th file, equal shard sizes: the remainder is
-    dropped, see launch()).  8-bit modes L / RGB / RGBA (what ToTensor turns into 1 / 3 / 4 channels of uint8 / 255); other
-    modes raise."""
+    `rank` / `world_size`: decode only this rank's shard (every world-th file, equal shard sizes: the ranks must run the same
+    number of steps per epoch, so len % world_size files - always the last ones of the sorted list - are left out, and the count
+    is printed; DistributedSampler pads with repeats instead).  `limit`: only the first `limit` files of the (unsharded) list -
+    the reference's `train_dataset[0..4]` of the final sampling.  Entries that are not files are skipped like any directory
+    listing tool would; a file Pillow cannot read raises with its name.  8-bit modes L / RGB / RGBA (what ToTensor turns into
+    1 / 3 / 4 channels of uint8 / 255); other modes raise."""
     import os
 
-    from PIL import Image
-    names = sorted(os.listdir(root_dir))
-    per_rank = len(names) // world_size
-    if per_rank == 0:
-        raise ValueError(f"dataset of {len(names)} images in {root_dir} cannot be sharded over {world_size} ranks")
-    names = names[rank::world_size][:per_rank]
+    from PIL import Image, UnidentifiedImageError
+    names = [n for n in sorted(os.listdir(root_dir)) if os.path.isfile(os.path.join(root_dir, n))]
+    if limit is not None:
+        names = names[:limit]
+    else:
+        per_rank = len(names) // world_size
+        if per_rank == 0:
+            raise ValueError(f"dataset of {len(names)} images in {root_dir} cannot be sharded over {world_size} ranks")
+        if len(names) % world_size and rank == 0:
+            print(f"{root_dir}: {len(names) % world_size} of {len(names)} images left out (equal shards over {world_size} ranks)")
+        names = names[rank::world_size][:per_rank]
     planes = []
     for name in names:
-        with Image.open(os.path.join(root_dir, name)) as y:
+        try:
+            img = Image.open(os.path.join(root_dir, name))
+        except (UnidentifiedImageError, OSError) as e:
+            raise ValueError(f"{os.path.join(root_dir, name)}: not an image Pillow can read ({e}); the dataset folders must hold "
+                             "image files only") from e
+        with img as y:
             y.load()
             if y.mode not in ("L", "RGB", "RGBA"):
                 raise ValueError(f"{name}: image mode {y.mode!r} is not an 8-bit L / RGB / RGBA image")

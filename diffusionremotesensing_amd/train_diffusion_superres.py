@@ -252,6 +252,11 @@ class Diffusion:
                 running_train_loss += self.train_step(model, optimizer, loss_function, lr_img, hr_img, ema,
                                                       ema_model).detach()
             running_train_loss = running_train_loss.item() / max(len(train_loader), 1)
+            # (the .item() above is the epoch's synchronisation point: a wave of the wave-specialised kernels that gave up on a
+            #  counter during this epoch's forwards or backwards - csrc/sp_sync.h - is reported here, not trained on)
+            net = model.module if hasattr(model, "module") and not hasattr(model, "hip_engine") else model
+            if hasattr(net, "hip_engine"):
+                net.hip_engine().check_faults()
             print(f"Epoch {epoch}: Running Train ({loss}) {running_train_loss}")
 
             if self._is_rank0() and epoch % check_preds_epoch == 0 and val_loader is None:
@@ -359,10 +364,17 @@ def launch(args):
                                     "(or synthetic[:N] / synthetic_u8[:N])")
         train_loader = make_feed(load_image_folder_u8(os.path.join(spec, "train_original"), args.image_size, r, wsz))
         val_loader = make_feed(load_image_folder_u8(os.path.join(spec, "val_original"), args.image_size, r, wsz))
-        if train_loader.hr.shape[1] != ch:
-            raise ValueError(f"the images have {train_loader.hr.shape[1]} channels, --inp_out_channels is {ch}")
-        n_final = min(5, train_loader.hr.shape[0])
-        final_lr = [train_loader.item(i)[0] for i in range(n_final)]
+        for what, feed in (("train_original", train_loader), ("val_original", val_loader)):
+            if feed.hr.shape[1] != ch:
+                raise ValueError(f"the images of {what} have {feed.hr.shape[1]} channels, --inp_out_channels is {ch}")
+        # the final sampling conditions on train_dataset[0..4] of the WHOLE sorted folder (reference :678-680), whatever this
+        # rank's shard holds; with Gauss_noise the dataset item carries its noise (utils.py:126-138)
+        first = load_image_folder_u8(os.path.join(spec, "train_original"), args.image_size, limit=5).to(device)
+        from .degradation import add_reference_noise, downblur
+        final_x = downblur(first, args.magnification_factor, train_loader.blur_radius)[0]
+        if gauss_noise:
+            add_reference_noise(final_x, noise_level1=2, noise_level2=10)
+        final_lr = [final_x[i] for i in range(final_x.shape[0])]
     else:
         length = int(spec.split(":")[1]) if ":" in spec else 4 * args.batch_size
         train_dataset = SyntheticSuperresDataset(length, ch, args.image_size, args.magnification_factor, seed=1)
@@ -403,6 +415,8 @@ def launch(args):
                     verbose=True)
     if args.multiple_gpus:
         drs_dist.destroy_process_group()
+    if r != 0:
+        return  # one rank samples and writes models_run/<name>/results/superres_results.pt (every rank holds the same weights)
     outs = [diffusion.sample(n=1, model=model, lr_img=lr_i, input_channels=ch, generate_video=args.generate_video)
             for lr_i in final_lr]
     torch.save(torch.cat(outs).cpu(), os.path.join(os.getcwd(), "models_run", args.model_name, "results",

@@ -720,6 +720,86 @@ def test_full_length_chain_is_deterministic(dev, model):
     assert not torch.isnan(outs[0]).any()
 
 
+def _alternating_forwards_are_bit_stable(eng, xs, ts, cond, mag, forwards, **kw):
+    """tools/diag_determinism.py as a test: the eval forward alternates between two inputs (so that a read of the PREVIOUS
+    forward's data would show), every output is compared bit for bit with the first run of its input; the comparison result
+    stays on the device until the end (no synchronisation inside the loop)."""
+    with torch.no_grad():
+        eng.forward(xs[0], ts[0], cond, mag, reuse_cond=False, **kw)
+        refs = [eng.forward(xs[i], ts[i], cond, mag, reuse_cond=True, check_weights=False, **kw).clone() for i in range(2)]
+        bad = torch.zeros((), dtype=torch.int64, device=xs[0].device)
+        for r in range(forwards):
+            y = eng.forward(xs[r & 1], ts[r & 1], cond, mag, reuse_cond=True, check_weights=False, **kw)
+            bad += (y != refs[r & 1]).any()
+    eng.check_faults()  # no wave ran into its poll bound (csrc/sp_sync.h)
+    return int(bad)
+
+
+def test_ring_protocol_holds_over_60000_forwards(dev, seeded_sd_gen):
+    """The weight-ring race of rounds 2 - 4 (a mover lifting a `landed` counter on behalf of a slower one: DESIGN.md 4.1) fired
+    once in ~50 000 forwards, in the single-chunk ring-hit launch (conv_blocks.1.conv1: Cin = 32, several items per block).
+    40 000 forwards of the super-resolution model at a shape with two such items per CU (its FL instance; the split-bf16
+    instance runs the same mover rule in the variant tests) + 20 000 of the 64 x 64 generation model, whose bottleneck is the
+    8 x 8 instance (tapconv_sp8_kernel): every output bit-equal to its reference."""
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    from diffusionremotesensing_amd.generate_new_imgs.UNet_model_generation import Residual_Attention_UNet_generation
+    m = Residual_Attention_UNet_superres(3, 3, dev)
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 0))
+    eng = m.to(dev).eval().hip_engine()
+    eng.set_impl("mfma_bf16x3")
+    lr = synthetic.tensor_uniform("ring.lr", (1, 3, 128, 128)).to(dev)
+    xs = [synthetic.tensor_normal(f"ring.x{i}", (8, 3, 256, 256)).to(dev) for i in range(2)]  # conv_blocks.1.conv1: 8 x 64 patches = 512 items, two per block
+    ts = [torch.full((8,), 700 + i, dtype=torch.int64, device=dev) for i in range(2)]
+    assert _alternating_forwards_are_bit_stable(eng, xs, ts, lr, 2, 40000) == 0
+    g = Residual_Attention_UNet_generation(3, 3, 10, dev)
+    g.load_state_dict(seeded_sd_gen)
+    geng = g.to(dev).eval().hip_engine()
+    geng.set_impl("mfma_bf16x3")
+    xs = [synthetic.tensor_normal(f"ring.g{i}", (16, 3, 64, 64)).to(dev) for i in range(2)]
+    ts = [torch.full((16,), 300 + i, dtype=torch.int64, device=dev) for i in range(2)]
+    labels = torch.arange(16, device=dev) % 10
+    assert _alternating_forwards_are_bit_stable(geng, xs, ts, None, 1, 20000, labels=labels) == 0
+
+
+def test_nan_reaches_the_output(dev, seeded_sd):
+    """A NaN in one image of the batch (in x, and in the conditioning image) must come out of the network as a non-finite
+    output of THAT image - through every ReLU (drs_maxf: IEEE maximum, like torch.relu; v_max_f32 would turn it into 0) and the
+    ReLU-free epilogues - and leave the other images untouched (batch independence).  The FL kernel's movers count a NaN block
+    as outside fp16's range: check_faults reports it (DRS_ERR_RANGE) and the split-bf16 kernels the plan falls back to carry
+    the NaN through as well."""
+    from diffusionremotesensing_amd import _lib, synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    model = Residual_Attention_UNet_superres(3, 3, dev)
+    model.load_state_dict(seeded_sd)
+    model = model.to(dev).eval()
+    eng = model.hip_engine()
+    eng.set_impl("mfma_bf16x3")
+    x = synthetic.tensor_normal("nan.x", (3, 3, 128, 128))
+    lr = synthetic.tensor_uniform("nan.lr", (3, 3, 64, 64))
+    t = torch.tensor([5, 700, 1400])
+    xn = x.clone()
+    xn[1, 0, 40, 77] = float("nan")
+    lrn = lr.clone()
+    lrn[2, 1, 3, 9] = float("nan")
+    with torch.no_grad():
+        clean = model(x.to(dev), t.to(dev), lr.to(dev), 2).cpu()
+        eng.check_faults()
+        for attempt in ("FL kernels", "split-bf16 fallback"):
+            got = model(xn.to(dev), t.to(dev), lr.to(dev), 2).cpu()
+            assert not torch.isfinite(got[1]).all(), f"{attempt}: a NaN input pixel left no trace in its image's output"
+            assert torch.equal(got[0], clean[0]) and torch.equal(got[2], clean[2]), attempt
+            got = model(x.to(dev), t.to(dev), lrn.to(dev), 2).cpu()
+            assert not torch.isfinite(got[2]).all(), f"{attempt}: a NaN in the conditioning image left no trace in its image's output"
+            assert torch.equal(got[0], clean[0]) and torch.equal(got[1], clean[1]), attempt
+            if attempt == "FL kernels":
+                with pytest.raises(_lib.RangeFault):
+                    eng.check_faults()
+                clean = model(x.to(dev), t.to(dev), lr.to(dev), 2).cpu()  # (the reference of the fallback arithmetic)
+            else:
+                eng.check_faults()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DRS_SP": "0"}, {"DRS_SP": "0", "DRS_WS": "0"}, {"DRS_FUSE_GATE": "0"},
                                  {"DRS_CONCURRENT": "1"}, {"DRS_D3K": "0", "DRS_S2K": "0"}, {"DRS_UPFUSE": "0"},
