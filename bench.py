@@ -31,6 +31,11 @@ PEAK_TFLOPS = {"direct": 157.3, "mfma_f32": 157.3, "mfma_bf16x3": 2500.0, "mfma_
 DTYPE = {"direct": "f32", "mfma_f32": "f32", "mfma_bf16x3": "bf16x3 (hi+lo split, f32 accumulate)",
          "mfma_f16": "f16 (f32 accumulate)"}
 HBM_PEAK_GBS = 8000.0
+# Rehearsal of the N > 1 path on a one-GPU lease (tests/test_gpu_dist.py): DRS_BENCH_BACKEND=gloo DRS_BENCH_SHARE_DEVICE=1 runs the
+# ranks of `--gpus N` as N processes on device 0 over gloo (RCCL needs a device per rank).  The driver's runs leave both unset:
+# one rank per GPU, backend "nccl" = RCCL over xGMI.  The JSON line records the backend in config.process_group.
+_BACKEND = os.environ.get("DRS_BENCH_BACKEND", "nccl")
+_SHARE_DEVICE = os.environ.get("DRS_BENCH_SHARE_DEVICE", "") not in ("", "0")
 
 
 def _host_model():
@@ -200,9 +205,9 @@ def other_workload(args):
     if args.gpus > 1 or world > 1 or "RANK" in os.environ:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
-        dist.init_process_group("nccl")
+        dist.init_process_group(_BACKEND)
     rank = dist.rank()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if _SHARE_DEVICE else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     wl = args.workload
@@ -224,7 +229,8 @@ def other_workload(args):
         print(json.dumps({"metric": f"{wl}_steps_per_s", "value": round(value, 4), "unit": unit, "n_gpus": world,
                           "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
-                          "data": "synthetic", "config": {"workload": desc, "batch_per_gpu": batch, "impl": args.impl},
+                          "data": "synthetic", "config": {"workload": desc, "batch_per_gpu": batch, "impl": args.impl,
+                                                          "process_group": torch.distributed.get_backend() if dist.is_initialized() else None},
                           "images_per_s": round(value * batch, 2),
                           "tflops_algorithmic": round(value * gflop / 1e3, 3)}), flush=True)
     if dist.is_initialized():
@@ -284,9 +290,9 @@ def main():
     if args.gpus > 1 or world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU, RCCL
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
-        dist.init_process_group("nccl")
+        dist.init_process_group(_BACKEND)
     rank = dist.rank()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if _SHARE_DEVICE else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -61,3 +61,21 @@ def test_two_ranks_share_one_gpu_train_step():
     line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     assert res["ok"] and res["params_identical_across_ranks"] and res["grad_elements"] == 4383058 - 387520  # all parameters minus the 6 structurally unused tensors
+
+
+@pytest.mark.parametrize("workload", ["train", "sample"])
+def test_bench_py_two_ranks_end_to_end(workload):
+    """`bench.py --gpus 2` end to end, launched the way the driver launches it, as two gloo ranks sharing the leased GPU
+    (DRS_BENCH_BACKEND / DRS_BENCH_SHARE_DEVICE): process group, per-rank inputs, the data-parallel training step with its flat
+    gradient exchange (train) / the sharded sampling step (the headline workload), barrier + max-over-ranks timing, ONE JSON
+    line from rank 0 with n_gpus 2 and the whole-job rate.  (No 1 -> 8 scaling curve has been measured: no multi-GPU node was
+    available to the builder; this proves the N > 1 code path is ready to be measured.)"""
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    if workload == "train":
+        args += ["--workload", "train"]
+    out = _torchrun(args, {"DRS_BENCH_BACKEND": "gloo", "DRS_BENCH_SHARE_DEVICE": "1"}, nproc=2, timeout=900)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"].get("process_group") == "gloo"
