@@ -28,7 +28,10 @@ BATCH, IMAGE, MAG, T_STEPS = 16, 256, 2, 1500
 GFLOP_PER_FWD = 454.39
 MB_PER_FWD = 4998.3
 PEAK_TFLOPS = {"direct": 157.3, "mfma_f32": 157.3, "mfma_bf16x3": 2500.0, "mfma_f16": 2500.0}
-DTYPE = {"direct": "f32", "mfma_f32": "f32", "mfma_bf16x3": "bf16x3 (hi+lo split, f32 accumulate)",
+_FL = os.environ.get("DRS_FL", "1") != "0"
+DTYPE = {"direct": "f32", "mfma_f32": "f32",
+         "mfma_bf16x3": ("bf16x3 (hi+lo split, f32 accumulate)" +
+                         ("; the wide 3x3 layers in the FL arithmetic: f16 main + block-scaled fp6 (e2m3) cross terms" if _FL else "")),
          "mfma_f16": "f16 (f32 accumulate)"}
 HBM_PEAK_GBS = 8000.0
 # Rehearsal of the N > 1 path on a one-GPU lease (tests/test_gpu_dist.py): DRS_BENCH_BACKEND=gloo DRS_BENCH_SHARE_DEVICE=1 runs the
@@ -383,6 +386,8 @@ def main():
         # newest committed PMC file whose per-op names cover this run's schedule; a stale file (kernels or plan changed since
         # it was collected) is not mixed with fresh times: the counter-based fields are then null
         tsource = None
+        by_name = {}
+        kern_of = {}
         import glob
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             if args.impl != "mfma_bf16x3":
@@ -424,7 +429,6 @@ def main():
         by_kernel = None
         if args.impl == "mfma_bf16x3":
             import re
-            kern_of = {}
             for op_name, kname in getattr(engine, "last_launch_log", None) or []:
                 if op_name:
                     kern_of.setdefault(op_name, re.sub(r"^void\s+", "", kname.replace("(anonymous namespace)::", "")).split("<")[0].split("(")[0].strip())
@@ -436,46 +440,81 @@ def main():
                 ms = sum(o[1] for o in sel)
                 by_kernel[kname] = {"launches": len(sel), "avg_launch_us": round(1e3 * ms / len(sel), 2),
                                     "achieved": round(sum(o[2] for o in sel) / (ms * 1e-3) / 1e12, 2)}
-        roofline = {"bound": "mfma",
-                    "kernel": ("3x3 stride-1 convolutions: tapconv_sp_kernel<HAS2, BNB, FUSE, DUAL> (conv_mfma_sp.hip; 8 MFMA + 4 "
-                               "mover waves per CU) on the deep layers + upfuse_sp_kernel (same structure: ups.i.transform composed "
-                               "with the x-half of up_convs.i, executed FLOPs counted) + resblock0_kernel (the first encoder block as "
-                               "one launch: conv1 + skip into an LDS window, conv2 + shortcut from it; algorithmic FLOPs, the halo "
-                               "recomputation not counted) + the top stage with result / up_convs.2 / output folded into its weights: "
-                               "conv3x3_proj_sp_kernel (att-half) and upfuse_proj_sp_kernel (composite), streaming direct-operand kernels "
-                               "with the kernel rows in the MFMA's M dimension (algorithmic FLOPs of the reference ops, a fraction of "
-                               "them executed); SP-format operands"
-                               if args.impl == "mfma_bf16x3" else
-                               "3x3 stride-1 family: tapconv_ws_kernel / tapconv_mfma_kernel<%s, 32, 4, CONV3X3, *>" % args.impl)
-                    if args.impl != "direct" else "tapconv_direct_kernel",
-                    "launches_per_forward": len(dom), "by_kernel": by_kernel,
-                    "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
-                    "flops_per_launch": round(dom_fl / len(dom)), "avg_launch_us": round(1e3 * dom_ms / len(dom), 2),
-                    "algorithmic_bytes_per_launch": round(dom_by / len(dom)),
-                    "traffic": traffic, "traffic_source": (tsource + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per "
-                                                           "op of one forward through the plan's launch log; op names AND the "
-                                                           "kernel behind every op match this run)") if tsource else None,
-                    "note": ("achieved counts the ALGORITHMIC FLOPs of the reference ops (SURVEY 8(d)); the composite stages execute "
-                             "25/54 of theirs and the top stage's two folded launches about a tenth (output o up_convs.2 o result is "
-                             "one 3-output convolution), so mfma_pipe_frac overstates the matrix pipe's load on those four launches"),
-                    "mfma_instructions_per_product": mfma_per_product,
-                    "mfma_pipe_frac": round(mfma_per_product * achieved / peak, 5),
-                    "forward_ms_sum_of_ops": round(all_ms, 4), "conv_ms": round(conv_ms, 4),
-                    "forward_hbm_GBs_algorithmic": round(step_mb / 1e3 / (all_ms * 1e-3), 1),
-                    "forward_hbm_frac_of_8TBs": round(step_mb / 1e3 / (all_ms * 1e-3) / HBM_PEAK_GBS, 5),
-                    "algorithmic_work_per_step": {"gflop": round(step_gflop, 2), "mb": round(step_mb, 1),
-                                                  "note": "reference graph (SURVEY 8(d)) minus the LR-conditioning branch, which a "
-                                                          "sampling step reuses (computed once per chain)"},
-                    "forward_hbm_counter_based": fwd_traffic,
-                    "hbm_frac_256_level": level256["frac"] if level256 else None, "level_256": level256,
-                    "top_ops_ms": {n: round(ms, 4) for n, ms, _, _ in top}}
+        # ---- the dominant kernel alone: the wave-specialised 3x3 tap-convolution (tapconv_fl_kernel where the FL arithmetic runs,
+        # tapconv_sp_kernel otherwise): 11 launches per forward (conv1 / conv2 (+ shortcut) of blocks 1 - 3, ups.*.conv, the
+        # att-halves of stages 0 / 1).  achieved = ALGORITHMIC FLOPs of those launches (2 * MACs of the reference
+        # ops they compute, all of them executed) / their HIP-event durations on the launch stream.
+        fl_on = os.environ.get("DRS_FL", "1") != "0" and args.impl == "mfma_bf16x3"
+        dk = None
+        if args.impl == "mfma_bf16x3" and by_kernel is not None:
+            dk_ops = [o for o in dom if kern_of.get(o[0], "").startswith(("tapconv_fl_kernel", "tapconv_sp_kernel"))]
+            if dk_ops:
+                dk_ms = sum(o[1] for o in dk_ops)
+                dk_fl = sum(o[2] for o in dk_ops)
+                n_fl = sum(kern_of.get(o[0], "").startswith("tapconv_fl_kernel") for o in dk_ops)
+                # matrix-pipe slots (16 cycles each) per product of one tap, tile and 32-channel chunk: 3 (split bf16) or
+                # (9 fp16 + 5 fp6) / 9 (FL: the cross terms of a tap PAIR are one instruction)
+                slots = (n_fl * (14.0 / 9.0) + (len(dk_ops) - n_fl) * 3.0) / len(dk_ops)
+                dk = {"launches": len(dk_ops), "fl_launches": int(n_fl), "ms": dk_ms, "flops": dk_fl, "slots": slots,
+                      "bytes": sum(o[3] for o in dk_ops),
+                      "traffic": (round(sum(by_name[o[0]] for o in dk_ops) / len(dk_ops)) if tsource else None)}
+        family = {"kernels": ("tapconv_fl / tapconv_sp (11) + upfuse_sp (2, executed FLOPs of the composite) + resblock0 (1) + the folded top "
+                              "stage's conv3x3_proj_sp and upfuse_proj_sp (2: ALGORITHMIC FLOPs of the reference ops, about a tenth of "
+                              "them executed)"),
+                  "launches_per_forward": len(dom), "by_kernel": by_kernel, "achieved": round(achieved, 3),
+                  "frac": round(achieved / peak, 5), "avg_launch_us": round(1e3 * dom_ms / len(dom), 2),
+                  "traffic": traffic}
+        if dk is not None:
+            d_ach = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma",
+                        "kernel": ("tapconv_fl_kernel<HAS2> (conv_mfma_fl.hip): wave-specialised 3x3 stride-1 implicit GEMM over SP-format "
+                                   "activations, 8 MFMA + 4 mover waves per CU, fp16 main product + block-scaled fp6 cross terms of tap "
+                                   "pairs (the movers convert the window to the FL line on its way into LDS)" if dk["fl_launches"] else
+                                   "tapconv_sp_kernel<HAS2, 64> (conv_mfma_sp.hip): wave-specialised 3x3 stride-1 implicit GEMM over "
+                                   "SP-format activations, split bf16 x3"),
+                        "launches_per_forward": dk["launches"], "fl_launches": dk["fl_launches"],
+                        "achieved": round(d_ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(d_ach / peak, 5),
+                        "flops_per_launch": round(dk["flops"] / dk["launches"]),
+                        "avg_launch_us": round(1e3 * dk["ms"] / dk["launches"], 2),
+                        "algorithmic_bytes_per_launch": round(dk["bytes"] / dk["launches"]),
+                        "traffic": dk["traffic"],
+                        "mfma_slots_per_product": round(dk["slots"], 3),
+                        "mfma_pipe_frac": round(dk["slots"] * d_ach / peak, 5),
+                        "note": ("all FLOPs of these launches are executed (no folded / composite op among them); mfma_pipe_frac = share "
+                                 "of the matrix pipe's 16-cycle slots the kernel fills at the NOMINAL clock (peak 2.5 PFLOP/s dense "
+                                 "bf16 / fp16; the fp6 instruction of the FL arithmetic occupies one such slot per tap pair)")}
+        else:
+            roofline = {"bound": "mfma", "kernel": "3x3 stride-1 family (%s)" % args.impl if args.impl != "direct" else "tapconv_direct_kernel",
+                        "launches_per_forward": len(dom), "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 5), "flops_per_launch": round(dom_fl / len(dom)),
+                        "avg_launch_us": round(1e3 * dom_ms / len(dom), 2), "algorithmic_bytes_per_launch": round(dom_by / len(dom)),
+                        "traffic": traffic}
+        roofline.update({
+            "traffic_source": (tsource + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per op of one forward through the "
+                                         "plan's launch log; op names AND the kernel behind every op match this run)") if tsource else None,
+            "family_3x3": family,
+            "forward_ms_sum_of_ops": round(all_ms, 4), "conv_ms": round(conv_ms, 4),
+            "forward_hbm_GBs_algorithmic": round(step_mb / 1e3 / (all_ms * 1e-3), 1),
+            "forward_hbm_frac_of_8TBs": round(step_mb / 1e3 / (all_ms * 1e-3) / HBM_PEAK_GBS, 5),
+            "algorithmic_work_per_step": {"gflop": round(step_gflop, 2), "mb": round(step_mb, 1),
+                                          "note": "reference graph (SURVEY 8(d)) minus the LR-conditioning branch, which a "
+                                                  "sampling step reuses (computed once per chain)"},
+            "forward_hbm_counter_based": fwd_traffic,
+            "hbm_frac_256_level": level256["frac"] if level256 else None, "level_256": level256,
+            "top_ops_ms": {n: round(ms, 4) for n, ms, _, _ in top}})
+        dtype = DTYPE[args.impl]
+        if fl_on and dk is not None and dk["fl_launches"]:
+            dtype = ("f16 main + block-scaled fp6 (e2m3) cross terms of tap pairs on the wide 3x3 layers (FL, %d of %d launches of the "
+                     "dominant kernel); split bf16 x3 (hi + lo) everywhere else; f32 accumulate" % (dk["fl_launches"], dk["launches"]))
         result = {
             "metric": "unet_denoise_steps_per_s", "value": round(value, 4), "unit": "batch16_steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.impl],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: Residual_Attention_UNet_superres 128x128->256x256 mag=2 DownBlur, "
                                    "batch 16 per GPU, cosine T=1500, eval-mode UNet forward + ancestral update per step",
+                       "timed_region": "`value` = the K steps of --steps (a short loop: 20 steps = ~25 ms); `full_chain` is the same "
+                                       "step over a whole 1499-step chain in this process",
                        "batch_per_gpu": BATCH, "image_size": IMAGE, "noise_steps": T_STEPS, "impl": args.impl,
                        "weights": "seeded random (no pretrained weights exist)",
                        "process_group": torch.distributed.get_backend() if dist.is_initialized() else None},
@@ -491,16 +530,40 @@ def main():
                     result["psnr_detail"] = q
                 if world == 1:
                     # a full sample() of T - 1 = 1499 steps at configs[1] (16 images, one cached LR image):
-                    # the end-to-end chain the reference's callers run, wall clock incl. the conditioning branch
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    out = diffusion.sample(BATCH, model, lr_cpu[0], input_channels=3)
-                    torch.cuda.synchronize()
-                    dt = time.perf_counter() - t1
-                    model.eval()
-                    result["full_chain"] = {"steps": T_STEPS - 1, "seconds": round(dt, 3),
-                                            "batch16_steps_per_s": round((T_STEPS - 1) / dt, 2),
-                                            "finite": bool(torch.isfinite(out).all().item())}
+                    # the end-to-end chain the reference's callers run, wall clock incl. the conditioning branch.
+                    # `full_chain`: the seeded weights with the `output` projection scaled by 1e-2 (the G10 golden chain's
+                    # weights): the chain's amplitude stays O(1), as a TRAINED model's does, and every forward runs the same
+                    # kernels as the timed loop.  `full_chain_untrained_weights`: the plain seeded weights - the amplitude grows
+                    # without bound (1e30 and beyond: meaningless), leaves fp16's range on the way, and the FL layers hand the
+                    # chain over to the split-bf16 kernels at one of its periodic fault checks (DRS_ERR_RANGE): the time
+                    # includes the <= 128 repeated steps; run LAST of the two, it leaves this plan on split bf16.
+                    def chain(m_):
+                        torch.cuda.synchronize()
+                        t1_ = time.perf_counter()
+                        out_ = diffusion.sample(BATCH, m_, lr_cpu[0], input_channels=3)
+                        torch.cuda.synchronize()
+                        dt_ = time.perf_counter() - t1_
+                        m_.eval()
+                        return {"steps": T_STEPS - 1, "seconds": round(dt_, 3), "batch16_steps_per_s": round((T_STEPS - 1) / dt_, 2),
+                                "finite": bool(torch.isfinite(out_).all().item())}
+                    bounded = Residual_Attention_UNet_superres(3, 3, dev)
+                    sdb = dict(sd)
+                    sdb["output.weight"] = sd["output.weight"] * 1e-2
+                    sdb["output.bias"] = sd["output.bias"] * 1e-2
+                    bounded.load_state_dict(sdb)
+                    bounded = bounded.to(dev).eval()
+                    bounded.hip_engine().set_impl(args.impl)
+                    result["full_chain"] = dict(chain(bounded), weights="seeded, `output` x 1e-2 (bounded chain)")
+                    del bounded
+                    fc = chain(model)
+                    fc["weights"] = "seeded (untrained: unbounded chain)"
+                    with torch.no_grad():  # (the chain's plan: ONE conditioning image broadcast over the batch)
+                        x.copy_(x_cpu)
+                        lr1_ = lr_cpu[:1].to(dev).contiguous()
+                        engine.forward(x, t.fill_(750), lr1_, MAG, reuse_cond=False)
+                        _, log_ = engine.logged_forward(x, t, lr1_, MAG, reuse_cond=True, check_weights=False)
+                    fc["handed_over_to_split_bf16"] = not any("tapconv_fl_kernel" in k_ for _, k_ in log_)
+                    result["full_chain_untrained_weights"] = fc
                 if args.impl != "mfma_f32":
                     # the exact-fp32 line beside the headline (same step, v_mfma_f32_16x16x4_f32 kernels): what the
                     # precision choice buys, in the driver's own record

@@ -319,11 +319,10 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
           }
       }
     };
-    auto store_window = [&](bool sec, int vm_last, char* buf) __attribute__((always_inline)) {
+    auto store_window = [&](bool sec, char* buf) __attribute__((always_inline)) {
       const unsigned keep = (HAS2 && sec) ? keep2 : keep1;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
-        if (i == NR - 1) sp_wait_vm(vm_last);  // the last round was loaded in this step (behind it: columns 1, 2)
         FlHalf f;
 #ifdef DRS_FL_COPYMOVER  // speed experiment (wrong numbers): what the kernel does when its movers only copy
         f.m0 = ww[i][0]; f.m1 = ww[i][1];
@@ -334,19 +333,44 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
 #endif
         if ((keep >> i) & 1u) fl_store_half(buf + (pw + 4 * i) * 4096, f, hh != 0, a_m0, a_m1, a_w4, a_p46, a_w5, a_p57);
 #ifndef DRS_FL_COPYMOVER
-        if (f.over && d.fault) atomicOr(d.fault, 2u);  // (never in a healthy network: reported by drs_unet_check_faults as DRS_ERR_RANGE)
+        if (f.over && d.fault) {  // (never in a healthy network: reported by drs_unet_check_faults as DRS_ERR_RANGE, with the place)
+          atomicOr(d.fault, 2u);
+          d.fault[1] = ((unsigned)d.Cin << 16) | (unsigned)d.Cout;
+          d.fault[2] = ((unsigned)d.TH << 16) | (sec ? 1u : 0u);
+          d.fault[3] = ((unsigned)blockIdx.x << 16) | ((unsigned)(pw + 4 * i) << 8) | (unsigned)lane;
+          d.fault[4] = f.sm;
+        }
 #endif
         __builtin_amdgcn_sched_barrier(0);  // one round's temporaries at a time
       }
     };
 
-    // Order of a step k (loads in issue order; the in-order vector-memory counter gives the waits):
-    //   col0(k) [5 | 2], window round 2 of k [4] | poll CR0, store col0 | col1(k) [7 | 0], col2(k) [6 | 0] | poll WR, convert +
-    //   store the window (rounds 0, 1 were loaded a step ahead) | window rounds 0, 1 of k + 1 [8] | poll CR1, store col1 | poll
-    //   CR2, store col2       (counts: 3x3 step | one-tap step; a ring hit loads no weights)
+    // Order of a step k (loads in issue order; the in-order vector-memory counter gives the waits).  Everything a step's FIRST
+    // stores need was requested during the previous step: its column 0 and its whole window.
+    //   poll CR0, store col0(k) | col1(k) [7 | 0], col2(k) [6 | 0] | poll WR, convert + store window k | window of k + 1 [12] |
+    //   poll CR1, store col1 | poll CR2, store col2 | col0(k + 1) [5 | 2]      (counts: 3x3 step | one-tap step; a ring hit loads
+    //   no weights)
+    auto load_col0 = [&](const Step& s, bool hit) __attribute__((always_inline)) {
+      const bool sec = HAS2 && s.c >= g.nchunks;
+      const int cc = sec ? s.c - g.nchunks : s.c;
+      if (hit) return;
+      if (sec) {
+        const char* w = wg2 + (size_t)cc * chunk2_b + (size_t)s.n0 * 16;
+        wrA[0] = *reinterpret_cast<const u32x4*>(w + vo_m[0]);
+        wrA[3] = *reinterpret_cast<const u32x4*>(w + (size_t)g.w2_gimage + vo_c[0]);
+      } else {
+        const char* mb = wg + (size_t)cc * chunk_b + (size_t)s.n0 * 16;  // memory row (i * 3 + 0) * 4 + pw
+        const char* cb = mb + (size_t)g.w_gimage;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wrA[i] = *reinterpret_cast<const u32x4*>(mb + vo_m[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wrA[3 + j] = *reinterpret_cast<const u32x4*>(cb + vo_c[j]);
+      }
+    };
     Step cur = {-1, -1, 0, 0, 0, 0};
     advance(cur);
-    load_window(cur, 0, 2);
+    load_window(cur, 0, 3);
+    load_col0(cur, false);
     int ring_n0 = -1;
     bool prev_fill = false;
     for (int k = 0; k < S; ++k) {
@@ -377,23 +401,10 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
           ev = u32x4{__float_as_uint(a.x + b.x), __float_as_uint(a.y + b.y), __float_as_uint(a.z + b.z), __float_as_uint(a.w + b.w)};
         }
       }
-      // ---- column 0 (+ the window's last round) ----
-      if (w3) {
-        const char* mb = wcur;  // memory row (i * 3 + 0) * 4 + pw
-        const char* cb = wcur + gim;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) wrA[i] = *reinterpret_cast<const u32x4*>(mb + vo_m[i]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) wrA[3 + j] = *reinterpret_cast<const u32x4*>(cb + vo_c[j]);
-      } else if (w1) {
-        wrA[0] = *reinterpret_cast<const u32x4*>(wcur + vo_m[0]);
-        wrA[3] = *reinterpret_cast<const u32x4*>(wcur + gim + vo_c[0]);
-      }
-      load_window(cur, 2, 3);
       FL_STAMP(0);
       if (k >= 1) FL_MPOLL(sCR, 8u * (unsigned)k, d.fault);  // every consumer holds column 0 of step k - 1 in registers
       FL_STAMP(1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // column 0 (and everything older: the constants, window rounds 0 / 1) has landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // column 0, the window (requested a step ago) and the constants have landed
       FL_STAMP(2);
       if (epi_step) {
         float* slot = sEpi + (cur.ord & 1) * (G::EPI / 4);
@@ -426,21 +437,21 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
       FL_STAMP(3);
       if (k >= 2) FL_MPOLL(sWR + (k & 1), 8u * (unsigned)(k >> 1), d.fault);  // the consumers left the buffer in step k - 2
       FL_STAMP(4);
-      store_window(second, w3 ? 13 : 0, sWin + (k & 1) * WBUF);
+      store_window(second, sWin + (k & 1) * WBUF);
       sp_wait_lds();
       if (lane == 0) sp_bump(sWL + (k & 1));
       FL_STAMP(5);
-      // the NEXT step's window, rounds 0 and 1: a step ahead of their conversion (behind the last step: the same ones once more)
+      // the NEXT step's window: a step ahead of its conversion (behind the last step: the same one once more, never used)
       Step nxt = cur;
       if (k + 1 < S) advance(nxt);
-      load_window(nxt, 0, 2);
+      load_window(nxt, 0, 3);
       FL_STAMP(6);
       // (the rule behind a filling step: conv_sp_movers.inc)
       const bool after_fill = prev_fill;
       prev_fill = w3;
       if (k >= 1 && (w3 || after_fill)) FL_MPOLL(sCR + 1, 8u * (unsigned)k, d.fault);
       if (w3) {
-        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // column 1 has landed (behind it: 6 pieces of column 2, 8 window loads)
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // column 1 has landed (behind it: 6 pieces of column 2, 12 window loads)
 #pragma unroll
         for (int i = 0; i < 7; ++i) *reinterpret_cast<u32x4*>(dlane + G::RING1 + (i < 3 ? 4 * i : 12 + 4 * (i - 3)) * 1024) = wrB[i];
       }
@@ -449,12 +460,15 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
       FL_STAMP(7);
       if (k >= 1 && (w3 || after_fill)) FL_MPOLL(sCR + 2, 8u * (unsigned)k, d.fault);
       if (w3) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(dlane + G::RING2 + (i < 3 ? 4 * i : 12 + 4 * (i - 3)) * 1024) = wrA[i];
       }
       sp_wait_lds();
       if (lane == 0) sp_bump(sCL + 2);
+      // column 0 of the NEXT step, into the registers column 2 has just left: in flight while the consumers of this step's
+      // predecessor are still a third of a step from releasing slot 0
+      if (k + 1 < S) load_col0(nxt, nck == 1 && nxt.n0 == cur.n0);
       FL_STAMP(8);
       cur = nxt;
     }
@@ -520,13 +534,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
     // cross-term products of one pair over the wave's four rows: the fragment of row r + 1 is requested before the
     // instructions of row r (the compiler barrier keeps the request order; left alone the scheduler hoists every read of a
     // column to its top and spills)
-    // (FL_CROSS_P: row 0's fragment was requested by the caller, in front of a ring-slot release that only waits for the reads
-    //  issued BEFORE it - a release that drains the whole LDS queue costs a fragment latency with an idle pipe, five per step)
-#ifdef DRS_FL_FULLDRAIN  // experiment: every release drains the queue
-#define FL_WAIT_BUT(n) sp_wait_lds()
-#else
-#define FL_WAIT_BUT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
-#endif
+    // (Releasing a ring slot behind a COUNTED wait - only the reads issued before the release, with the next fragment already
+    //  requested - was measured: no gain, and the fragment held across the release cost registers the step loop does not have.)
 #define FL_CROSS(XQ, W) { const i32x8 x0_ = XQ(0); FL_CROSS_P(XQ, W, x0_) }
 #ifdef DRS_FL_X_NOCROSS  // speed experiment (wrong numbers): no cross-term fragments / instructions
 #undef FL_CROSS
@@ -547,7 +556,8 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
 #endif
     // fp16 products of kernel column `col` (weights wm[ky]); PRE: the main weight fragments of the next column (ring offset
     // `next`) replace wm[ky] as soon as the last window row that needs the old ones has been issued
-    auto main_col = [&](const char* buf, int col, bool pre, int next, unsigned ltarget, u32x4 af) __attribute__((always_inline)) {  // af: the fragment of window row 0
+    auto main_col = [&](const char* buf, int col, bool pre, int next, unsigned ltarget) __attribute__((always_inline)) {
+      u32x4 af = mfrag(buf, col);
 #pragma unroll
       for (int wr = 0; wr < RPW + 2; ++wr) {
         u32x4 afn = af;
@@ -627,12 +637,10 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
             for (int t = 0; t < NT; ++t) wm[ky][t] = wmain(G::RING0, ky, t);
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_full(G::RING0 + G::CROSS, t);
-          asm volatile("" ::: "memory");
-          const u32x4 af0 = mfrag(buf, 0);
-          FL_WAIT_BUT(1);  // everything but the window fragment just requested
+          sp_wait_lds();
           fl_bump_prio(sCR, 8u * (unsigned)k, lane);  // slot 0 is in registers
           FL_STAMP(2);
-          main_col(buf, 0, true, G::RING1, ltarget, af0);
+          main_col(buf, 0, true, G::RING1, ltarget);
           FL_STAMP(3);
 #define XQ0(r_) xq_row(buf, (r_) * IW)
           FL_CROSS(XQ0, wq)
@@ -645,18 +653,16 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
           i32x8 wq[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_full(G::RING1 + G::CROSS, t);
-          main_col(buf, 1, true, G::RING2, ltarget, mfrag(buf, 1));
+          main_col(buf, 1, true, G::RING2, ltarget);
           FL_STAMP(5);
 #define XQ1(r_) xq_row(buf, (r_) * IW + 1)
 #define XQ2(r_) xq_col(buf, ((r_) + 2) * IW)
           FL_CROSS(XQ1, wq)
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_full(G::RING1 + G::CROSS + 8192, t);
-          asm volatile("" ::: "memory");
-          const i32x8 x20 = XQ2(0);
-          FL_WAIT_BUT(2);
+          sp_wait_lds();
           fl_bump_prio(sCR + 1, 8u * (unsigned)k, lane);
-          FL_CROSS_P(XQ2, wq, x20)
+          FL_CROSS(XQ2, wq)
           FL_STAMP(6);
         }
         // ---- column 2: pair 3 = (c2k0 | c2k1), pair 4 = (c2k2 | -) ----
@@ -664,18 +670,16 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
           i32x8 wq[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_full(G::RING2 + G::CROSS, t);
-          main_col(buf, 2, false, 0, 0u, mfrag(buf, 2));
+          main_col(buf, 2, false, 0, 0u);
           FL_STAMP(7);
 #define XQ3(r_) xq_row(buf, (r_) * IW + 2)
 #define XQ4(r_) xq_half(buf, ((r_) + 2) * IW + 2)
           FL_CROSS(XQ3, wq)
 #pragma unroll
           for (int t = 0; t < NT; ++t) wq[t] = wq_half(G::RING2 + G::CROSS + 8192, t);
-          asm volatile("" ::: "memory");
-          const i32x8 x40 = XQ4(0);
-          FL_WAIT_BUT(2);
+          sp_wait_lds();
           fl_bump_prio(sCR + 2, 8u * (unsigned)k, lane);
-          FL_CROSS_P(XQ4, wq, x40)
+          FL_CROSS(XQ4, wq)
         }
         sp_wait_lds();  // the last window fragment has been read: the buffer may be refilled (for step k + 2)
         if (lane == 0) sp_bump(sWR + (k & 1));

@@ -1675,16 +1675,19 @@ extern "C" int drs_unet_forward_labels(drs_plan* plan, const void* packed, const
 extern "C" int drs_unet_check_faults(drs_plan* plan, const void* packed, drs_stream_t stream) {
   DRS_REQUIRE(plan && packed, DRS_ERR_ARG, "check_faults: null pointer");
   DRS_REQUIRE(plan->packed_ok && plan->packed_ptr == packed, DRS_ERR_STATE, "check_faults: weights not packed into this buffer");
-  unsigned word = 0;
-  DRS_CHECK_HIP(hipMemcpyAsync(&word, aligned_base(packed) + plan->o_fault, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  unsigned words[5] = {0, 0, 0, 0, 0};
+  DRS_CHECK_HIP(hipMemcpyAsync(words, aligned_base(packed) + plan->o_fault, sizeof(words), hipMemcpyDeviceToHost, (hipStream_t)stream));
   DRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  const unsigned word = words[0];
   DRS_REQUIRE((word & 1u) == 0, DRS_ERR_HIP, "a wave-specialised kernel timed out on an LDS counter (protocol fault); results are incomplete");
   if (word & 2u) {  // the FL kernel's movers met an activation block whose maximum fp16 cannot hold
     plan->fl_off = true;
-    DRS_CHECK_HIP(hipMemsetAsync(aligned_base(packed) + plan->o_fault, 0, 4, (hipStream_t)stream));
+    DRS_CHECK_HIP(hipMemsetAsync(aligned_base(packed) + plan->o_fault, 0, 32, (hipStream_t)stream));
     DRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    DrsErr::set("an activation left fp16's range in the FL arithmetic: the forward(s) since the last check are invalid; this plan "
-                "now runs the split-bf16 kernels - run the forward / chain again");
+    DrsErr::set("an activation left fp16's range in the FL arithmetic (last report: layer Cin=%u Cout=%u, %u rows, %s input, block %u "
+                "round %u lane %u, block scale exponent %u): the forward(s) since the last check are invalid; this plan now runs the "
+                "split-bf16 kernels - run the forward / chain again", words[1] >> 16, words[1] & 0xffffu, words[2] >> 16,
+                (words[2] & 1u) ? "second (1x1)" : "3x3", words[3] >> 16, (words[3] >> 8) & 0xffu, words[3] & 0xffu, words[4]);
     return DRS_ERR_RANGE;
   }
   return DRS_OK;

@@ -71,22 +71,85 @@ def reference_noise(c, h, w, noise_level1=2, noise_level2=25):
     return np.ascontiguousarray(noise)
 
 
-def add_reference_noise(x, noise_level1=2, noise_level2=10):
-    """In place: x (N, C, H, W) float32 on the device += the reference's noise, item by item in batch order, clipped to
-    [0, 1] (the dataset item's `add_Gaussian_noise(x, noise_level1=2, noise_level2=10)`, utils.py:163-164)."""
-    lib = _lib.load()
+def _check_noise_target(x):
     if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
         raise RuntimeError("add_reference_noise: x must be a contiguous (N, C, H, W) float32 tensor on a ROCm device")
+
+
+def reference_noise_batch(n, c, h, w, noise_level1=2, noise_level2=10, pin=False):
+    """The noise of n consecutive dataset items (reference_noise, item by item in batch order) as one (n, h, w, c) float32 host
+    tensor; `pin`: in page-locked memory, for an asynchronous upload."""
+    noise = torch.from_numpy(np.stack([reference_noise(c, h, w, noise_level1, noise_level2) for _ in range(n)]))
+    return noise.pin_memory() if pin and torch.cuda.is_available() else noise
+
+
+def add_noise_clip_(x, noise_host):
+    """In place: x (N, C, H, W) float32 on the device += noise_host (N, H, W, C), clipped to [0, 1] (drs_add_noise_clip_f32)."""
+    _check_noise_target(x)
     n, c, h, w = x.shape
-    if n == 0:
-        return x
-    noise = np.stack([reference_noise(c, h, w, noise_level1, noise_level2) for _ in range(n)])
-    nd = torch.from_numpy(noise).to(x.device)
+    if tuple(noise_host.shape) != (n, h, w, c):
+        raise RuntimeError(f"add_noise_clip_: noise {tuple(noise_host.shape)} for a batch {tuple(x.shape)}")
+    lib = _lib.load()
+    nd = noise_host.to(x.device, non_blocking=True)
     with torch.cuda.device(x.device):
         st = lib.drs_add_noise_clip_f32(C.c_void_p(x.data_ptr()), C.c_void_p(nd.data_ptr()), n, c, h, w,
                                         C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     _lib.check(st, "drs_add_noise_clip_f32")
     return x
+
+
+def add_reference_noise(x, noise_level1=2, noise_level2=10):
+    """In place: x (N, C, H, W) float32 on the device += the reference's noise, item by item in batch order, clipped to
+    [0, 1] (the dataset item's `add_Gaussian_noise(x, noise_level1=2, noise_level2=10)`, utils.py:163-164)."""
+    _check_noise_target(x)
+    n, c, h, w = x.shape
+    if n == 0:
+        return x
+    return add_noise_clip_(x, reference_noise_batch(n, c, h, w, noise_level1, noise_level2))
+
+
+class NoisePrefetcher:
+    """The DownBlurNoise feed's host side, off the training thread: a worker draws the batches' noise AHEAD - same generators
+    (Python's `random`, numpy's global state), same order of draws as the reference's dataset items (utils.py:15-38), batch after
+    batch - into page-locked buffers, at most `depth` batches ahead; the training thread only uploads (asynchronously) and adds.
+    One 16 x 3 x 128 x 128 batch takes ~20 ms to draw, as long as a training step: drawn inline (round 4) it made the trainer
+    feed-bound by ~2.4x.  numpy's legacy generators release the GIL while they fill an array.  Nothing else in the training
+    process draws from these two generators while an epoch runs (timesteps and the diffusion noise use torch's)."""
+
+    def __init__(self, sizes, c, h, w, noise_level1=2, noise_level2=10, depth=2):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=depth)
+        self._stop = threading.Event()
+        self._error = None
+
+        def work():
+            try:
+                for n in sizes:
+                    if self._stop.is_set():
+                        return
+                    item = reference_noise_batch(n, c, h, w, noise_level1, noise_level2, pin=True)
+                    while not self._stop.is_set():
+                        try:
+                            self._q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+            except BaseException as e:  # reported on the training thread by next()
+                self._error = e
+                self._q.put(None)
+        self._t = threading.Thread(target=work, name="drs-noise-prefetch", daemon=True)
+        self._t.start()
+
+    def next(self):
+        item = self._q.get()
+        if item is None:
+            raise self._error
+        return item
+
+    def close(self):
+        self._stop.set()
+        self._t.join(timeout=5)
 
 
 def load_image_folder_u8(root_dir, image_size=None, rank=0, world_size=1, limit=None):
@@ -168,8 +231,17 @@ class DeviceSuperresFeed:
         n = self.hr.shape[0]
         order = torch.randperm(n, generator=self.generator) if self.shuffle else torch.arange(n)
         order = order.to(self.hr.device)
-        for i in range(0, n, self.batch_size):
-            x, y = downblur(self.hr[order[i:i + self.batch_size]], self.magnification_factor, self.blur_radius)
-            if self.Gauss_noise:
-                add_reference_noise(x, noise_level1=2, noise_level2=10)
-            yield x, y
+        noise = None
+        if self.Gauss_noise and n:
+            m = int(self.magnification_factor)
+            c, h, w = self.hr.shape[1], self.hr.shape[3] // m, self.hr.shape[2] // m  # (downblur's output shape: the reference's swapped Resize)
+            noise = NoisePrefetcher([min(self.batch_size, n - i) for i in range(0, n, self.batch_size)], c, h, w, 2, 10)
+        try:
+            for i in range(0, n, self.batch_size):
+                x, y = downblur(self.hr[order[i:i + self.batch_size]], self.magnification_factor, self.blur_radius)
+                if noise is not None:
+                    add_noise_clip_(x, noise.next())
+                yield x, y
+        finally:
+            if noise is not None:
+                noise.close()

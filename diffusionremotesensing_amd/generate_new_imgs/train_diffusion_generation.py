@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .. import dist as drs_dist
 from .. import hip_ops
-from ..train_diffusion_superres import Diffusion as _SuperresDiffusion, retry_on_range_fault
+from ..train_diffusion_superres import Diffusion as _SuperresDiffusion, run_reverse_chain
 from .UNet_model_generation import Residual_Attention_UNet_generation
 
 
@@ -38,7 +38,6 @@ class Diffusion(_SuperresDiffusion):
     def _predict(self, net, x_t, t, cond):
         return net(x_t, t, cond)
 
-    @retry_on_range_fault
     def sample(self, n, model, target_class=None, cfg_scale=3, input_channels=3, generate_video=False,
                noise_source=None):
         """Reference :206-259."""
@@ -63,26 +62,25 @@ class Diffusion(_SuperresDiffusion):
                                      else target_class.to(torch.int64), torch.full((n,), -1, dtype=torch.int64,
                                                                                    device=x.device)]).contiguous()
             t_rows = hip_ops.timestep_table(self.noise_steps, 2 * n, x.device)  # (row i: step i; the unguided forward takes n of the 2n)
-            first = True
-            for i in reversed(range(1, self.noise_steps)):
+            state = {"first": True}
+
+            def step(i):
                 if i > 1:
                     noise = noise_source(i, shape).to(x.device) if noise_source is not None else torch.randn_like(x)
                 else:
                     noise = None
                 if guided:
-                    eps2 = engine.forward(x.repeat(2, 1, 1, 1), t_rows[i], None, 1, labels=labels2, check_weights=first)
+                    eps2 = engine.forward(x.repeat(2, 1, 1, 1), t_rows[i], None, 1, labels=labels2, check_weights=state["first"])
                     hip_ops.sampler_step_cfg_(x, eps2[:n], eps2[n:], cfg_scale, noise, i, self.alpha, self.alpha_hat,
                                               self.beta)
                 else:
                     # cfg_scale > 0 without a class: lerp(u, u, w) == u, one forward is enough
-                    predicted_noise = engine.forward(x, t_rows[i, :n], None, 1, labels=target_class, check_weights=first)
+                    predicted_noise = engine.forward(x, t_rows[i, :n], None, 1, labels=target_class, check_weights=state["first"])
                     hip_ops.sampler_step_(x, predicted_noise, noise, i, self.alpha, self.alpha_hat, self.beta)
-                first = False
+                state["first"] = False
                 if generate_video:
                     frames.append(x.clone())
-        # a protocol fault of the wave-specialised kernels is reported through a device word instead of a trap
-        # (csrc/sp_sync.h): read it where the caller is about to consume x (one 4-byte copy + stream sync per chain)
-        engine.check_faults()
+            run_reverse_chain(engine, x, self.noise_steps, step, frames if generate_video else None)  # (reads the kernels' fault word)
         if generate_video:
             from ..video import video_maker
             video_maker(frames, os.path.join(os.getcwd(), "models_run", self.model_name, "results",

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import dist as drs_dist
 from . import hip_ops
-from .train_diffusion_superres import Diffusion as _SuperresDiffusion, retry_on_range_fault
+from .train_diffusion_superres import Diffusion as _SuperresDiffusion, run_reverse_chain
 from .UNet_model_SAR_TO_NDVI import Residual_Attention_UNet_SAR_TO_NDVI
 
 
@@ -29,7 +29,6 @@ class Diffusion(_SuperresDiffusion):
     def _predict(self, net, x_t, t, cond):
         return net(x_t, t, cond)
 
-    @retry_on_range_fault
     def sample(self, n, model, SAR_img, NDVI_channels=1, generate_video=False, noise_source=None):
         """Reference :204-249.  One (SAR_channels, S, S) image conditions all n chains; its encoder branch is computed
         once per chain instead of once per step.  `noise_source(i, shape)` as in the super-resolution sampler."""
@@ -43,11 +42,11 @@ class Diffusion(_SuperresDiffusion):
             x = (noise_source(self.noise_steps, shape) if noise_source is not None else torch.randn(shape)).to(self.device)
             x = x.contiguous()
             t_rows = hip_ops.timestep_table(self.noise_steps, n, x.device)
-            first = True
-            for i in reversed(range(1, self.noise_steps)):
-                t = t_rows[i]
-                predicted_noise = engine.forward(x, t, SAR_img, 1, reuse_cond=not first, check_weights=first)
-                first = False
+            state = {"first": True}
+
+            def step(i):
+                predicted_noise = engine.forward(x, t_rows[i], SAR_img, 1, reuse_cond=not state["first"], check_weights=state["first"])
+                state["first"] = False
                 if i > 1:
                     noise = noise_source(i, shape).to(x.device) if noise_source is not None else torch.randn_like(x)
                 else:
@@ -55,9 +54,7 @@ class Diffusion(_SuperresDiffusion):
                 hip_ops.sampler_step_(x, predicted_noise, noise, i, self.alpha, self.alpha_hat, self.beta)
                 if generate_video:
                     frames.append(x.clone())
-        # a protocol fault of the wave-specialised kernels is reported through a device word instead of a trap
-        # (csrc/sp_sync.h): read it where the caller is about to consume x (one 4-byte copy + stream sync per chain)
-        engine.check_faults()
+            run_reverse_chain(engine, x, self.noise_steps, step, frames if generate_video else None)  # (reads the kernels' fault word)
         if generate_video:
             from .video import video_maker
             video_maker(frames, os.path.join(os.getcwd(), "models_run", self.model_name, "results",

@@ -27,19 +27,37 @@ _DEGRADATIONS = ("downblur", "bsrgan", "downblurnoise")
 
 
 
-def retry_on_range_fault(fn):
-    """`sample` chains end with engine.check_faults(); DRS_ERR_RANGE (an activation left fp16's range in the FL arithmetic,
-    csrc/conv_mfma_fl.hip) invalidates the chain and switches the plan to the split-bf16 kernels: run it once more."""
-    import functools
+CHAIN_CHECK_EVERY = 128  # reverse steps between two reads of the kernels' fault word inside a sampling chain
 
-    @functools.wraps(fn)
-    def wrapper(*args, **kwargs):
-        try:
-            return fn(*args, **kwargs)
-        except _lib.RangeFault as e:
-            print(f"[drs] {e}\n[drs] re-running the chain on the split-bf16 kernels")
-            return fn(*args, **kwargs)
-    return wrapper
+
+def run_reverse_chain(engine, x, noise_steps, step, frames=None, every=CHAIN_CHECK_EVERY):
+    """The reverse loop of `Diffusion.sample` (reference :234-251): `step(i)` performs reverse step i in place on x, for i =
+    noise_steps - 1 .. 1.  Every `every` steps (and at the end) the fault word of the wave-specialised kernels is read (one
+    4-byte copy + a stream synchronisation: ~0.1 ms per 128 steps of ~1.2 ms each).  A protocol fault raises.  DRS_ERR_RANGE - an
+    activation left the range of the FL arithmetic's fp16 main operand (csrc/conv_mfma_fl.hip; chains of UNTRAINED weights do
+    that, their amplitude grows without bound) - has already switched the plan to the split-bf16 kernels: the chain goes back
+    to its last checkpoint (x as of the last clean check) and continues from there."""
+    i = noise_steps - 1
+    ckpt_i, ckpt_x, ckpt_frames, since = i, x.clone(), 0, 0
+    while i >= 1:
+        step(i)
+        i -= 1
+        since += 1
+        if since >= every or i == 0:
+            since = 0
+            try:
+                engine.check_faults()
+            except _lib.RangeFault as e:
+                print(f"[drs] {e}\n[drs] resuming the chain at step {ckpt_i} on the split-bf16 kernels")
+                x.copy_(ckpt_x)
+                i = ckpt_i
+                if frames is not None:
+                    del frames[ckpt_frames:]
+                continue
+            ckpt_i = i
+            ckpt_x.copy_(x)
+            ckpt_frames = len(frames) if frames is not None else 0
+    return x
 
 
 class Diffusion:
@@ -99,7 +117,6 @@ class Diffusion:
         return torch.randint(low=1, high=self.noise_steps, size=(n,))
 
     # -- reverse process (reference :207-255) ---------------------------------------------------
-    @retry_on_range_fault
     def sample(self, n, model, lr_img, input_channels=3, generate_video=False, noise_source=None):
         """`noise_source(i, shape)`, when given, supplies x_T (i == noise_steps) and the per-step noise z_i
         instead of torch.randn — used to drive this sampler and the oracle with identical noise."""
@@ -125,12 +142,12 @@ class Diffusion:
                 x = torch.randn(shape).to(self.device)  # CPU generator, like the reference (:230)
             x = x.contiguous()
             t_rows = hip_ops.timestep_table(self.noise_steps, n, x.device)
-            first = True
-            for i in reversed(range(1, self.noise_steps)):
-                t = t_rows[i]
-                predicted_noise = engine.forward(x, t, lr_img, self.magnification_factor, reuse_cond=not first,
-                                                 check_weights=first)
-                first = False
+            state = {"first": True}
+
+            def step(i):
+                predicted_noise = engine.forward(x, t_rows[i], lr_img, self.magnification_factor, reuse_cond=not state["first"],
+                                                 check_weights=state["first"])
+                state["first"] = False
                 if i > 1:
                     noise = noise_source(i, shape).to(x.device) if noise_source is not None else torch.randn_like(x)
                 else:
@@ -138,9 +155,9 @@ class Diffusion:
                 hip_ops.sampler_step_(x, predicted_noise, noise, i, self.alpha, self.alpha_hat, self.beta)
                 if generate_video:
                     frames.append(x.clone())
-        # a protocol fault of the wave-specialised kernels is reported through a device word instead of a trap
-        # (csrc/sp_sync.h): read it where the caller is about to consume x (one 4-byte copy + stream sync per chain)
-        engine.check_faults()
+            # (the fault word of the wave-specialised kernels - a protocol fault reports itself through it instead of a trap,
+            #  csrc/sp_sync.h - is read inside the loop, every CHAIN_CHECK_EVERY steps and at the end)
+            run_reverse_chain(engine, x, self.noise_steps, step, frames if generate_video else None)
         if generate_video:
             from .video import video_maker  # optional dependency (cv2), same call as reference :253
             video_maker(frames, os.path.join(os.getcwd(), "models_run", self.model_name, "results",

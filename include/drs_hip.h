@@ -56,7 +56,8 @@ enum {
  * entry points (noise_images, sampler steps, adam / ema, downblur, aggregate) are re-entrant.  The library's only
  * process-wide state is a mutex-guarded per-device cache of kernel attributes, plus kernel-family switches read ONCE per
  * process from the environment (A/B experiments and the variant tests; unset = the shipped defaults): DRS_SP,
- * DRS_WS, DRS_D3K, DRS_S2K, DRS_NWG, DRS_BLOCKS_PER_CU, DRS_FUSE_GATE, DRS_UPFUSE, DRS_XT_ONLY, DRS_RB0, DRS_DOWNK, DRS_SP8, DRS_CONCURRENT, DRS_DEBUG_FLAGS, DRS_TRAIN_BWD_IMPL, DRS_TRAIN_WGRAD_IMPL.
+ * DRS_FL, DRS_WS, DRS_D3K, DRS_S2K, DRS_NWG, DRS_BLOCKS_PER_CU, DRS_FUSE_GATE, DRS_UPFUSE, DRS_XT_ONLY, DRS_RB0, DRS_DOWNK, DRS_SP8,
+ * DRS_FOLD_PROJ, DRS_GATE_PSI, DRS_CONCURRENT, DRS_DEBUG_FLAGS, DRS_TRAIN_BWD_IMPL, DRS_TRAIN_WGRAD_IMPL, DRS_WGRAD, DRS_WGRAD_STREAM.
  * Human-readable message for the last non-zero status returned on this thread. */
 DRS_API const char* drs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */

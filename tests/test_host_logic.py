@@ -242,3 +242,27 @@ def test_image_folder_loader_decodes_like_the_reference_dataset(tmp_path):
     Image.fromarray(g.astype(np.uint16) * 200).save(gray / "b.png")  # mode I;16: not an 8-bit image
     with pytest.raises(ValueError):
         load_image_folder_u8(str(gray), 8)
+
+
+def test_every_environment_switch_the_library_reads_is_documented():
+    """INTEGRATION.md / README.md list exactly the names csrc passes to getenv (round 4's list still carried three retired
+    switches and missed four new ones)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for path in glob.glob(os.path.join(root, "diffusionremotesensing_amd", "csrc", "*.*")):
+        if path.endswith((".hip", ".h", ".inc")):
+            names |= set(re.findall(r'getenv\("(DRS_[A-Z0-9_]+)"\)', open(path).read()))
+    experiment_builds_only = {"DRS_SP_MAXBLOCKS", "DRS_RB0_DEBUG"}  # behind #ifdef DRS_SP_TIMELINE
+    shipped = names - experiment_builds_only
+    assert len(shipped) >= 15
+    integration = open(os.path.join(root, "INTEGRATION.md")).read()
+    readme = open(os.path.join(root, "README.md")).read()
+    header = open(os.path.join(root, "include", "drs_hip.h")).read()
+    for n in sorted(shipped):
+        assert f"`{n}`" in integration, f"{n} is read by the library but missing from INTEGRATION.md"
+        assert n in readme, f"{n} is read by the library but missing from README.md"
+        assert n in header, f"{n} is read by the library but missing from include/drs_hip.h"
+    listed = set(re.findall(r"`(DRS_[A-Z0-9_]+)`", integration[integration.index("kernel-family switches"):integration.index("A plan is driven")]))
+    assert listed - experiment_builds_only <= names, f"INTEGRATION.md lists switches the library no longer reads: {sorted(listed - names)}"

@@ -245,3 +245,28 @@ def test_feed_noise_term_consumes_the_generators_like_the_oracle():
         assert noise.shape == (10, 14, 3) and noise.dtype == np.float32
         assert np.array_equal(got, want), seed
         assert after_oracle == after_feed, seed
+
+
+def test_noise_prefetcher_draws_in_the_inline_order():
+    """The DownBlurNoise feed's worker thread (degradation.NoisePrefetcher) consumes `random` / numpy's global generator exactly
+    as the inline draws of the same batches do: same batches, bit for bit, including a ragged last batch and an early close."""
+    import random
+
+    from diffusionremotesensing_amd.degradation import NoisePrefetcher, reference_noise_batch
+    sizes = [4, 4, 4, 3]
+    random.seed(11)
+    np.random.seed(12)
+    want = [reference_noise_batch(n, 3, 8, 6, 2, 10) for n in sizes]
+    random.seed(11)
+    np.random.seed(12)
+    pre = NoisePrefetcher(sizes, 3, 8, 6, 2, 10, depth=2)
+    try:
+        got = [pre.next() for _ in sizes]
+    finally:
+        pre.close()
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)
+    pre = NoisePrefetcher([2] * 50, 3, 8, 6)  # a consumer that stops after one batch: the worker ends with it
+    pre.next()
+    pre.close()
+    assert not pre._t.is_alive()
