@@ -440,9 +440,12 @@ __global__ __launch_bounds__(768, 1) void upfuse_sp_kernel(UpFuseDesc d, int til
               for (int q = 0; q < 4; ++q) {
                 const int r = half * 2 + (q >> 1), py = q & 1;
                 const int oy = 2 * (myb + r) + py;
-                const float k = (myb + r < d.LH && oy > 0 && oy < OH - 1) ? 1.f : 0.f;  // (rows 0 / OH-1 took the row vectors)
+                // rows 0 / OH-1 took the row vectors, and ev HAS NO VALUE there (the edge kernel does not write those rows: whatever
+                // the workspace held): selected, not multiplied by 0 - 0 x NaN is NaN (found in round 5, once a previous test's
+                // unbounded chain had left NaNs in the allocator's memory; finite garbage x 0 had hidden it since round 3)
+                const bool k = myb + r < d.LH && oy > 0 && oy < OH - 1;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[r][py][0][j] += k * e8[q][j]; acc[r][py][1][j] += k * e8[q][4 + j]; }
+                for (int j = 0; j < 4; ++j) { acc[r][py][0][j] += k ? e8[q][j] : 0.f; acc[r][py][1][j] += k ? e8[q][4 + j] : 0.f; }
               }
             }
           }

@@ -779,6 +779,34 @@ def test_ring_protocol_holds_over_60000_forwards(dev, seeded_sd_gen):
     assert _alternating_forwards_are_bit_stable(geng, xs, ts, None, 1, 20000, labels=labels) == 0
 
 
+@pytest.mark.parametrize("shape", [(3, 128), (1, 64), (2, 96)])
+def test_forward_reads_nothing_it_did_not_write(dev, seeded_sd, shape):
+    """The workspace is caller-owned, uninitialised memory.  Filled with NaN bit patterns (and then with +inf) before a
+    forward, the result must be bit-identical to the first run's: a kernel that reads a location nobody wrote - and hides it
+    behind a multiplication by zero, a ReLU or a masked store - shows up.  (Round 5: `upfuse_sp_kernel` multiplied the
+    never-written rows 0 / OH-1 of its column edge vector by 0; finite garbage had hidden that since round 3.)"""
+    from diffusionremotesensing_amd import synthetic
+    from diffusionremotesensing_amd.UNet_model_superres import Residual_Attention_UNet_superres
+    b, s_ = shape
+    model = Residual_Attention_UNet_superres(3, 3, dev)
+    model.load_state_dict(seeded_sd)
+    model = model.to(dev).eval()
+    eng = model.hip_engine()
+    eng.set_impl("mfma_bf16x3")
+    x = synthetic.tensor_normal("poison.x", (b, 3, s_, s_)).to(dev)
+    lr = synthetic.tensor_uniform("poison.lr", (b, 3, s_ // 2, s_ // 2)).to(dev)
+    t = torch.arange(b, device=dev) * 400 + 7
+    with torch.no_grad():
+        want = eng.forward(x, t, lr, 2, reuse_cond=False).clone()
+        ws = eng._last_plan.workspace
+        for pattern in (0x7FC00000, 0x7F800000, 0xFFFFFFFF):
+            ws.view(torch.int32)[: ws.numel() // 4].fill_(pattern - (1 << 32) if pattern >= (1 << 31) else pattern)
+            got = eng.forward(x, t, lr, 2, reuse_cond=False)
+            assert torch.isfinite(got).all(), hex(pattern)
+            assert torch.equal(got, want), hex(pattern)
+    eng.check_faults()
+
+
 def test_nan_reaches_the_output(dev, seeded_sd):
     """A NaN in one image of the batch (in x, and in the conditioning image) must come out of the network as a non-finite
     output of THAT image - through every ReLU (drs_maxf: IEEE maximum, like torch.relu; v_max_f32 would turn it into 0) and the
