@@ -98,8 +98,10 @@ struct FlHalf { u32x4 m0, m1; unsigned qm[3], qr[3]; unsigned sm, sr; bool over;
 __device__ __forceinline__ unsigned fl_block_exp(const f16x2 (&v)[8], bool& over) {  // biased (E8M0) exponent of the lane pair's block scale
   f16x2 mx = v[0], mn = v[0];
 #pragma unroll
-  for (int d = 1; d < 8; ++d) { mx = __builtin_elementwise_max(mx, v[d]); mn = __builtin_elementwise_min(mn, v[d]); }
-  const f16x2 am = __builtin_elementwise_max(mx, -mn);  // |.| maxima of the even / odd elements (non-negative: ordered as integers)
+  // (IEEE maximum / minimum: hipcc folds the chains into v_pk_maximum3_f16 / v_pk_minimum3_f16 - 8 instructions instead of 15 -
+  //  and a NaN element reaches the result, where `over` catches it)
+  for (int d = 1; d < 8; ++d) { mx = __builtin_elementwise_maximum(mx, v[d]); mn = __builtin_elementwise_minimum(mn, v[d]); }
+  const f16x2 am = __builtin_elementwise_maximum(mx, -mn);  // |.| maxima of the even / odd elements (non-negative: ordered as integers)
   const unsigned ab = __builtin_bit_cast(unsigned, am);
   unsigned a16 = max(ab & 0xffffu, ab >> 16);
   a16 = max(a16, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a16, 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]: the pair's other lane
