@@ -166,15 +166,21 @@ __device__ __forceinline__ void tile_epilogue(const TapConv& d, f32x4 (&acc)[RPW
 __device__ __forceinline__ int drs_sp_group_bytes(int cs) { return cs >= 32 ? 64 : cs * 2; }  // bytes of the hi half of a group
 
 typedef __bf16 drs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float drs_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 drs_bf16x2 __attribute__((ext_vector_type(2)));
+// hi = bf16(v) (round to nearest even), lo = bf16(v - hi), two values at a time: one v_cvt_pk_bf16_f32 per pair and part, the
+// pair's remainders by one v_pk_add_f32 (element-wise conversions cost a conversion per VALUE and a merge per dword: the item
+// epilogue of the wave-specialised kernels was ~830 vector instructions per wave, 6 - 7 k cycles with two waves per SIMD)
 __device__ __forceinline__ void drs_sp_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
-  drs_bf16x8 h, l;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    h[j] = (__bf16)v[j];
-    l[j] = (__bf16)(v[j] - (float)h[j]);
+  for (int p = 0; p < 4; ++p) {
+    const drs_f32x2 x = {v[2 * p], v[2 * p + 1]};
+    const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, drs_bf16x2));
+    const drs_f32x2 hf = {__uint_as_float(hu << 16), __uint_as_float(hu & 0xffff0000u)};
+    const drs_f32x2 r = x - hf;
+    hi[p] = hu;
+    lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, drs_bf16x2));
   }
-  hi = __builtin_bit_cast(u32x4, h);
-  lo = __builtin_bit_cast(u32x4, l);
 }
 typedef __bf16 drs_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void drs_sp_split4(const float (&v)[4], unsigned (&hi)[2], unsigned (&lo)[2]) {  // half a slot
@@ -314,9 +320,11 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
                                                      int ty0, int tx0, int wave, int lr, int kg) {
   const bool lo = lr < 8;
   const int pl = lr & 7;
-  // (the two optional ReLUs as maximum(v, bound) with a launch-uniform bound, 0 or -inf: one instruction per value instead of
-  // a max and a select on the flag; drs_maxf propagates a NaN accumulator whether the ReLU is on or off)
-  const float lo_pre = d.relu_pre ? 0.f : -__builtin_inff(), lo_post = d.relu_post ? 0.f : -__builtin_inff();
+  // Written for FEW vector instructions (this epilogue runs on all eight consumer waves at once with the matrix pipe idle):
+  // the affine part two values at a time (v_pk_add_f32), the two optional ReLUs behind launch-uniform branches (as
+  // maximum(v, flag ? 0 : -inf) they compiled to a maximum AND a select per value), the hi / lo exchange with the lane 8
+  // further by bank-masked DPP moves that leave the other half of the row untouched (no selects).  drs_maxf propagates a NaN.
+  const bool relu_pre = d.relu_pre != 0, relu_post = d.relu_post != 0;
   const int tyb = ty0 + wave * RPW;
   const size_t pix0 = ((size_t)n * d.OH + tyb) * d.OW + tx0 + pl;  // (out_scale 1, no phase offset: 3x3 stride 1)
   const int lane_b = (lo ? 0 : 64) + kg * 16;
@@ -325,19 +333,35 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
   const size_t row1 = (size_t)d.OW * d.out_cs * 4, row2 = OUT2 ? (size_t)d.OW * d.out2_cs * 4 : 0;
   const int h1 = 8 * d.out_cs * 4, h2 = OUT2 ? 8 * d.out2_cs * 4 : 0;
   const bool ok0 = tx0 + pl < d.TW, ok1 = tx0 + pl + 8 < d.TW;
+  drs_f32x2 kb[4], kp[4], kq[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    kb[p] = drs_f32x2{k.bias[2 * p], k.bias[2 * p + 1]};
+    kp[p] = drs_f32x2{k.post[2 * p], k.post[2 * p + 1]};
+    kq[p] = drs_f32x2{k.post2[2 * p], k.post2[2 * p + 1]};
+  }
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     if (tyb + r < d.TH) {
-      float v[8];
+      drs_f32x2 v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = acc[r][0][j] + k.bias[j]; v[4 + j] = acc[r][1][j] + k.bias[4 + j]; }
+      for (int p = 0; p < 4; ++p) v[p] = drs_f32x2{acc[r][p >> 1][2 * (p & 1)], acc[r][p >> 1][2 * (p & 1) + 1]} + kb[p];
+      if (relu_pre) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = drs_maxf(drs_maxf(v[j], lo_pre) + k.post[j], lo_post);
+        for (int p = 0; p < 4; ++p) v[p] = drs_f32x2{drs_maxf(v[p][0], 0.f), drs_maxf(v[p][1], 0.f)};
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) v[p] = v[p] + kp[p];
+      if (relu_post) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v[p] = drs_f32x2{drs_maxf(v[p][0], 0.f), drs_maxf(v[p][1], 0.f)};
+      }
 #ifdef DRS_X_NOAFFINE
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = acc[r][0][j]; v[4 + j] = acc[r][1][j]; }
+      for (int p = 0; p < 4; ++p) v[p] = drs_f32x2{acc[r][p >> 1][2 * (p & 1)], acc[r][p >> 1][2 * (p & 1) + 1]};
 #endif
-      auto put = [&](char* g, int hb, const float (&w8)[8]) __attribute__((always_inline)) {
+      auto put = [&](char* g, int hb, const drs_f32x2 (&w2)[4]) __attribute__((always_inline)) {
+        const float w8[8] = {w2[0][0], w2[0][1], w2[1][0], w2[1][1], w2[2][0], w2[2][1], w2[3][0], w2[3][1]};
         u32x4 H, L;
 #ifdef DRS_X_NOSPLIT
         H = u32x4{__float_as_uint(w8[0]), __float_as_uint(w8[1]), __float_as_uint(w8[2]), __float_as_uint(w8[3])};
@@ -349,17 +373,25 @@ __device__ __forceinline__ void tile_epilogue_sp_pre(const TapConv& d, f32x4 (&a
         if (ok0) drs_store16(g, H);
         if (ok1) drs_store16(g + hb, L);
 #else
-        const u32x4 got = drs_dpp_swap8(lo ? L : H);  // lr < 8 receives the partner's hi, lr >= 8 the partner's lo
-        if (ok0) drs_store16(g, lo ? H : got);
-        if (ok1) drs_store16(g + hb, lo ? got : L);
+        // first store: lanes lr < 8 their own hi, lanes lr >= 8 the lo of the lane 8 below; second store: lanes lr < 8 the hi of
+        // the lane 8 above, lanes lr >= 8 their own lo.  row_ror:8 = the lane lr ^ 8 of the 16-lane row; bank mask 0xc writes
+        // lanes 8 - 15 only, 0x3 lanes 0 - 7 only; the rest keeps `old`.
+        u32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[j] = (unsigned)__builtin_amdgcn_update_dpp((int)H[j], (int)L[j], 0x128, 0xf, 0xc, false);
+          b[j] = (unsigned)__builtin_amdgcn_update_dpp((int)L[j], (int)H[j], 0x128, 0xf, 0x3, false);
+        }
+        if (ok0) drs_store16(g, a);
+        if (ok1) drs_store16(g + hb, b);
 #endif
       };
       if (o1) put(o1 + r * row1, h1, v);
       if constexpr (OUT2) {
         if (o2) {
-          float p2[8];
+          drs_f32x2 p2[4];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) p2[j] = v[j] + k.post2[j];
+          for (int p = 0; p < 4; ++p) p2[p] = v[p] + kq[p];
           put(o2 + r * row2, h2, p2);
         }
       }
