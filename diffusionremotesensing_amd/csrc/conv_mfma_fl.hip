@@ -687,7 +687,11 @@ __global__ __launch_bounds__(768, 1) void tapconv_fl_kernel(TapConv d, MfmaGeom 
         if (lane == 0) sp_bump(sWR + (k & 1));
         FL_STAMP(8);
       }
+#ifdef DRS_FL_X_NOEPI  // speed experiment (wrong numbers): what the item epilogues cost
+      if (c == nck - 1 && k + 1 == S) {
+#else
       if (c == nck - 1) {
+#endif
         int lr_e = lr, kg_e = kg;  // (opaque copies: conv_mfma_sp.hip)
         asm volatile("" : "+v"(lr_e), "+v"(kg_e));
         const float* ek = sEpi + (ord & 1) * (G::EPI / 4);
