@@ -14,6 +14,7 @@ Deliberately different (documented in DESIGN.md):
 """
 import copy
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -48,7 +49,7 @@ def run_reverse_chain(engine, x, noise_steps, step, frames=None, every=CHAIN_CHE
             try:
                 engine.check_faults()
             except _lib.RangeFault as e:
-                print(f"[drs] {e}\n[drs] resuming the chain at step {ckpt_i} on the split-bf16 kernels")
+                print(f"[drs] {e}\n[drs] resuming the chain at step {ckpt_i} on the split-bf16 kernels", file=sys.stderr)
                 x.copy_(ckpt_x)
                 i = ckpt_i
                 if frames is not None:

@@ -53,6 +53,20 @@ def test_bench_py_under_torchrun_initialises_rccl():
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"].get("process_group") == "nccl"
 
 
+def test_bench_py_prints_exactly_one_line_on_stdout():
+    """The driver's contract: rank 0 prints ONE JSON line.  Run with the extras the default invocation has (both 1499-step
+    chains - the untrained one leaves fp16's range mid-chain and resumes on the split-bf16 kernels, with a notice that must
+    go to stderr - and the other configs); only the CPU baseline is skipped."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:-1]
+    res = json.loads(lines[0])
+    assert res["value"] > 0 and res["roofline"]["frac"] > 0 and res["full_chain"]["finite"]
+    assert res["full_chain_untrained_weights"]["finite"]
+
+
 def test_two_ranks_share_one_gpu_train_step():
     """World size 2 on device memory: two processes on the one leased GPU (gloo process group: RCCL needs a device per rank),
     each running the HIP training step on its own shard - the flat in-place gradient exchange, FusedAdam behind it, identical
