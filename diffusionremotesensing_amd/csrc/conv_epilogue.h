@@ -166,32 +166,15 @@ __device__ __forceinline__ void tile_epilogue(const TapConv& d, f32x4 (&acc)[RPW
 __device__ __forceinline__ int drs_sp_group_bytes(int cs) { return cs >= 32 ? 64 : cs * 2; }  // bytes of the hi half of a group
 
 typedef __bf16 drs_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float drs_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 drs_bf16x2 __attribute__((ext_vector_type(2)));
-// hi = bf16(v) (round to nearest even), lo = bf16(v - hi), two values at a time: one v_cvt_pk_bf16_f32 per pair and part, the
-// pair's remainders by one v_pk_add_f32 (element-wise conversions cost a conversion per VALUE and a merge per dword: the item
-// epilogue of the wave-specialised kernels was ~830 vector instructions per wave, 6 - 7 k cycles with two waves per SIMD)
+// hi = bf16(v), lo = bf16(v - hi) of 8 values (drs_split2: two values per conversion instruction; the item epilogue of the
+// wave-specialised kernels was ~830 vector instructions per wave with element-wise conversions)
 __device__ __forceinline__ void drs_sp_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const drs_f32x2 x = {v[2 * p], v[2 * p + 1]};
-    const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, drs_bf16x2));
-    const drs_f32x2 hf = {__uint_as_float(hu << 16), __uint_as_float(hu & 0xffff0000u)};
-    const drs_f32x2 r = x - hf;
-    hi[p] = hu;
-    lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, drs_bf16x2));
-  }
+  for (int p = 0; p < 4; ++p) { const uint2 s_ = drs_split2(v[2 * p], v[2 * p + 1]); hi[p] = s_.x; lo[p] = s_.y; }
 }
-typedef __bf16 drs_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void drs_sp_split4(const float (&v)[4], unsigned (&hi)[2], unsigned (&lo)[2]) {  // half a slot
-  drs_bf16x4 h, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    h[j] = (__bf16)v[j];
-    l[j] = (__bf16)(v[j] - (float)h[j]);
-  }
-  const uint2 hh = __builtin_bit_cast(uint2, h), ll = __builtin_bit_cast(uint2, l);
-  hi[0] = hh.x; hi[1] = hh.y; lo[0] = ll.x; lo[1] = ll.y;
+  { const uint2 s_ = drs_split2(v[0], v[1]); hi[0] = s_.x; lo[0] = s_.y; }
+  { const uint2 s_ = drs_split2(v[2], v[3]); hi[1] = s_.x; lo[1] = s_.y; }
 }
 __device__ __forceinline__ void drs_sp_join8(const u32x4& hi, const u32x4& lo, float (&v)[8]) {
   const drs_bf16x8 h = __builtin_bit_cast(drs_bf16x8, hi), l = __builtin_bit_cast(drs_bf16x8, lo);

@@ -316,15 +316,11 @@ __global__ __launch_bounds__(768, 1) void tapconv_ws_kernel(TapConv d, MfmaGeom 
     for (int it = 0; it < CV_ITERS; ++it) {
       if (it < CV_ITERS - 1 || tid + it * 512 < NQUAD) {
         if constexpr (P::IMAGES == 2) {
-          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-          bf16x4 h, l;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            h[j] = (__bf16)v[it][j];
-            l[j] = (__bf16)(v[it][j] - (float)h[j]);
-          }
-          *reinterpret_cast<bf16x4*>(sA + cv_dst[it]) = h;
-          *reinterpret_cast<bf16x4*>(sA + cv_dst[it] + A_IMAGE) = l;
+          uint2 h, l;
+          { const uint2 s_ = drs_split2(v[it][0], v[it][1]); h.x = s_.x; l.x = s_.y; }
+          { const uint2 s_ = drs_split2(v[it][2], v[it][3]); h.y = s_.x; l.y = s_.y; }
+          *reinterpret_cast<uint2*>(sA + cv_dst[it]) = h;
+          *reinterpret_cast<uint2*>(sA + cv_dst[it] + A_IMAGE) = l;
         } else {
           *reinterpret_cast<f32x4*>(sA + cv_dst[it]) = v[it];
         }

@@ -143,6 +143,20 @@ void drs_note_launch(const void* kernel_fn, const char* expr);
 // CU count.  Keyed by device, mutex-protected: correct with several devices in one process and from several host threads.
 int drs_kernel_prepare(const void* kernel, int max_dynamic_lds, int* num_cu);
 
+// ---- split bf16 of TWO fp32 values: hi = bf16(x) (round to nearest even), lo = bf16(x - hi), packed [first | second << 16] ----
+// One v_cvt_pk_bf16_f32 per pair and part and one v_pk_add_f32 for the pair's remainders; element-wise `(__bf16)x`
+// conversions compile to one conversion per VALUE plus a merge per dword (twice the vector instructions).
+#ifdef __HIPCC__
+typedef float drs_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 drs_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 drs_split2(float a, float b) {  // .x = hi pair, .y = lo pair
+  const drs_f32x2 x = {a, b};
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, drs_bf16x2));
+  const drs_f32x2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  return uint2{hi, __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, drs_bf16x2))};
+}
+#endif
+
 // ---- kernel launchers (each returns a DRS_* status) ------------------------------------------
 int drs_launch_tapconv_direct(const TapConv& d, hipStream_t s);
 int drs_launch_tapconv_mfma(const TapConv& d, int impl, hipStream_t s);

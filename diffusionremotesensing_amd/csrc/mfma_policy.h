@@ -43,14 +43,11 @@ struct PolicyBF16X3 {  // x = hi + lo (both bf16, 16 mantissa bits together): w*
   static constexpr int SLOT_CH = 8, IMAGES = 2, IMPL = DRS_IMPL_MFMA_BF16X3;
   struct Frag { bf16x8 hi, lo; };
   __device__ static void cvt_store(char* base, size_t img_stride, size_t off, const float* x) {
-    bf16x8 h, l;
+    u32x4 h, l;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      h[j] = (__bf16)x[j];
-      l[j] = (__bf16)(x[j] - (float)h[j]);
-    }
-    *reinterpret_cast<bf16x8*>(base + off) = h;
-    *reinterpret_cast<bf16x8*>(base + img_stride + off) = l;
+    for (int p = 0; p < 4; ++p) { const uint2 s_ = drs_split2(x[2 * p], x[2 * p + 1]); h[p] = s_.x; l[p] = s_.y; }
+    *reinterpret_cast<u32x4*>(base + off) = h;
+    *reinterpret_cast<u32x4*>(base + img_stride + off) = l;
   }
   __device__ static Frag load(const char* base, size_t img_stride, size_t off) {
     return Frag{*reinterpret_cast<const bf16x8*>(base + off), *reinterpret_cast<const bf16x8*>(base + img_stride + off)};

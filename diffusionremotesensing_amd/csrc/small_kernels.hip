@@ -115,15 +115,14 @@ __global__ void sp_add_rowvec_kernel(const char* __restrict__ src, char* __restr
     const int64_t off = (pix * C + grp * 32) * 4 + kg * 16;
     const bf16x8_t h = *reinterpret_cast<const bf16x8_t*>(src + off), l = *reinterpret_cast<const bf16x8_t*>(src + off + 64);
     const float* v = vec + (int64_t)n * vec_stride + grp * 32 + kg * 8;
-    bf16x8_t oh, ol;
+    float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = (float)h[j] + (float)l[j] + v[j];
-      oh[j] = (__bf16)x;
-      ol[j] = (__bf16)(x - (float)oh[j]);
-    }
-    *reinterpret_cast<bf16x8_t*>(dst + off) = oh;
-    *reinterpret_cast<bf16x8_t*>(dst + off + 64) = ol;
+    for (int j = 0; j < 8; ++j) x[j] = (float)h[j] + (float)l[j] + v[j];
+    u32x4 oh, ol;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const uint2 s_ = drs_split2(x[2 * q], x[2 * q + 1]); oh[q] = s_.x; ol[q] = s_.y; }
+    *reinterpret_cast<u32x4*>(dst + off) = oh;
+    *reinterpret_cast<u32x4*>(dst + off + 64) = ol;
   }
 }
 static inline int ew_blocks(int64_t total) {
@@ -341,17 +340,13 @@ __global__ __launch_bounds__(256, DRS_STEM_BPC) void stem_kernel(const float* __
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is rewritten below
       }
       if (out_sp) {  // SP format (drs_common.h): one group of [COUT x bf16 hi | COUT x bf16 lo] per pixel
-        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #pragma unroll
         for (int co = 0; co < COUT; co += 8) {
-          bf16x8_t h, l;
+          u32x4 h, l;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            h[j] = (__bf16)acc[o][co + j];
-            l[j] = (__bf16)(acc[o][co + j] - (float)h[j]);
-          }
-          *reinterpret_cast<bf16x8_t*>(tb + lane * 64 + (((co >> 3) ^ sw_px) << 4)) = h;        // chunks 0, 1: hi halves
-          *reinterpret_cast<bf16x8_t*>(tb + lane * 64 + (((2 + (co >> 3)) ^ sw_px) << 4)) = l;  // chunks 2, 3: lo halves
+          for (int q = 0; q < 4; ++q) { const uint2 s_ = drs_split2(acc[o][co + 2 * q], acc[o][co + 2 * q + 1]); h[q] = s_.x; l[q] = s_.y; }
+          *reinterpret_cast<u32x4*>(tb + lane * 64 + (((co >> 3) ^ sw_px) << 4)) = h;        // chunks 0, 1: hi halves
+          *reinterpret_cast<u32x4*>(tb + lane * 64 + (((2 + (co >> 3)) ^ sw_px) << 4)) = l;  // chunks 2, 3: lo halves
         }
       } else {
 #pragma unroll

@@ -86,14 +86,13 @@ __global__ __launch_bounds__(256, MINB) void wgrad_bf16_kernel(WgradBf16Args g) 
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
+  // (drs_split2: the staging's vector work is of the order of the tile's matrix work, and nothing overlaps the two in this kernel)
   auto split4 = [&](const f32x4& v, s16x4& h, s16x4& l) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const __bf16 hh = (__bf16)v[j];
-      const __bf16 ll = (__bf16)(v[j] - (float)hh);
-      h[j] = __builtin_bit_cast(short, hh);
-      l[j] = __builtin_bit_cast(short, ll);
-    }
+    uint2 hu, lu;
+    { const uint2 s_ = drs_split2(v[0], v[1]); hu.x = s_.x; lu.x = s_.y; }
+    { const uint2 s_ = drs_split2(v[2], v[3]); hu.y = s_.x; lu.y = s_.y; }
+    h = __builtin_bit_cast(s16x4, hu);
+    l = __builtin_bit_cast(s16x4, lu);
   };
 
   // Staging, software-pipelined: the global loads of the NEXT tile are issued before this tile's MFMAs and converted /
