@@ -5,6 +5,8 @@
 //   mode 3  as 2, plus a partner wave per SIMD that runs packed-fp16 VALU work and ds_write_b128 (a stand-in for a mover)
 //   mode 4  as 2, plus a partner wave that only stores to LDS
 //   mode 5  as 2, plus a partner wave that only runs VALU work
+//   mode 6  as 2, the three reads one behind every fourth matrix instruction
+//   mode 7 / 8  as 2 with the matrix instructions as inline assembly, accumulators tied in arch VGPRs / in AccVGPRs
 // Prints cycles per matrix instruction (s_memtime of wave 0 of block 0) and the in-kernel clock.
 // Build: hipcc --offload-arch=gfx950 -O3 -o issue_probe issue_probe.hip ; run: ./issue_probe [slots]
 #include <hip/hip_runtime.h>
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(512) void k(const int* __restrict__ src, float* __r
   __syncthreads();
   const bool partner = wid >= 4;
   if (partner) {
-    if (MODE < 3) return;
+    if (MODE < 3 || MODE >= 6) return;
     f16x2 v[8];
     for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(f16x2, src[(tid + i) & 8191]);
     u32x4 w = {1u, 2u, 3u, 4u};
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(512) void k(const int* __restrict__ src, float* __r
   for (int s = 0; s < slots; ++s) {
     u32x4 afn = af;
     i32x8 xn = xq;
-    if (MODE >= 2 && MODE != 6) {
+    if (MODE >= 2 && MODE != 6) {  // (modes 7 / 8: as mode 2)
       const char* p = base + ((s & 1) ? 3072 : 0);
       afn = *reinterpret_cast<const u32x4*>(p);
       const u32x4 a = *reinterpret_cast<const u32x4*>(p + 1024), b = *reinterpret_cast<const u32x4*>(p + 2048);
@@ -83,6 +85,9 @@ __global__ __launch_bounds__(512) void k(const int* __restrict__ src, float* __r
     u32x4 ra = {0u, 0u, 0u, 0u}, rb = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
+      if (MODE == 7) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[i]) : "v"(wa[i]), "v"(af));  // accumulator tied, arch VGPRs
+      else if (MODE == 8) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c[i]) : "v"(wa[i]), "v"(af));  // ... in AccVGPRs
+      else
       c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wa[i]), __builtin_bit_cast(f16x8, af), c[i], 0, 0, 0);
       if (MODE == 6 && (i == 1 || i == 5 || i == 9)) {  // mode 6: the three reads of mode 2, one behind every fourth instruction
         const char* p = base + ((s & 1) ? 3072 : 0);
@@ -97,6 +102,12 @@ __global__ __launch_bounds__(512) void k(const int* __restrict__ src, float* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (MODE == 0) c[12 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wa[i]), __builtin_bit_cast(f16x8, af), c[12 + i], 0, 0, 0);
+      else if (MODE == 7 || MODE == 8) {
+        typedef int i32x6 __attribute__((ext_vector_type(6)));
+        const i32x6 w6 = __builtin_shufflevector(wq[i], wq[i], 0, 1, 2, 3, 4, 5), x6 = __builtin_shufflevector(xq, xq, 0, 1, 2, 3, 4, 5);
+        if (MODE == 7) asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(c[12 + i]) : "v"(w6), "v"(x6), "v"(wq[i][6]), "v"(xq[6]));
+        else asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+a"(c[12 + i]) : "v"(w6), "v"(x6), "v"(wq[i][6]), "v"(xq[6]));
+      }
       else c[12 + i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq[i], xq, c[12 + i], 2, 2, 0, wq[i][6], 0, xq[6]);
     }
     af = afn;
@@ -201,6 +212,8 @@ int main(int argc, char** argv) {
     run<4>("4 + partner wave: LDS stores only", blocks, slots, src, out, clk);
     run<5>("5 + partner wave: VALU only", blocks, slots, src, out, clk);
     run<6>("6 as 2, reads interleaved with the matrix instructions", blocks, slots, src, out, clk);
+    run<7>("7 as 2, inline assembly, accumulators tied in arch VGPRs", blocks, slots, src, out, clk);
+    run<8>("8 as 2, inline assembly, accumulators in AccVGPRs", blocks, slots, src, out, clk);
   }
   return 0;
 }
