@@ -43,6 +43,12 @@ int drs_kernel_prepare(const void* kernel, int max_dynamic_lds, int* num_cu) {
     it = cus.emplace(dev, n).first;
   }
   *num_cu = it->second;
+#ifdef DRS_X_NUM_CU  // experiment (tools/two_stream_probe.py): persistent kernels size their grids for DRS_X_NUM_CU compute units
+  {
+    static const int lim = getenv("DRS_X_NUM_CU") ? atoi(getenv("DRS_X_NUM_CU")) : 0;
+    if (lim > 0 && lim < *num_cu) *num_cu = lim;
+  }
+#endif
   bool& done = attr_set[std::make_pair(dev, kernel)];
   if (!done && max_dynamic_lds > 0) {
     DRS_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_dynamic_lds));
