@@ -254,7 +254,8 @@ def test_every_environment_switch_the_library_reads_is_documented():
     for path in glob.glob(os.path.join(root, "diffusionremotesensing_amd", "csrc", "*.*")):
         if path.endswith((".hip", ".h", ".inc")):
             names |= set(re.findall(r'getenv\("(DRS_[A-Z0-9_]+)"\)', open(path).read()))
-    experiment_builds_only = {"DRS_SP_MAXBLOCKS", "DRS_RB0_DEBUG"}  # behind #ifdef DRS_SP_TIMELINE
+    experiment_builds_only = {"DRS_SP_MAXBLOCKS", "DRS_RB0_DEBUG",  # behind #ifdef DRS_SP_TIMELINE
+                              "DRS_X_NUM_CU"}  # behind #ifdef DRS_X_NUM_CU (tools/two_stream_probe.py)
     shipped = names - experiment_builds_only
     assert len(shipped) >= 15
     integration = open(os.path.join(root, "INTEGRATION.md")).read()
